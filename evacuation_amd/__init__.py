@@ -1,0 +1,27 @@
+"""evacuation_amd -- MI355X-native step path of the cinemere/evacuation environment.
+
+Public surface = the reference's ``src.env`` exports (src/env/__init__.py:3-21):
+``setup_env, EvacuationEnv, EnvConfig, EnvWrappersConfig, Status`` plus the batched form
+``BatchedEvacuationEnv`` and the sharded form ``ShardedEvacuationEnv``.  Importing the package does
+not touch the GPU; constructing an env loads libevac.so and fails loudly without it."""
+from .config import EnvConfig, EnvWrappersConfig
+from .statuses import Status
+
+__all__ = ["EnvConfig", "EnvWrappersConfig", "Status", "setup_env", "EvacuationEnv", "BatchedEvacuationEnv",
+           "ShardedEvacuationEnv", "RandomAgent"]
+
+
+def __getattr__(name):   # lazy: keeps `import evacuation_amd` light and torch-free for config users
+    if name in ("setup_env", "EvacuationEnv"):
+        from . import env as _env
+        return getattr(_env, name)
+    if name == "BatchedEvacuationEnv":
+        from .vector_env import BatchedEvacuationEnv
+        return BatchedEvacuationEnv
+    if name == "ShardedEvacuationEnv":
+        from .distributed import ShardedEvacuationEnv
+        return ShardedEvacuationEnv
+    if name == "RandomAgent":
+        from .agents import RandomAgent
+        return RandomAgent
+    raise AttributeError(name)

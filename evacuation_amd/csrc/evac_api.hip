@@ -1,0 +1,292 @@
+// Host side of the libevac C ABI (include/evac.h): argument checking, kernel dispatch by env size,
+// error reporting.  No device allocation, no synchronisation: every call only enqueues work on the
+// caller's stream, so the step can be captured into a hipGraph by the caller.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "evac_device.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+int validate(const evac_config_t* c, std::string& err) {
+    if (!c) { err = "cfg is NULL"; return EVAC_ERR_INVALID_ARGUMENT; }
+    if (c->number_of_pedestrians < 1 || c->number_of_pedestrians > EVAC_MAX_PEDESTRIANS) {
+        err = "number_of_pedestrians must be in [1, " + std::to_string(EVAC_MAX_PEDESTRIANS) + "]";
+        return EVAC_ERR_INVALID_ARGUMENT;
+    }
+    if (!(c->width > 0.f) || !(c->height > 0.f) || !(c->step_size > 0.f)) { err = "width, height, step_size must be > 0"; return EVAC_ERR_INVALID_ARGUMENT; }
+    if (c->max_timesteps < 1) { err = "max_timesteps must be >= 1"; return EVAC_ERR_INVALID_ARGUMENT; }
+    if (c->positions < EVAC_POS_ABS || c->positions > EVAC_POS_GRAV) { err = "positions must be abs|rel|grav"; return EVAC_ERR_INVALID_ARGUMENT; }
+    if (c->statuses < EVAC_STAT_NO || c->statuses > EVAC_STAT_CAT) { err = "statuses must be no|ohe|cat"; return EVAC_ERR_INVALID_ARGUMENT; }
+    if (c->type != EVAC_TYPE_DICT && c->type != EVAC_TYPE_BOX) { err = "type must be Dict|Box"; return EVAC_ERR_INVALID_ARGUMENT; }   // wrappers/config.py:81-82 ValueError
+    if (c->positions == EVAC_POS_GRAV && c->type == EVAC_TYPE_BOX) {
+        err = "positions='grav' with type='Box' is not implemented (reference wrappers/config.py:79-80 raises NotImplementedError)";
+        return EVAC_ERR_UNSUPPORTED;
+    }
+    return EVAC_OK;
+}
+
+int64_t obs_dim_of(const evac_config_t* c) {
+    const int64_t n = c->number_of_pedestrians;
+    if (c->positions == EVAC_POS_GRAV) return 6;
+    const int64_t sc = c->statuses == EVAC_STAT_OHE ? 4 : (c->statuses == EVAC_STAT_CAT ? 1 : 0);
+    if (c->type == EVAC_TYPE_BOX) return (n + 2) * (2 + sc);
+    return 4 + 2 * n + sc * n;
+}
+
+}  // namespace
+
+struct evac_handle {
+    evac_config_t cfg;
+    evac::Params p;
+    int device;
+    bool bound;
+    std::string err;
+};
+
+namespace {
+
+int fail(evac_handle_t h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+int check_launch(evac_handle_t h, const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, EVAC_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return EVAC_OK;
+}
+
+int waves_per_env(int n_ped) { return n_ped <= 64 ? 1 : (n_ped <= 256 ? 4 : (n_ped <= 512 ? 8 : 16)); }
+
+template <int WPE>
+dim3 grid_for(int n_envs) {
+    const int per = evac::Geometry<WPE>::kEnvsPerBlock;
+    return dim3((unsigned)((n_envs + per - 1) / per));
+}
+
+#define EVAC_DISPATCH(h, KERNEL, stream, ...)                                                                   \
+    do {                                                                                                        \
+        const int wpe_ = waves_per_env((h)->p.n_ped);                                                           \
+        hipStream_t s_ = (hipStream_t)(stream);                                                                 \
+        if (wpe_ == 1) hipLaunchKernelGGL(evac::KERNEL<1>, grid_for<1>((h)->p.n_envs), dim3(evac::Geometry<1>::kBlock), 0, s_, __VA_ARGS__);      \
+        else if (wpe_ == 4) hipLaunchKernelGGL(evac::KERNEL<4>, grid_for<4>((h)->p.n_envs), dim3(evac::Geometry<4>::kBlock), 0, s_, __VA_ARGS__); \
+        else if (wpe_ == 8) hipLaunchKernelGGL(evac::KERNEL<8>, grid_for<8>((h)->p.n_envs), dim3(evac::Geometry<8>::kBlock), 0, s_, __VA_ARGS__); \
+        else hipLaunchKernelGGL(evac::KERNEL<16>, grid_for<16>((h)->p.n_envs), dim3(evac::Geometry<16>::kBlock), 0, s_, __VA_ARGS__);             \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int evac_version(void) { return EVAC_VERSION; }
+
+const char* evac_status_string(int s) {
+    switch (s) {
+        case EVAC_OK: return "ok";
+        case EVAC_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case EVAC_ERR_NOT_BOUND: return "state buffers not bound";
+        case EVAC_ERR_UNSUPPORTED: return "unsupported configuration";
+        case EVAC_ERR_HIP: return "HIP error";
+        case EVAC_ERR_NO_DEVICE: return "no HIP device";
+        default: return "unknown status";
+    }
+}
+
+const char* evac_last_error(evac_handle_t h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int evac_config_validate(const evac_config_t* cfg) {
+    std::string err;
+    const int rc = validate(cfg, err);
+    g_create_error = err;
+    return rc;
+}
+
+int64_t evac_config_obs_dim(const evac_config_t* cfg) {
+    std::string err;
+    if (validate(cfg, err) != EVAC_OK) { g_create_error = err; return -1; }
+    return obs_dim_of(cfg);
+}
+
+int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint64_t seed, uint64_t env_id_offset,
+                evac_handle_t* out) {
+    if (!out) { g_create_error = "out is NULL"; return EVAC_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    std::string err;
+    const int rc = validate(cfg, err);
+    if (rc != EVAC_OK) { g_create_error = err; return rc; }
+    if (num_envs < 1) { g_create_error = "num_envs must be >= 1"; return EVAC_ERR_INVALID_ARGUMENT; }
+    if (env_id_offset + (uint64_t)num_envs > 0xffffffffull) { g_create_error = "env_id_offset + num_envs exceeds 2^32"; return EVAC_ERR_INVALID_ARGUMENT; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        g_create_error = "no HIP device visible: libevac has no CPU path";
+        return EVAC_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) { g_create_error = "device index out of range"; return EVAC_ERR_INVALID_ARGUMENT; }
+    evac_handle* h = new (std::nothrow) evac_handle();
+    if (!h) { g_create_error = "out of host memory"; return EVAC_ERR_INVALID_ARGUMENT; }
+    h->cfg = *cfg;
+    h->device = device;
+    h->bound = false;
+    evac::Params& p = h->p;
+    std::memset(&p, 0, sizeof(p));
+    p.n_envs = num_envs;
+    p.n_ped = cfg->number_of_pedestrians;
+    p.width = cfg->width;
+    p.height = cfg->height;
+    p.step_size = cfg->step_size;
+    p.noise_coef = cfg->noise_coef;
+    p.eps = cfg->eps;
+    p.ens = cfg->enslaving_degree;
+    p.one_minus_ens = (float)(1.0 - (double)cfg->enslaving_degree);   // area.py:141 computes (1. - e) in double
+    p.init_reward = cfg->init_reward_each_step;
+    p.intrinsic_coef = cfg->intrinsic_reward_coef;
+    p.new_exiting_reward = cfg->is_new_exiting_reward != 0;
+    p.new_followers_reward = cfg->is_new_followers_reward != 0;
+    p.term_on_wall = cfg->is_termination_agent_wall_collision != 0;
+    p.max_timesteps = cfg->max_timesteps;
+    // constants.py:35-38.  Squared radii are rounded from the double product.
+    p.r_leader2 = (float)(0.2 * 0.2);
+    p.r_ped2 = (float)(0.1 * 0.1);
+    p.r_exit = 0.4f;
+    p.r_escape = 0.01f;
+    p.obs_pos = cfg->positions;
+    p.obs_stat = cfg->statuses;
+    p.obs_box = cfg->type == EVAC_TYPE_BOX;
+    p.obs_dim = (int32_t)obs_dim_of(cfg);
+    p.alpha = cfg->alpha;
+    p.neg_alpha = -cfg->alpha;
+    p.grav_pow = cfg->alpha + 2.0f;
+    const float gp = cfg->alpha + 2.0f;
+    p.grav_pow_int = (gp == std::floor(gp) && gp >= 1.0f && gp <= 32.0f) ? (int)gp : 0;
+    p.nan_guard = cfg->nan_guard != 0;
+    p.small_noise = std::fabs(cfg->noise_coef) * 0.5f <= 0.78539816f;
+    p.seed_lo = (uint32_t)(seed & 0xffffffffull);
+    p.seed_hi = (uint32_t)(seed >> 32);
+    p.env_id_offset = (uint32_t)env_id_offset;
+    *out = h;
+    return EVAC_OK;
+}
+
+int evac_destroy(evac_handle_t h) {
+    delete h;
+    return EVAC_OK;
+}
+
+int64_t evac_obs_dim(evac_handle_t h) { return h ? h->p.obs_dim : -1; }
+int32_t evac_num_envs(evac_handle_t h) { return h ? h->p.n_envs : -1; }
+
+int64_t evac_algorithmic_bytes_per_env_step(evac_handle_t h) {
+    if (!h) return -1;
+    // per agent-update 16 B read + 16 B write of (x,y,dx,dy); per env-step: action 8 +
+    // leader pos 8 r / 8 w + now 4 r / 4 w + reward 4 + terminated 1 + truncated 1 = 38; plus the obs write.
+    return 32ll * h->p.n_ped + 38ll + 4ll * h->p.obs_dim;
+}
+
+int evac_bind_state(evac_handle_t h, float* ped, uint8_t* status, float* agent, int32_t* clock, float* acc) {
+    if (!h) return EVAC_ERR_INVALID_ARGUMENT;
+    if (!ped || !status || !agent || !clock || !acc) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_bind_state: NULL buffer");
+    if (((uintptr_t)ped | (uintptr_t)agent | (uintptr_t)clock | (uintptr_t)acc) & 15u)
+        return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_bind_state: ped/agent/clock/acc must be 16-byte aligned");
+    h->p.ped = (float4*)ped;
+    h->p.status = status;
+    h->p.agent = (float4*)agent;
+    h->p.clock = (int4*)clock;
+    h->p.acc = (float4*)acc;
+    h->bound = true;
+    return EVAC_OK;
+}
+
+#define EVAC_REQUIRE_BOUND(h, name)                                               \
+    if (!(h)) return EVAC_ERR_INVALID_ARGUMENT;                                  \
+    if (!(h)->bound) return fail((h), EVAC_ERR_NOT_BOUND, name ": call evac_bind_state first")
+
+int evac_reset(evac_handle_t h, const uint8_t* mask, const float* draws, float* obs_out, void* stream) {
+    EVAC_REQUIRE_BOUND(h, "evac_reset");
+    if (draws && ((uintptr_t)draws & 15u)) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_reset: draws must be 16-byte aligned");
+    DeviceGuard g(h->device);
+    EVAC_DISPATCH(h, k_reset, stream, h->p, mask, (const float4*)draws, obs_out);
+    return check_launch(h, "evac_reset");
+}
+
+int evac_step(evac_handle_t h, const float* actions, const float* noise, float* obs_out, float* reward_out,
+              uint8_t* terminated_out, uint8_t* truncated_out, int32_t autoreset, float* final_obs,
+              evac_episode_stats_t* final_stats, void* stream) {
+    EVAC_REQUIRE_BOUND(h, "evac_step");
+    if (!actions || !obs_out || !reward_out || !terminated_out || !truncated_out)
+        return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_step: actions/obs/reward/terminated/truncated must be non-NULL");
+    if ((uintptr_t)actions & 7u) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_step: actions must be 8-byte aligned");
+    DeviceGuard g(h->device);
+    EVAC_DISPATCH(h, k_step, stream, h->p, (const float2*)actions, noise, obs_out, reward_out, terminated_out,
+                  truncated_out, (int)autoreset, final_obs, final_stats);
+    return check_launch(h, "evac_step");
+}
+
+int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* actions_out, float* obs_out,
+                 float* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
+                 evac_episode_stats_t* final_stats, void* stream) {
+    EVAC_REQUIRE_BOUND(h, "evac_rollout");
+    if (n_steps < 1) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_rollout: n_steps must be >= 1");
+    if (!obs_out || !reward_out || !terminated_out || !truncated_out)
+        return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_rollout: obs/reward/terminated/truncated must be non-NULL");
+    if (((uintptr_t)actions | (uintptr_t)actions_out) & 7u)
+        return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_rollout: actions buffers must be 8-byte aligned");
+    DeviceGuard g(h->device);
+    EVAC_DISPATCH(h, k_rollout, stream, h->p, (int)n_steps, (const float2*)actions, (float2*)actions_out, obs_out,
+                  reward_out, terminated_out, truncated_out, final_stats);
+    return check_launch(h, "evac_rollout");
+}
+
+int evac_observe(evac_handle_t h, float* obs_out, void* stream) {
+    EVAC_REQUIRE_BOUND(h, "evac_observe");
+    if (!obs_out) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_observe: obs_out is NULL");
+    DeviceGuard g(h->device);
+    EVAC_DISPATCH(h, k_observe, stream, h->p, obs_out);
+    return check_launch(h, "evac_observe");
+}
+
+static unsigned state_grid(const evac::Params& p) {
+    const size_t n = (size_t)p.n_envs * p.n_ped;
+    const size_t b = (n + 255) / 256;
+    return (unsigned)(b < 2048 ? (b ? b : 1) : 2048);
+}
+
+int evac_get_state(evac_handle_t h, float* pos, float* dir, uint8_t* status, float* agent_pos, float* agent_dir,
+                   int32_t* now, void* stream) {
+    EVAC_REQUIRE_BOUND(h, "evac_get_state");
+    DeviceGuard g(h->device);
+    hipLaunchKernelGGL(evac::k_get_state, dim3(state_grid(h->p)), dim3(256), 0, (hipStream_t)stream, h->p, (float2*)pos,
+                       (float2*)dir, status, (float2*)agent_pos, (float2*)agent_dir, now);
+    return check_launch(h, "evac_get_state");
+}
+
+int evac_set_state(evac_handle_t h, const float* pos, const float* dir, const uint8_t* status, const float* agent_pos,
+                   const float* agent_dir, const int32_t* now, void* stream) {
+    EVAC_REQUIRE_BOUND(h, "evac_set_state");
+    DeviceGuard g(h->device);
+    hipLaunchKernelGGL(evac::k_set_state, dim3(state_grid(h->p)), dim3(256), 0, (hipStream_t)stream, h->p,
+                       (const float2*)pos, (const float2*)dir, status, (const float2*)agent_pos,
+                       (const float2*)agent_dir, now);
+    return check_launch(h, "evac_set_state");
+}
+
+}  // extern "C"

@@ -1,0 +1,712 @@
+// Device code of libevac: the fused evacuation-env step for gfx950 (CDNA4, wave64).
+//
+// One env is owned by WPE waves (WPE = 1 for N <= 64, else 4/8/16 = one workgroup); lane i owns
+// pedestrian i in registers.  The only O(N^2) part -- the Vicsek neighbour average, area.py:104-119
+// of the reference -- reads the peers' (x, y, unit heading) from an LDS tile with wave-uniform
+// (broadcast) ds_read_b128.  Everything else is O(N) per-lane work plus wave reductions
+// (__ballot/__popcll for the status-transition counts, shuffle trees for the float sums).
+// No MFMA: there is no dense contraction here (output width 2).
+//
+// Built with -ffp-contract=off: every fused multiply-add is written explicitly, so the f32
+// arithmetic is the same sequence of IEEE operations as the NumPy f32 oracle wherever the two
+// use the same formula.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/evac.h"
+
+namespace evac {
+
+constexpr int kViscek = 1, kFollower = 2, kExiting = 3, kEscaped = 4;   // statuses.py:16-27
+constexpr float kExitX = 0.0f, kExitY = -1.0f;                           // area.py:39
+constexpr int kWave = 64;
+
+// Philox stream ids (counter word 3)
+constexpr uint32_t kStreamNoise = 0x4e4f4953u;   // 'NOIS'
+constexpr uint32_t kStreamReset = 0x52455345u;   // 'RESE'
+constexpr uint32_t kStreamAction = 0x41435449u;  // 'ACTI'
+
+struct Params {
+    int32_t n_envs, n_ped;
+    float width, height, step_size, noise_coef, eps;
+    float ens, one_minus_ens;
+    float init_reward, intrinsic_coef;
+    int32_t new_exiting_reward, new_followers_reward, term_on_wall, max_timesteps;
+    float r_leader2, r_ped2, r_exit, r_escape;     // constants.py:35-38 (squared where compared squared)
+    int32_t obs_pos, obs_stat, obs_box, obs_dim;
+    float alpha, neg_alpha, grav_pow;               // grav_pow = alpha + 2
+    int32_t grav_pow_int;                           // alpha+2 if it is an integer in [1,32], else 0
+    int32_t nan_guard, small_noise;                 // small_noise: noise_coef/2 <= pi/4 -> polynomial sincos
+    uint32_t seed_lo, seed_hi, env_id_offset;
+    // bound state
+    float4* ped;
+    uint8_t* status;
+    float4* agent;
+    int4* clock;
+    float4* acc;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11; Random123).  Restated in oracle/philox.py and checked there
+// against the Random123 known-answer vectors.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+// 24-bit uniform in [0,1): exact in f32
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * 0x1.0p-24f; }
+// U[-1,1): exact in f32 (pedestrians.py:17-18 draws U(-1,1); random_agent.py:8-9 samples Box(-1,1))
+__device__ __forceinline__ float usym(uint32_t x) { return 2.0f * u01(x) - 1.0f; }
+
+// ------------------------------------------------------------------------------------------------
+// wave-level helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ int wave_count(bool p) { return __popcll(__ballot(p)); }
+
+// x^k for a wave-uniform small integer k (square-and-multiply; a few ulp)
+__device__ __forceinline__ float powi(float x, int k) {
+    float r = 1.0f;
+    while (k) {
+        if (k & 1) r *= x;
+        x *= x;
+        k >>= 1;
+    }
+    return r;
+}
+
+// sin/cos of the angular noise.  |a| <= pi/4 when small_noise: Taylor to x^9 / x^10 (remainder
+// < 2e-9 relative), otherwise the ocml routines with full range reduction.
+__device__ __forceinline__ void noise_sincos(float a, int small_noise, float& s, float& c) {
+    if (small_noise) {
+        const float z = a * a;
+        float ps = fmaf(z, 2.7557319e-6f, -1.9841270e-4f);
+        ps = fmaf(ps, z, 8.3333333e-3f);
+        ps = fmaf(ps, z, -1.6666667e-1f);
+        ps = ps * z;
+        s = fmaf(ps, a, a);
+        float pc = fmaf(z, -2.7557319e-7f, 2.4801587e-5f);
+        pc = fmaf(pc, z, -1.3888889e-3f);
+        pc = fmaf(pc, z, 4.1666667e-2f);
+        pc = fmaf(pc, z, -0.5f);
+        c = fmaf(pc, z, 1.0f);
+    } else {
+        sincosf(a, &s, &c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-lane / per-env register state
+// ------------------------------------------------------------------------------------------------
+struct Ped {
+    float x, y, dx, dy;
+    int st;   // status code; 0 on lanes beyond n_ped
+};
+struct Env {
+    float ax, ay, adx, ady;           // leader position / direction        area.py:12-30
+    int now, n_resets;                // Time.now, reset count               area.py:42-59
+    uint32_t total;                   // steps since creation (Philox counter)
+    float acc_ret, acc_intr, acc_stat;   // env.py:65-67
+};
+struct StepOut {
+    float reward;
+    bool terminated, truncated;
+    int n_escaped, n_exiting, n_follower, n_viscek;
+};
+
+template <int WPE>
+struct Geometry {
+    static constexpr int kThreadsPerEnv = WPE * kWave;
+    static constexpr int kBlock = (kThreadsPerEnv < 256) ? 256 : kThreadsPerEnv;
+    static constexpr int kEnvsPerBlock = kBlock / kThreadsPerEnv;
+};
+
+template <int WPE>
+struct Smem {
+    float4 tile[Geometry<WPE>::kEnvsPerBlock][WPE * kWave];   // (x, y, ux, uy) of every pedestrian
+    float redf[Geometry<WPE>::kEnvsPerBlock][WPE][4];
+    int redi[Geometry<WPE>::kEnvsPerBlock][WPE][8];
+};
+
+// Sync the WPE waves of one env.  WPE == 1: a wave is in lock-step; only keep the compiler from
+// moving LDS accesses across the point.  WPE > 1: one env per workgroup, so a workgroup barrier.
+template <int WPE>
+__device__ __forceinline__ void env_sync() {
+    if constexpr (WPE == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
+struct Sums {
+    float f0, f1, f2;
+    int i[8];
+};
+// Reduce 3 floats and up to 8 predicates over all lanes of the env.  Result in every lane.
+template <int WPE>
+__device__ __forceinline__ void env_reduce(Smem<WPE>& sm, int slot, int wave_in_env, int lane, Sums& s,
+                                           const bool (&pred)[8]) {
+    s.f0 = wave_sum(s.f0);
+    s.f1 = wave_sum(s.f1);
+    s.f2 = wave_sum(s.f2);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s.i[k] = wave_count(pred[k]);
+    if constexpr (WPE > 1) {
+        env_sync<WPE>();   // previous users of redf/redi are done
+        if (lane == 0) {
+            sm.redf[slot][wave_in_env][0] = s.f0;
+            sm.redf[slot][wave_in_env][1] = s.f1;
+            sm.redf[slot][wave_in_env][2] = s.f2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sm.redi[slot][wave_in_env][k] = s.i[k];
+        }
+        env_sync<WPE>();
+        s.f0 = s.f1 = s.f2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s.i[k] = 0;
+        for (int w = 0; w < WPE; ++w) {   // fixed order: deterministic
+            s.f0 += sm.redf[slot][w][0];
+            s.f1 += sm.redf[slot][w][1];
+            s.f2 += sm.redf[slot][w][2];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s.i[k] += sm.redi[slot][w][k];
+        }
+    }
+}
+
+// statuses.py:29-48 -- pure function of the position, the leader position and the exit.
+// `de` returns the distance to the exit (reused by the intrinsic reward, distances.py:51-56).
+__device__ __forceinline__ int classify(const Params& p, float x, float y, float ax, float ay, float& de) {
+    const float lx = x - ax, ly = y - ay;
+    const float dl2 = lx * lx + ly * ly;
+    const float ex = x - kExitX, ey = y - kExitY;
+    de = sqrtf(ex * ex + ey * ey);
+    int st = kViscek;
+    if (dl2 < p.r_leader2) st = kFollower;
+    if (de < p.r_exit) st = kExiting;
+    if (de < p.r_escape) st = kEscaped;
+    return st;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Observation epilogue: env.py:98-104 through the wrapper chain of wrappers/config.py:46-93.
+// `viscek_gx/gy`, `n_follower` come from the caller's reduction when positions == grav.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void grav_term(const Params& p, float rx, float ry, float& gx, float& gy) {
+    // gravity_encoding.py:15-16,35-37:  -alpha / (|R| + eps)^(alpha+2) * R
+    const float nrm = sqrtf(rx * rx + ry * ry) + p.eps;
+    const float pw = p.grav_pow_int ? powi(nrm, p.grav_pow_int) : powf(nrm, p.grav_pow);
+    const float c = p.neg_alpha / pw;
+    gx = c * rx;
+    gy = c * ry;
+}
+
+template <int WPE>
+__device__ __forceinline__ void write_obs(const Params& p, Smem<WPE>& sm, int slot, int wave_in_env, int lane,
+                                          int i, bool active, const Ped& q, const Env& e, float* __restrict__ obs) {
+    if (p.obs_pos == EVAC_POS_GRAV) {
+        Sums s{};
+        float gx = 0.0f, gy = 0.0f;
+        const bool visc = active && q.st == kViscek;
+        if (visc) grav_term(p, e.ax - q.x, e.ay - q.y, gx, gy);     // gravity_encoding.py:8-25
+        s.f0 = gx;
+        s.f1 = gy;
+        s.f2 = 0.0f;
+        bool pred[8] = {active && q.st == kFollower, false, false, false, false, false, false, false};
+        env_reduce<WPE>(sm, slot, wave_in_env, lane, s, pred);
+        if (i == 0) {
+            float ex, ey;
+            grav_term(p, e.ax - kExitX, e.ay - kExitY, ex, ey);      // gravity_encoding.py:28-38
+            const float nf = (float)s.i[0];
+            obs[0] = e.ax;
+            obs[1] = e.ay;
+            obs[2] = ex * nf;
+            obs[3] = ey * nf;
+            obs[4] = s.f0;
+            obs[5] = s.f1;
+        }
+        return;
+    }
+    const bool rel = p.obs_pos == EVAC_POS_REL;
+    const float hyp = 1.41421356237f;                                 // wrappers.py:12-18 sqrt(1+1) in f32
+    float px = q.x, py = q.y, ex = kExitX, ey = kExitY;
+    if (rel) {                                                        // wrappers.py:20-27
+        px = (q.x - e.ax) / hyp;
+        py = (q.y - e.ay) / hyp;
+        ex = (kExitX - e.ax) / hyp;
+        ey = (kExitY - e.ay) / hyp;
+    }
+    const int code = 4 - q.st;                                        // wrappers.py:49
+    if (p.obs_box) {                                                  // wrappers.py:77-96
+        const int C = p.obs_stat == EVAC_STAT_OHE ? 6 : (p.obs_stat == EVAC_STAT_CAT ? 3 : 2);
+        if (i == 0) {
+            obs[0] = e.ax;
+            obs[1] = e.ay;
+            obs[C + 0] = ex;
+            obs[C + 1] = ey;
+            if (p.obs_stat == EVAC_STAT_OHE) {
+                obs[2] = obs[3] = obs[4] = obs[5] = 0.0f;
+                obs[C + 2] = 1.0f;
+                obs[C + 3] = obs[C + 4] = obs[C + 5] = 0.0f;
+            } else if (p.obs_stat == EVAC_STAT_CAT) {
+                obs[2] = 0.0f;
+                obs[C + 2] = 1.0f;
+            }
+        }
+        if (active) {
+            float* row = obs + (size_t)(i + 2) * C;
+            row[0] = px;
+            row[1] = py;
+            if (p.obs_stat == EVAC_STAT_OHE) {
+                row[2] = code == 0 ? 1.0f : 0.0f;
+                row[3] = code == 1 ? 1.0f : 0.0f;
+                row[4] = code == 2 ? 1.0f : 0.0f;
+                row[5] = code == 3 ? 1.0f : 0.0f;
+            } else if (p.obs_stat == EVAC_STAT_CAT) {
+                row[2] = (float)code / 4.0f;
+            }
+        }
+        return;
+    }
+    // Dict, flattened in gymnasium key order: agent, exit, pedestrians_positions, pedestrians_statuses
+    const int N = p.n_ped;
+    if (i == 0) {
+        obs[0] = e.ax;
+        obs[1] = e.ay;
+        obs[2] = ex;
+        obs[3] = ey;
+    }
+    if (active) {
+        obs[4 + 2 * i] = px;
+        obs[5 + 2 * i] = py;
+        float* st = obs + 4 + 2 * N;
+        if (p.obs_stat == EVAC_STAT_OHE) {                            // wrappers.py:50-54
+            st[4 * i + 0] = code == 0 ? 1.0f : 0.0f;
+            st[4 * i + 1] = code == 1 ? 1.0f : 0.0f;
+            st[4 * i + 2] = code == 2 ? 1.0f : 0.0f;
+            st[4 * i + 3] = code == 3 ? 1.0f : 0.0f;
+        } else if (p.obs_stat == EVAC_STAT_CAT) {                     // wrappers.py:55-56
+            st[i] = (float)code / 4.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// EvacuationEnv.reset: env.py:129-137, pedestrians.py:16-27, area.py:27-30, 49-51.
+// `draw` = the four U(-1,1) numbers of this pedestrian (pos.x, pos.y, dir.x, dir.y).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void reset_env(const Params& p, bool active, float4 draw, Ped& q, Env& e) {
+    e.ax = e.ay = e.adx = e.ady = 0.0f;
+    e.now = 0;
+    e.n_resets += 1;
+    e.acc_ret = e.acc_intr = e.acc_stat = 0.0f;
+    q.x = draw.x;
+    q.y = draw.y;
+    const float nrm = sqrtf(draw.z * draw.z + draw.w * draw.w);        // pedestrians.py:29-31
+    q.dx = draw.z / nrm;
+    q.dy = draw.w / nrm;
+    float de;
+    q.st = active ? classify(p, q.x, q.y, 0.0f, 0.0f, de) : 0;
+}
+
+__device__ __forceinline__ float4 philox_reset_draw(const Params& p, uint32_t env_gid, int i, int n_resets) {
+    const uint4 r = philox4x32_10(make_uint4(env_gid, (uint32_t)i, (uint32_t)n_resets, kStreamReset), p.seed_lo, p.seed_hi);
+    return make_float4(usym(r.x), usym(r.y), usym(r.z), usym(r.w));
+}
+__device__ __forceinline__ float philox_noise(const Params& p, uint32_t env_gid, int i, uint32_t total) {
+    const uint4 r = philox4x32_10(make_uint4(env_gid, (uint32_t)i, total >> 2, kStreamNoise), p.seed_lo, p.seed_hi);
+    const uint32_t sel = total & 3u;
+    const uint32_t w = sel == 0 ? r.x : (sel == 1 ? r.y : (sel == 2 ? r.z : r.w));
+    return (u01(w) - 0.5f) * p.noise_coef;                             // area.py:124: U(-c/2, c/2)
+}
+__device__ __forceinline__ float2 philox_action(const Params& p, uint32_t env_gid, uint32_t total) {
+    const uint4 r = philox4x32_10(make_uint4(env_gid, 0u, total, kStreamAction), p.seed_lo, p.seed_hi);
+    return make_float2(usym(r.x), usym(r.y));
+}
+
+// ------------------------------------------------------------------------------------------------
+// One env step: env.py:141-171.  All lanes of the env call this together.
+// ------------------------------------------------------------------------------------------------
+template <int WPE>
+__device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slot, int wave_in_env, int lane, int i,
+                                         bool active, Ped& q, Env& e, float act_x, float act_y, float noise,
+                                         StepOut& out) {
+    // ---- Time.step: area.py:53-59 ----
+    e.now += 1;
+    e.total += 1u;
+    out.truncated = e.now >= p.max_timesteps;
+
+    // ---- Area.agent_step: area.py:182-210 (wave-uniform, every lane computes the same values) ----
+    float r_agent = 0.0f;
+    bool term_agent = false;
+    {
+        const float nrm = sqrtf(act_x * act_x + act_y * act_y) + p.eps;   // area.py:190
+        const float nx = act_x / nrm, ny = act_y / nrm;
+        e.adx = p.step_size * nx;                                           // area.py:192
+        e.ady = p.step_size * ny;
+        const float tx = e.ax + e.adx, ty = e.ay + e.ady;                   // area.py:201
+        const bool hit = tx < -p.width || tx > p.width || ty < -p.height || ty > p.height;
+        if (!hit) {
+            e.ax = tx;                                                      // area.py:195
+            e.ay = ty;
+        } else {
+            r_agent = -5.0f;                                                // area.py:198
+            term_agent = p.term_on_wall != 0;
+        }
+    }
+
+    // ---- Area.pedestrians_step: area.py:76-180 ----
+    const int old_st = q.st;
+    if (q.st == kEscaped) {                                                 // area.py:79-81
+        q.dx = q.dy = 0.0f;
+        q.x = kExitX;
+        q.y = kExitY;
+    }
+    if (q.st == kExiting) {                                                 // area.py:84-90
+        const float vx = kExitX - q.x, vy = kExitY - q.y;
+        const float ln = sqrtf(vx * vx + vy * vy);
+        const float sz = ln > p.step_size ? p.step_size : ln;
+        q.dx = vx / ln * sz;
+        q.dy = vy / ln * sz;
+    }
+    const bool efv = active && (q.st == kExiting || q.st == kFollower || q.st == kViscek);   // area.py:99
+    const bool fv = active && (q.st == kFollower || q.st == kViscek);                         // area.py:104
+    const bool fol = active && q.st == kFollower;
+
+    // unit headings of the moving pedestrians: area.py:100-101 (0/0 -> NaN, see below)
+    float ux = 0.0f, uy = 0.0f;
+    bool bad = false;
+    if (efv) {
+        const float nrm = sqrtf(q.dx * q.dx + q.dy * q.dy);
+        ux = q.dx / nrm;
+        uy = q.dy / nrm;
+        bad = (ux != ux) || (uy != uy);
+        if (bad && p.nan_guard) ux = uy = 0.0f;
+    }
+    env_sync<WPE>();   // tile readers of the previous step are done
+    // non-moving (escaped / padding) pedestrians are parked far away: they are not columns of the
+    // reference's distance matrix (area.py:105-106)
+    sm.tile[slot][wave_in_env * kWave + lane] = make_float4(efv ? q.x : 3.0e38f, q.y, bad ? 0.0f : ux, bad ? 0.0f : uy);
+    // (intersection * u).sum(): NaN * 0 = NaN, so ONE zero-heading pedestrian poisons every row
+    // (area.py:118-119).  Reproduced exactly unless nan_guard.
+    bool poison = false;
+    if constexpr (WPE == 1) {
+        if (!p.nan_guard) poison = __ballot(bad) != 0ull;
+        env_sync<WPE>();
+    } else {
+        poison = __syncthreads_or((bad && !p.nan_guard) ? 1 : 0) != 0;   // barrier + OR over the env's waves
+    }
+
+    // ---- all-pairs neighbour sum: area.py:105-119.  The count n_intersections only rescales the
+    // mean heading, which arctan2 ignores; it is not needed.
+    float sx = 0.0f, sy = 0.0f;
+    {
+        const float4* __restrict__ tile = sm.tile[slot];
+        const int n = p.n_ped;
+        const float r2 = p.r_ped2;
+#pragma unroll 4
+        for (int j = 0; j < n; ++j) {
+            const float4 t = tile[j];
+            const float ddx = q.x - t.x, ddy = q.y - t.y;
+            const float d2 = ddx * ddx + ddy * ddy;
+            if (d2 < r2) {
+                sx += t.z;
+                sy += t.w;
+            }
+        }
+    }
+    if (poison) sx = sy = __builtin_nanf("");
+
+    // ---- new heading = mean heading rotated by the noise: area.py:120-136.
+    // cos/sin(arctan2(my,mx)+eta) = rotation of (mx,my)/|m| by eta; arctan2(0,0) = 0.
+    if (fv) {
+        float cx = 1.0f, cy = 0.0f;
+        if (!(sx == 0.0f && sy == 0.0f)) {
+            const float l = sqrtf(sx * sx + sy * sy);
+            cx = sx / l;
+            cy = sy / l;
+        }
+        float sn, cs;
+        noise_sincos(noise, p.small_noise, sn, cs);
+        q.dx = (cx * cs - cy * sn) * p.step_size;
+        q.dy = (cy * cs + cx * sn) * p.step_size;
+    }
+    if (fol) {                                                              // area.py:139-142
+        q.dx = p.ens * e.adx + p.one_minus_ens * q.dx;
+        q.dy = p.ens * e.ady + p.one_minus_ens * q.dy;
+    }
+    if (efv) {                                                              // area.py:145
+        q.x += q.dx;
+        q.y += q.dy;
+    }
+    {                                                                       // area.py:148-152 (NaN-propagating clip)
+        const float cx = q.x < -p.width ? -p.width : (q.x > p.width ? p.width : q.x);
+        const float cy = q.y < -p.height ? -p.height : (q.y > p.height ? p.height : q.y);
+        const float mx = q.x - cx, my = q.y - cy;
+        q.x -= 2.0f * mx;
+        q.y -= 2.0f * my;
+        if (mx != 0.0f) q.dx = -q.dx;
+        if (my != 0.0f) q.dy = -q.dy;
+    }
+
+    // ---- statuses, rewards, termination: area.py:155-178, statuses.py:29-48, reward.py:19-47 ----
+    float de = 0.0f;
+    const int new_st = active ? classify(p, q.x, q.y, e.ax, e.ay, de) : 0;
+    q.st = new_st;
+    Sums s{};
+    s.f0 = active ? de : 0.0f;
+    const bool pred[8] = {
+        (old_st == kViscek || old_st == kFollower) && new_st == kExiting,    // reward.py:35-39
+        old_st == kViscek && new_st == kFollower,                             // reward.py:43-46
+        new_st == kEscaped, new_st == kExiting, new_st == kFollower, new_st == kViscek, false, false};
+    env_reduce<WPE>(sm, slot, wave_in_env, lane, s, pred);
+    out.n_escaped = s.i[2];
+    out.n_exiting = s.i[3];
+    out.n_follower = s.i[4];
+    out.n_viscek = s.i[5];
+
+    const float n_f = (float)p.n_ped;
+    const float tf = 1.0f - (float)e.now / (200.0f * n_f);                  // reward.py:26
+    float r_ped = p.init_reward;
+    if (p.new_exiting_reward) r_ped += (15.0f + 10.0f * tf) * (float)s.i[0];
+    if (p.new_followers_reward) r_ped += (10.0f + 5.0f * tf) * (float)s.i[1];
+    const float intrinsic = 0.0f - s.f0 / n_f;                              // reward.py:19-21
+    out.reward = r_agent + r_ped + p.intrinsic_coef * intrinsic;           // env.py:158
+    out.terminated = term_agent || (s.i[2] == p.n_ped);                     // area.py:175-178, env.py:171
+    e.acc_ret += out.reward;                                                // env.py:168-170
+    e.acc_intr += intrinsic;
+    e.acc_stat += r_agent + r_ped;
+}
+
+// ------------------------------------------------------------------------------------------------
+// state <-> HBM
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_env(const Params& p, int env, int i, bool active, Ped& q, Env& e) {
+    const float4 a = p.agent[env];
+    const int4 c = p.clock[env];
+    const float4 k = p.acc[env];
+    e.ax = a.x; e.ay = a.y; e.adx = a.z; e.ady = a.w;
+    e.now = c.x; e.n_resets = c.y; e.total = (uint32_t)c.z;
+    e.acc_ret = k.x; e.acc_intr = k.y; e.acc_stat = k.z;
+    if (active) {
+        const float4 v = p.ped[(size_t)env * p.n_ped + i];
+        q.x = v.x; q.y = v.y; q.dx = v.z; q.dy = v.w;
+        q.st = p.status[(size_t)env * p.n_ped + i];
+    } else {
+        q.x = q.y = q.dx = q.dy = 0.0f;
+        q.st = 0;
+    }
+}
+__device__ __forceinline__ void store_env(const Params& p, int env, int i, bool active, const Ped& q, const Env& e) {
+    if (active) {
+        p.ped[(size_t)env * p.n_ped + i] = make_float4(q.x, q.y, q.dx, q.dy);
+        p.status[(size_t)env * p.n_ped + i] = (uint8_t)q.st;
+    }
+    if (i == 0) {
+        p.agent[env] = make_float4(e.ax, e.ay, e.adx, e.ady);
+        p.clock[env] = make_int4(e.now, e.n_resets, (int)e.total, 0);
+        p.acc[env] = make_float4(e.acc_ret, e.acc_intr, e.acc_stat, 0.0f);
+    }
+}
+
+__device__ __forceinline__ void write_stats(evac_episode_stats_t* dst, const Env& e, const StepOut& o) {
+    dst->episode_reward = e.acc_ret;
+    dst->episode_length = (float)e.now;
+    dst->episode_intrinsic_reward = e.acc_intr;
+    dst->episode_status_reward = e.acc_stat;
+    dst->escaped_pedestrians = (float)o.n_escaped;
+    dst->exiting_pedestrians = (float)o.n_exiting;
+    dst->following_pedestrians = (float)o.n_follower;
+    dst->viscek_pedestrians = (float)o.n_viscek;
+}
+
+// Which env / pedestrian does this thread own?
+template <int WPE>
+struct Who {
+    int env, slot, wave_in_env, lane, i;
+    __device__ __forceinline__ Who() {
+        const int t = threadIdx.x;
+        slot = t / Geometry<WPE>::kThreadsPerEnv;
+        const int tin = t - slot * Geometry<WPE>::kThreadsPerEnv;
+        wave_in_env = tin / kWave;
+        lane = tin & (kWave - 1);
+        i = tin;
+        env = blockIdx.x * Geometry<WPE>::kEnvsPerBlock + slot;
+        if constexpr (WPE == 1) {   // wave-uniform by construction: let the compiler keep it in SGPRs
+            env = __builtin_amdgcn_readfirstlane(env);
+            slot = __builtin_amdgcn_readfirstlane(slot);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Kernels
+// ------------------------------------------------------------------------------------------------
+template <int WPE>
+__global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_step(
+    Params p, const float2* __restrict__ actions, const float* __restrict__ noise_in, float* __restrict__ obs_out,
+    float* __restrict__ reward_out, uint8_t* __restrict__ term_out, uint8_t* __restrict__ trunc_out, int autoreset,
+    float* __restrict__ final_obs, evac_episode_stats_t* __restrict__ final_stats) {
+    __shared__ Smem<WPE> sm;
+    const Who<WPE> w;
+    if (w.env >= p.n_envs) return;   // whole waves (WPE == 1) or whole workgroups: no barrier is skipped by a subset
+    const bool active = w.i < p.n_ped;
+    Ped q;
+    Env e;
+    load_env(p, w.env, w.i, active, q, e);
+    const uint32_t gid = p.env_id_offset + (uint32_t)w.env;
+    const float2 a = actions[w.env];
+    float nz = 0.0f;
+    if (active) nz = noise_in ? noise_in[(size_t)w.env * p.n_ped + w.i] : philox_noise(p, gid, w.i, e.total);
+    StepOut o;
+    step_env<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, a.x, a.y, nz, o);
+    const bool done = o.terminated || o.truncated;
+    float* obs = obs_out + (size_t)w.env * p.obs_dim;
+    if (done && autoreset) {
+        if (final_obs) write_obs<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, final_obs + (size_t)w.env * p.obs_dim);
+        if (final_stats && w.i == 0) write_stats(final_stats + w.env, e, o);
+        reset_env(p, active, philox_reset_draw(p, gid, w.i, e.n_resets), q, e);
+    }
+    write_obs<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, obs);
+    store_env(p, w.env, w.i, active, q, e);
+    if (w.i == 0) {
+        reward_out[w.env] = o.reward;
+        term_out[w.env] = o.terminated ? 1 : 0;
+        trunc_out[w.env] = o.truncated ? 1 : 0;
+    }
+}
+
+// T steps per launch, state in registers (rpo_agent.py:180-203 rollout loop, RandomAgent or given actions).
+template <int WPE>
+__global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_rollout(
+    Params p, int n_steps, const float2* __restrict__ actions, float2* __restrict__ actions_out,
+    float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ term_out,
+    uint8_t* __restrict__ trunc_out, evac_episode_stats_t* __restrict__ final_stats) {
+    __shared__ Smem<WPE> sm;
+    const Who<WPE> w;
+    if (w.env >= p.n_envs) return;
+    const bool active = w.i < p.n_ped;
+    Ped q;
+    Env e;
+    load_env(p, w.env, w.i, active, q, e);
+    const uint32_t gid = p.env_id_offset + (uint32_t)w.env;
+    const size_t E = (size_t)p.n_envs;
+    uint4 nzr = make_uint4(0, 0, 0, 0);
+    bool have = false;
+    for (int t = 0; t < n_steps; ++t) {
+        float2 a;
+        if (actions) a = actions[(size_t)t * E + w.env];
+        else a = philox_action(p, gid, e.total);
+        if (actions_out && w.i == 0) actions_out[(size_t)t * E + w.env] = a;
+        // one Philox call serves four consecutive steps of this pedestrian
+        const uint32_t sel = e.total & 3u;
+        if (!have || sel == 0u) {
+            nzr = philox4x32_10(make_uint4(gid, (uint32_t)w.i, e.total >> 2, kStreamNoise), p.seed_lo, p.seed_hi);
+            have = true;
+        }
+        const uint32_t wsel = sel == 0 ? nzr.x : (sel == 1 ? nzr.y : (sel == 2 ? nzr.z : nzr.w));
+        const float nz = (u01(wsel) - 0.5f) * p.noise_coef;
+        StepOut o;
+        step_env<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, a.x, a.y, nz, o);
+        if (o.terminated || o.truncated) {
+            if (final_stats && w.i == 0) write_stats(final_stats + (size_t)t * E + w.env, e, o);
+            reset_env(p, active, philox_reset_draw(p, gid, w.i, e.n_resets), q, e);
+        }
+        write_obs<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, obs_out + ((size_t)t * E + w.env) * p.obs_dim);
+        if (w.i == 0) {
+            reward_out[(size_t)t * E + w.env] = o.reward;
+            term_out[(size_t)t * E + w.env] = o.terminated ? 1 : 0;
+            trunc_out[(size_t)t * E + w.env] = o.truncated ? 1 : 0;
+        }
+    }
+    store_env(p, w.env, w.i, active, q, e);
+}
+
+template <int WPE>
+__global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_reset(Params p, const uint8_t* __restrict__ mask,
+                                                                const float4* __restrict__ draws,
+                                                                float* __restrict__ obs_out) {
+    __shared__ Smem<WPE> sm;
+    const Who<WPE> w;
+    if (w.env >= p.n_envs) return;
+    if (mask && !mask[w.env]) return;   // per env: uniform over the env's waves
+    const bool active = w.i < p.n_ped;
+    Ped q;
+    Env e;
+    load_env(p, w.env, w.i, active, q, e);
+    const uint32_t gid = p.env_id_offset + (uint32_t)w.env;
+    float4 d = make_float4(0.f, 0.f, 1.f, 0.f);
+    if (active) d = draws ? draws[(size_t)w.env * p.n_ped + w.i] : philox_reset_draw(p, gid, w.i, e.n_resets);
+    reset_env(p, active, d, q, e);
+    if (obs_out) write_obs<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, obs_out + (size_t)w.env * p.obs_dim);
+    store_env(p, w.env, w.i, active, q, e);
+}
+
+template <int WPE>
+__global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_observe(Params p, float* __restrict__ obs_out) {
+    __shared__ Smem<WPE> sm;
+    const Who<WPE> w;
+    if (w.env >= p.n_envs) return;
+    const bool active = w.i < p.n_ped;
+    Ped q;
+    Env e;
+    load_env(p, w.env, w.i, active, q, e);
+    write_obs<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, obs_out + (size_t)w.env * p.obs_dim);
+}
+
+// state exchange in the reference's shapes
+__global__ void k_get_state(Params p, float2* pos, float2* dir, uint8_t* status, float2* apos, float2* adir, int32_t* now) {
+    const size_t n = (size_t)p.n_envs * p.n_ped;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = p.ped[k];
+        if (pos) pos[k] = make_float2(v.x, v.y);
+        if (dir) dir[k] = make_float2(v.z, v.w);
+        if (status) status[k] = p.status[k];
+        if (k < (size_t)p.n_envs) {
+            const float4 a = p.agent[k];
+            if (apos) apos[k] = make_float2(a.x, a.y);
+            if (adir) adir[k] = make_float2(a.z, a.w);
+            if (now) now[k] = p.clock[k].x;
+        }
+    }
+}
+__global__ void k_set_state(Params p, const float2* pos, const float2* dir, const uint8_t* status, const float2* apos,
+                            const float2* adir, const int32_t* now) {
+    const size_t n = (size_t)p.n_envs * p.n_ped;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+        float4 v = p.ped[k];
+        if (pos) { v.x = pos[k].x; v.y = pos[k].y; }
+        if (dir) { v.z = dir[k].x; v.w = dir[k].y; }
+        p.ped[k] = v;
+        if (status) p.status[k] = status[k];
+        if (k < (size_t)p.n_envs) {
+            float4 a = p.agent[k];
+            if (apos) { a.x = apos[k].x; a.y = apos[k].y; }
+            if (adir) { a.z = adir[k].x; a.w = adir[k].y; }
+            p.agent[k] = a;
+            if (now) {
+                int4 c = p.clock[k];
+                c.x = now[k];
+                p.clock[k] = c;
+            }
+        }
+    }
+}
+
+}  // namespace evac

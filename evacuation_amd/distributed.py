@@ -1,0 +1,139 @@
+"""Env-sharded data parallelism: one process per GPU, a contiguous block of envs per rank, and ONE
+collective -- an all-gather of the packed step outputs -- because the envs are fully independent
+(no cross-env term anywhere in the reference's area.py).
+
+The reference has no distributed code at all (its "vector env" is gym.vector.SyncVectorEnv stepping
+3 envs sequentially, rpo_agent.py:123-126); this is the MI355X-native replacement for scaling it.
+
+Layout of the gathered slab: float32 [..., E_total, D + 3] = [obs(D) | reward | terminated | truncated]
+in GLOBAL env order (rank r owns envs [r*E_local, (r+1)*E_local)).  Philox streams are keyed by the
+global env id (evac_create's env_id_offset), so a sharded run reproduces the single-GPU run bit for
+bit.  With backend "nccl" (= RCCL on ROCm) the gather runs over xGMI; the sizes are small
+(C4: 4096 envs x 9 floats = 144 KiB per rank per step) so it is latency-bound and is issued on a
+side stream, chunked over T steps, overlapping the next chunk's compute.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total_envs: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous equal shards; total_envs must divide evenly (all_gather_into_tensor needs equal sizes)."""
+    if total_envs % world_size != 0:
+        raise ValueError(f"num_envs={total_envs} is not divisible by world_size={world_size}")
+    per = total_envs // world_size
+    return rank * per, per
+
+
+def pack_outputs(obs: torch.Tensor, reward: torch.Tensor, terminated: torch.Tensor, truncated: torch.Tensor,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[..., E, D] obs + [..., E] reward/flags -> one float32 slab [..., E, D+3] (a single message)."""
+    d = obs.shape[-1]
+    shape = tuple(obs.shape[:-1]) + (d + 3,)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=obs.device)
+    out[..., :d] = obs
+    out[..., d] = reward
+    out[..., d + 1] = terminated.to(torch.float32)
+    out[..., d + 2] = truncated.to(torch.float32)
+    return out
+
+
+def unpack_outputs(slab: torch.Tensor):
+    d = slab.shape[-1] - 3
+    return slab[..., :d], slab[..., d], slab[..., d + 1] != 0, slab[..., d + 2] != 0
+
+
+def all_gather_envs(local: torch.Tensor, env_dim: int = -2, group=None, out: Optional[torch.Tensor] = None,
+                    async_op: bool = False):
+    """All-gather ``local`` ([..., E_local, C]) along its env dimension into global env order.
+
+    RCCL's all_gather_into_tensor concatenates along dim 0, so for time-major chunks [T, E_local, C]
+    the gathered buffer is [world, T, E_local, C]; ``gathered_view`` turns it into [T, E_total, C]
+    without a copy of the payload being needed by callers that index by (rank, env)."""
+    world = dist.get_world_size(group)
+    local = local.contiguous()
+    if out is None:
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    # concatenated-along-dim-0 form: accepted by both RCCL and gloo
+    flat_out = out.view((world * local.shape[0],) + tuple(local.shape[1:]))
+    work = dist.all_gather_into_tensor(flat_out, local, group=group, async_op=async_op)
+    return out, work
+
+
+def gathered_view(gathered: torch.Tensor, env_dim: int = -2) -> torch.Tensor:
+    """[world, ..., E_local, C] -> [..., world*E_local, C] (global env order)."""
+    world = gathered.shape[0]
+    nd = gathered.dim()
+    env_axis = env_dim % (nd - 1) + 1           # axis of E_local in `gathered`
+    perm = list(range(1, env_axis)) + [0] + list(range(env_axis, nd))
+    g = gathered.permute(perm)                    # [..., world, E_local, C...]
+    shape = list(g.shape)
+    k = env_axis - 1
+    return g.reshape(shape[:k] + [world * shape[k + 1]] + shape[k + 2:])
+
+
+class ShardedEvacuationEnv:
+    """``total_envs`` envs sharded over the ranks of a torch.distributed group; each rank steps its
+    shard with a BatchedEvacuationEnv and the packed outputs are all-gathered."""
+
+    def __init__(self, env_config, wrap_config=None, total_envs: int = 1, device=None, seed: int = 0, group=None,
+                 autoreset: bool = True):
+        from .vector_env import BatchedEvacuationEnv
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.total_envs = int(total_envs)
+        self.offset, self.local_envs = shard_range(self.total_envs, self.rank, self.world_size)
+        if device is None:
+            device = f"cuda:{torch.cuda.current_device()}"
+        self.local = BatchedEvacuationEnv(env_config, wrap_config, num_envs=self.local_envs, device=device, seed=seed,
+                                          env_id_offset=self.offset, autoreset=autoreset)
+        self.obs_dim = self.local.obs_dim
+        self.comm_stream = torch.cuda.Stream(device=self.local.device) if self.world_size > 1 else None
+
+    def reset(self, **kw):
+        return self.local.reset(**kw)
+
+    def step(self, actions_local, gather: bool = True):
+        """Step the local shard; returns the local outputs and (if gather) the global slab
+        [E_total, D+3] in global env order."""
+        obs, rew, term, trunc, info = self.local.step(actions_local)
+        if not gather:
+            return obs, rew, term, trunc, info, None
+        slab = pack_outputs(obs, rew, term, trunc)
+        if self.world_size == 1:
+            return obs, rew, term, trunc, info, slab
+        g, _ = all_gather_envs(slab, group=self.group)
+        return obs, rew, term, trunc, info, gathered_view(g)
+
+    def rollout_gathered(self, n_steps: int, actions=None, prev=None):
+        """One T-step rollout launch on the compute stream, then the all-gather of its packed
+        outputs on the comm stream.  Returns (local rollout dict, pending) where
+        ``pending = (gathered [world,T,E_local,D+3], event)``; pass it back as ``prev`` (or call
+        ``wait``) before reading it.  The gather of chunk k overlaps the compute of chunk k+1."""
+        ro = self.local.rollout(n_steps, actions=actions)
+        slab = pack_outputs(ro["obs"], ro["reward"], ro["terminated"], ro["truncated"])
+        if self.world_size == 1:
+            return ro, (slab.unsqueeze(0), None)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.local.device))
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ready)
+            g, _ = all_gather_envs(slab, group=self.group)
+            done = torch.cuda.Event()
+            done.record(self.comm_stream)
+        slab.record_stream(self.comm_stream)
+        return ro, (g, done)
+
+    def wait(self, pending):
+        g, ev = pending
+        if ev is not None:
+            torch.cuda.current_stream(self.local.device).wait_event(ev)
+        return gathered_view(g)
+
+    def close(self):
+        self.local.close()

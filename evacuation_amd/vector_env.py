@@ -1,0 +1,262 @@
+"""BatchedEvacuationEnv: E independent evacuation envs stepped by ONE fused HIP kernel per step.
+
+Replaces ``gym.vector.SyncVectorEnv([make_env]*num_envs)`` of the reference trainer
+(/root/reference/src/agents/rpo_agent.py:123-128,168,193-203) for the env + observation-wrapper
+part of the chain: same ``reset(seed=) -> (obs, infos)`` / ``step(actions) -> (obs, reward,
+terminations, truncations, infos)`` surface, same-step autoreset (gymnasium 0.29 semantics the
+trainer assumes), but observations, rewards and flags are device tensors that never leave HBM.
+
+PyTorch is used only as the device-buffer container (``tensor.data_ptr()``) and for the current
+HIP stream; all compute is in libevac.so (csrc/), reached through ctypes (include/evac.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict as TDict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import EnvConfig, EnvWrappersConfig, obs_dim, to_c_config
+from .spaces import Box, Dict
+
+STATS_FIELDS = ("episode_reward", "episode_length", "episode_intrinsic_reward", "episode_status_reward",
+                "escaped_pedestrians", "exiting_pedestrians", "following_pedestrians", "viscek_pedestrians")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def observation_space_for(env_config: EnvConfig, wrap: EnvWrappersConfig):
+    """Spaces as declared by the reference (env.py:86-96, gravity_encoding.py:52-57,
+    wrappers.py:32-45,61-75)."""
+    n = env_config.number_of_pedestrians
+    f32 = np.float32
+    if wrap.positions == "grav":
+        return Dict({"agent_position": Box(-1, 1, (2,), f32),
+                     "grad_potential_pedestrians": Box(-1, 1, (2,), f32),
+                     "grad_potential_exit": Box(-1, 1, (2,), f32)})
+    if wrap.type == "Box":
+        c = {"no": 2, "ohe": 6, "cat": 3}[wrap.statuses]
+        return Box(-1, 1, (n + 2, c), f32)
+    d = {"agent_position": Box(-1, 1, (2,), f32),
+         "pedestrians_positions": Box(-1, 1, (n, 2), f32),
+         "exit_position": Box(-1, 1, (2,), f32)}
+    if wrap.statuses == "ohe":
+        d["pedestrians_statuses"] = Box(0, 1, (n, 4), f32)
+    elif wrap.statuses == "cat":
+        d["pedestrians_statuses"] = Box(0, 1, (n,), f32)
+    return Dict(d)
+
+
+def split_observation(flat, env_config: EnvConfig, wrap: EnvWrappersConfig):
+    """Views of a flat ``[..., D]`` observation in the reference's structure (Dict keys / Box shape).
+    Works on torch tensors and numpy arrays alike (pure slicing + reshape)."""
+    n = env_config.number_of_pedestrians
+    lead = tuple(flat.shape[:-1])
+    if wrap.positions == "grav":
+        return {"agent_position": flat[..., 0:2], "grad_potential_exit": flat[..., 2:4],
+                "grad_potential_pedestrians": flat[..., 4:6]}
+    if wrap.type == "Box":
+        c = {"no": 2, "ohe": 6, "cat": 3}[wrap.statuses]
+        return flat.reshape(lead + (n + 2, c))
+    out = {"agent_position": flat[..., 0:2], "exit_position": flat[..., 2:4],
+           "pedestrians_positions": flat[..., 4:4 + 2 * n].reshape(lead + (n, 2))}
+    if wrap.statuses == "ohe":
+        out["pedestrians_statuses"] = flat[..., 4 + 2 * n:4 + 6 * n].reshape(lead + (n, 4))
+    elif wrap.statuses == "cat":
+        out["pedestrians_statuses"] = flat[..., 4 + 2 * n:4 + 3 * n]
+    return out
+
+
+class BatchedEvacuationEnv:
+    """``num_envs`` evacuation envs on one GPU.
+
+    Parameters mirror ``setup_env(env_config, wrap_config)`` (src/env/__init__.py:18-21) plus the
+    batch size, the device, the Philox ``seed`` and ``env_id_offset`` (global id of env 0, so that
+    a sharded run draws the same random numbers as a single-GPU run)."""
+
+    def __init__(self, env_config: EnvConfig, wrap_config: Optional[EnvWrappersConfig] = None, num_envs: int = 1,
+                 device="cuda:0", seed: int = 0, env_id_offset: int = 0, autoreset: bool = True):
+        self.lib = _lib.load()                       # raises if the HIP library is missing
+        self.env_config = env_config
+        self.wrap_config = wrap_config or EnvWrappersConfig()
+        self.num_envs = int(num_envs)
+        self.n_ped = int(env_config.number_of_pedestrians)
+        self.autoreset = bool(autoreset)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("BatchedEvacuationEnv needs an MI355X device ('cuda:N' under PyTorch-ROCm); "
+                               "there is no CPU path")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible to PyTorch; evacuation_amd has no CPU fallback")
+        self.seed_value = int(seed)
+        self.env_id_offset = int(env_id_offset)
+        self._cfg = to_c_config(env_config, self.wrap_config)
+        self._h = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._dev_index = dev_index
+        _lib.check(self.lib.evac_create(C.byref(self._cfg), self.num_envs, dev_index, C.c_uint64(self.seed_value),
+                                        C.c_uint64(self.env_id_offset), C.byref(self._h)))
+        self.obs_dim = int(self.lib.evac_obs_dim(self._h))
+        assert self.obs_dim == obs_dim(env_config, self.wrap_config)
+        E, N, dev = self.num_envs, self.n_ped, self.device
+        # caller-owned state (include/evac.h 'Device layouts')
+        self.ped = torch.zeros((E, N, 4), dtype=torch.float32, device=dev)
+        self.status = torch.zeros((E, N), dtype=torch.uint8, device=dev)
+        self.agent = torch.zeros((E, 4), dtype=torch.float32, device=dev)
+        self.clock = torch.zeros((E, 4), dtype=torch.int32, device=dev)
+        self.acc = torch.zeros((E, 4), dtype=torch.float32, device=dev)
+        _lib.check(self.lib.evac_bind_state(self._h, _ptr(self.ped), _ptr(self.status), _ptr(self.agent),
+                                            _ptr(self.clock), _ptr(self.acc)), self._h)
+        # step outputs (reused every step; callers that keep them must clone, like the reference's
+        # live-reference observations, env.py:98-104)
+        self.obs = torch.zeros((E, self.obs_dim), dtype=torch.float32, device=dev)
+        self.reward = torch.zeros((E,), dtype=torch.float32, device=dev)
+        self.terminated = torch.zeros((E,), dtype=torch.uint8, device=dev)
+        self.truncated = torch.zeros((E,), dtype=torch.uint8, device=dev)
+        self.final_obs = torch.zeros((E, self.obs_dim), dtype=torch.float32, device=dev)
+        self.final_stats = torch.zeros((E, len(STATS_FIELDS)), dtype=torch.float32, device=dev)
+        self.single_action_space = Box(-1.0, 1.0, (2,), np.float32)            # env.py:69
+        self.single_observation_space = observation_space_for(env_config, self.wrap_config)
+        self.action_space = Box(-1.0, 1.0, (E, 2), np.float32)
+        self.observation_space = Box(-np.inf, np.inf, (E, self.obs_dim), np.float32)
+        self.algorithmic_bytes_per_env_step = int(self.lib.evac_algorithmic_bytes_per_env_step(self._h))
+        self._was_reset = False
+
+    # ------------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check_tensor(self, t: torch.Tensor, shape, dtype, name):
+        if tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != self.device or not t.is_contiguous():
+            raise ValueError(f"{name}: expected contiguous {dtype} tensor of shape {tuple(shape)} on {self.device}, "
+                             f"got {t.dtype} {tuple(t.shape)} on {t.device}")
+        return t
+
+    def _as_device(self, x, shape, dtype, name):
+        if x is None:
+            return None
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.asarray(x))
+        x = x.to(device=self.device, dtype=dtype).contiguous()
+        return self._check_tensor(x, shape, dtype, name)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.evac_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # ------------------------------------------------------------------------------------------
+    def reset(self, seed: Optional[int] = None, options=None, *, mask=None, draws=None):
+        """EvacuationEnv.reset for every env (env.py:106-139).  ``seed`` is accepted for API
+        compatibility; like the reference (whose dynamics use the global NumPy RNG, not
+        ``self.np_random``) it does NOT reseed the dynamics -- the Philox key is fixed at
+        construction.  ``draws`` [E,N,4] injects the U(-1,1) reset draws (parity tests)."""
+        E, N = self.num_envs, self.n_ped
+        mask_t = self._as_device(mask, (E,), torch.uint8, "mask")
+        draws_t = self._as_device(draws, (E, N, 4), torch.float32, "draws")
+        _lib.check(self.lib.evac_reset(self._h, _ptr(mask_t), _ptr(draws_t), _ptr(self.obs), self._stream()), self._h)
+        self._was_reset = True
+        return self.obs, {}
+
+    def step(self, actions, noise=None):
+        """EvacuationEnv.step + wrappers for the batch (env.py:141-171).  ``actions`` [E,2] f32 on
+        the device; ``noise`` [E,N] injects the per-pedestrian angular noise (parity tests)."""
+        E, N = self.num_envs, self.n_ped
+        if isinstance(actions, torch.Tensor) and actions.device == self.device and actions.dtype == torch.float32 \
+                and actions.is_contiguous() and tuple(actions.shape) == (E, 2):
+            act = actions
+        else:
+            act = self._as_device(actions, (E, 2), torch.float32, "actions")
+        nz = self._as_device(noise, (E, N), torch.float32, "noise")
+        _lib.check(self.lib.evac_step(self._h, _ptr(act), _ptr(nz), _ptr(self.obs), _ptr(self.reward),
+                                      _ptr(self.terminated), _ptr(self.truncated), int(self.autoreset),
+                                      _ptr(self.final_obs) if self.autoreset else None,
+                                      _ptr(self.final_stats) if self.autoreset else None, self._stream()), self._h)
+        infos = {}
+        if self.autoreset:
+            # device tensors; rows are meaningful where terminated | truncated (no host sync here)
+            infos = {"final_observation": self.final_obs, "episode_stats": self.final_stats}
+        return self.obs, self.reward, self.terminated, self.truncated, infos
+
+    def rollout(self, n_steps: int, actions=None, record_actions: bool = False, out: Optional[TDict] = None):
+        """``n_steps`` env steps in ONE kernel launch with the state held in registers (the
+        rollout loop rpo_agent.py:180-203 with given or RandomAgent actions).  Returns time-major
+        device tensors: obs [T,E,D], reward [T,E], terminated/truncated [T,E] (uint8),
+        episode_stats [T,E,8] (rows valid where an episode ended), actions [T,E,2] if recorded."""
+        T, E = int(n_steps), self.num_envs
+        dev = self.device
+        if out is None:
+            out = {
+                "obs": torch.empty((T, E, self.obs_dim), dtype=torch.float32, device=dev),
+                "reward": torch.empty((T, E), dtype=torch.float32, device=dev),
+                "terminated": torch.empty((T, E), dtype=torch.uint8, device=dev),
+                "truncated": torch.empty((T, E), dtype=torch.uint8, device=dev),
+                "episode_stats": torch.zeros((T, E, len(STATS_FIELDS)), dtype=torch.float32, device=dev),
+            }
+            if record_actions:
+                out["actions"] = torch.empty((T, E, 2), dtype=torch.float32, device=dev)
+        act = self._as_device(actions, (T, E, 2), torch.float32, "actions")
+        _lib.check(self.lib.evac_rollout(self._h, T, _ptr(act), _ptr(out.get("actions")), _ptr(out["obs"]),
+                                         _ptr(out["reward"]), _ptr(out["terminated"]), _ptr(out["truncated"]),
+                                         _ptr(out.get("episode_stats")), self._stream()), self._h)
+        return out
+
+    def observe(self, out: Optional[torch.Tensor] = None):
+        """Observation of the current state without stepping (env.py:98-104 through the wrappers)."""
+        out = self.obs if out is None else self._check_tensor(out, (self.num_envs, self.obs_dim), torch.float32, "out")
+        _lib.check(self.lib.evac_observe(self._h, _ptr(out), self._stream()), self._h)
+        return out
+
+    def split_observation(self, flat):
+        return split_observation(flat, self.env_config, self.wrap_config)
+
+    # ------------------------------------------------------------------------------------------
+    def get_state(self) -> TDict[str, torch.Tensor]:
+        """State in the reference's shapes (pedestrians.py:6-27, area.py:12-59): pos/dir [E,N,2],
+        status [E,N], agent_pos/agent_dir [E,2], now [E]."""
+        E, N, dev = self.num_envs, self.n_ped, self.device
+        st = {"pos": torch.empty((E, N, 2), dtype=torch.float32, device=dev),
+              "dir": torch.empty((E, N, 2), dtype=torch.float32, device=dev),
+              "status": torch.empty((E, N), dtype=torch.uint8, device=dev),
+              "agent_pos": torch.empty((E, 2), dtype=torch.float32, device=dev),
+              "agent_dir": torch.empty((E, 2), dtype=torch.float32, device=dev),
+              "now": torch.empty((E,), dtype=torch.int32, device=dev)}
+        _lib.check(self.lib.evac_get_state(self._h, _ptr(st["pos"]), _ptr(st["dir"]), _ptr(st["status"]),
+                                           _ptr(st["agent_pos"]), _ptr(st["agent_dir"]), _ptr(st["now"]),
+                                           self._stream()), self._h)
+        return st
+
+    def set_state(self, pos=None, dir=None, status=None, agent_pos=None, agent_dir=None, now=None):  # noqa: A002
+        E, N = self.num_envs, self.n_ped
+        a = [self._as_device(pos, (E, N, 2), torch.float32, "pos"), self._as_device(dir, (E, N, 2), torch.float32, "dir"),
+             self._as_device(status, (E, N), torch.uint8, "status"),
+             self._as_device(agent_pos, (E, 2), torch.float32, "agent_pos"),
+             self._as_device(agent_dir, (E, 2), torch.float32, "agent_dir"),
+             self._as_device(now, (E,), torch.int32, "now")]
+        _lib.check(self.lib.evac_set_state(self._h, *[_ptr(t) for t in a], self._stream()), self._h)
+        self._keepalive = a   # the copy kernel runs asynchronously on the stream
+
+    # ------------------------------------------------------------------------------------------
+    def final_info_list(self, infos, terminated=None, truncated=None):
+        """gymnasium-0.29 style ``infos['final_info']`` (list with one dict or None per env), as
+        consumed by rpo_agent.py:198-203.  Synchronises with the device."""
+        term = (self.terminated if terminated is None else terminated).bool()
+        trunc = (self.truncated if truncated is None else truncated).bool()
+        done = (term | trunc).cpu().numpy()
+        stats = infos["episode_stats"].cpu().numpy()
+        out = [None] * self.num_envs
+        for k in np.nonzero(done)[0]:
+            rec = {f: float(stats[k, j]) for j, f in enumerate(STATS_FIELDS)}
+            rec["episode"] = {"r": rec["episode_reward"], "l": int(rec["episode_length"])}
+            out[k] = rec
+        return out

@@ -1,0 +1,173 @@
+/*
+ * libevac -- MI355X (gfx950) implementation of the cinemere/evacuation env step path.
+ *
+ * C ABI: plain pointers and sizes, no C++/torch types.  This is the drop-in boundary: the
+ * reference is pure Python and has no FFI of its own, so each entry point below names the
+ * reference *Python* interface it replaces (file:line under /root/reference).  INTEGRATION.md
+ * shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative evac_status_t; nothing throws;
+ *  - the CALLER owns every device buffer (PyTorch tensors in our host code); the library owns
+ *    only a host-side copy of the config, the Philox key and the bound pointers;
+ *  - all work is enqueued on the caller's stream (a hipStream_t passed as void*); no call
+ *    synchronises or allocates device memory, so calls can be captured into a hipGraph;
+ *  - one handle per (device, set of state buffers); a handle is not thread-safe, distinct
+ *    handles are independent.
+ *
+ * Device layouts (row-major, E = num_envs, N = n_ped)
+ *    ped    float [E][N][4]   (x, y, dir_x, dir_y)      pedestrians.py:17-19
+ *    status uint8 [E][N]      1 VISCEK 2 FOLLOWER 3 EXITING 4 ESCAPED   statuses.py:16-27
+ *    agent  float [E][4]      (x, y, dir_x, dir_y)      area.py:12-30
+ *    clock  int32 [E][4]      (now, n_resets, total_steps, 0)           area.py:42-59
+ *    acc    float [E][4]      (episode_reward, episode_intrinsic_reward, episode_status_reward, 0)
+ *                                                                       env.py:65-67,168-170
+ *    obs    float [E][D]      D = evac_obs_dim(); layout per observation mode below
+ *
+ * Observation layouts (all f32; D floats per env)
+ *    positions=grav                  [agent(2), grad_potential_exit(2), grad_potential_pedestrians(2)]
+ *                                    (gymnasium Dict key order, i.e. what FlattenObservation yields)
+ *    type=Box                        [(N+2)][C] rows agent, exit, pedestrians; C = 2 / 3 (cat) / 6 (ohe)
+ *    type=Dict, positions=abs|rel    [agent(2), exit(2), pedestrians_positions(2N), pedestrians_statuses(4N | N | 0)]
+ */
+#ifndef EVAC_H
+#define EVAC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVAC_VERSION 100          /* 0.1.0 */
+#define EVAC_MAX_PEDESTRIANS 1024 /* one workgroup (<=16 waves) per env */
+
+typedef enum evac_status {
+    EVAC_OK = 0,
+    EVAC_ERR_INVALID_ARGUMENT = -1,
+    EVAC_ERR_NOT_BOUND = -2,
+    EVAC_ERR_UNSUPPORTED = -3, /* e.g. positions=grav with type=Box: wrappers/config.py:79-80 raises NotImplementedError */
+    EVAC_ERR_HIP = -4,
+    EVAC_ERR_NO_DEVICE = -5
+} evac_status_t;
+
+enum { EVAC_POS_ABS = 0, EVAC_POS_REL = 1, EVAC_POS_GRAV = 2 };   /* wrappers/config.py:19-24 */
+enum { EVAC_STAT_NO = 0, EVAC_STAT_OHE = 1, EVAC_STAT_CAT = 2 };  /* wrappers/config.py:26-29 */
+enum { EVAC_TYPE_DICT = 0, EVAC_TYPE_BOX = 1 };                   /* wrappers/config.py:31-33 */
+
+/* Parameter block = the fields of EnvConfig (src/env/env/config.py:11-59) and EnvWrappersConfig
+ * (src/env/wrappers/config.py:12-38) that enter the arithmetic.  Same names, same meaning. */
+typedef struct evac_config {
+    int32_t number_of_pedestrians;
+    float width;
+    float height;
+    float step_size;
+    float noise_coef;
+    float eps;
+    float enslaving_degree;
+    int32_t is_new_exiting_reward;
+    int32_t is_new_followers_reward;
+    float intrinsic_reward_coef;
+    int32_t is_termination_agent_wall_collision;
+    float init_reward_each_step;
+    int32_t max_timesteps;
+    /* observation wrappers */
+    int32_t positions; /* EVAC_POS_*  */
+    int32_t statuses;  /* EVAC_STAT_* */
+    int32_t type;      /* EVAC_TYPE_* */
+    float alpha;       /* GravityEncoding alpha (gravity_encoding.py:41-57) */
+    /* 0 (default): bit-faithful to the reference, where a zero heading (0/0, area.py:101) poisons every
+     * FOLLOWER/VISCEK pedestrian with NaN.  1: a zero heading contributes nothing (non-reference). */
+    int32_t nan_guard;
+} evac_config_t;
+
+/* Written for envs whose episode ended this step (env.py:115-125 logging dict). */
+typedef struct evac_episode_stats {
+    float episode_reward;
+    float episode_length;
+    float episode_intrinsic_reward;
+    float episode_status_reward;
+    float escaped_pedestrians;
+    float exiting_pedestrians;
+    float following_pedestrians;
+    float viscek_pedestrians;
+} evac_episode_stats_t;
+
+typedef struct evac_handle* evac_handle_t;
+
+int evac_version(void);
+const char* evac_status_string(int status);
+/* Last error message of a handle (or of the last failed evac_create when h == NULL). */
+const char* evac_last_error(evac_handle_t h);
+
+/* Device-free helpers: validate a config (same errors as evac_create) / floats per env of its
+ * observation.  Mirror the checks of wrappers/config.py:76-82. */
+int evac_config_validate(const evac_config_t* cfg);
+int64_t evac_config_obs_dim(const evac_config_t* cfg);
+
+/* Replaces EvacuationEnv.__init__ + EnvWrappersConfig.wrap_env for a batch of `num_envs` independent
+ * envs (env.py:41-84, wrappers/config.py:46-93, src/env/__init__.py:18-21).  `seed` keys the Philox
+ * streams; env e uses stream id `env_id_offset + e`, so a sharded run reproduces the single-GPU run. */
+int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint64_t seed,
+                uint64_t env_id_offset, evac_handle_t* out);
+int evac_destroy(evac_handle_t h);
+
+/* Floats per env in the observation buffer for this handle's observation mode. */
+int64_t evac_obs_dim(evac_handle_t h);
+int32_t evac_num_envs(evac_handle_t h);
+
+/* Bind the caller-owned state buffers (device pointers, layouts above). */
+int evac_bind_state(evac_handle_t h, float* ped, uint8_t* status, float* agent, int32_t* clock, float* acc);
+
+/* EvacuationEnv.reset (env.py:106-139) for every env, or for those with mask[e] != 0.
+ * draws_or_null: float [E][N][4] of U(-1,1) values (pos.x, pos.y, dir.x, dir.y) replacing the Philox
+ * draws (pedestrians.py:17-18) -- the injection mode used by the parity tests.
+ * obs_out_or_null: reset observation, float [E][D] (only rows of reset envs are written). */
+int evac_reset(evac_handle_t h, const uint8_t* mask_or_null, const float* draws_or_null,
+               float* obs_out_or_null, void* stream);
+
+/* EvacuationEnv.step + observation wrappers (env.py:141-171, area.py:76-210, statuses.py:29-48,
+ * reward.py:19-47, gravity_encoding.py:8-81, wrappers.py:8-96) for the whole batch, one launch.
+ *   actions            float [E][2]  (device)
+ *   noise_or_null      float [E][N]  per-pedestrian angular noise (injection mode); NULL = Philox
+ *   obs_out            float [E][D]
+ *   reward_out         float [E];  terminated_out / truncated_out  uint8 [E]
+ *   autoreset != 0     finished envs are reset in the same launch (gymnasium-0.29 SyncVectorEnv
+ *                      semantics, rpo_agent.py:193-203): obs_out then holds the reset observation,
+ *                      final_obs_or_null [E][D] the terminal one, final_stats_or_null [E] the episode record
+ */
+int evac_step(evac_handle_t h, const float* actions, const float* noise_or_null, float* obs_out,
+              float* reward_out, uint8_t* terminated_out, uint8_t* truncated_out, int32_t autoreset,
+              float* final_obs_or_null, evac_episode_stats_t* final_stats_or_null, void* stream);
+
+/* T consecutive steps in ONE launch with the env state held in registers/LDS (the trainer's rollout
+ * loop rpo_agent.py:180-203 with the policy replaced by caller-provided or RandomAgent actions,
+ * random_agent.py:8-9).  Always autoresets.  Buffers are time-major:
+ *   actions_or_null  float [T][E][2]   NULL = draw U(-1,1)^2 on device (Philox)
+ *   actions_out_or_null float [T][E][2] records the actions actually used
+ *   obs_out float [T][E][D]; reward_out float [T][E]; terminated_out/truncated_out uint8 [T][E]
+ *   final_stats_or_null [T][E] (rows of envs that finished at step t) */
+int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions_or_null, float* actions_out_or_null,
+                 float* obs_out, float* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
+                 evac_episode_stats_t* final_stats_or_null, void* stream);
+
+/* State exchange in the reference's own shapes (needed for parity tests, checkpoints):
+ * pos/dir float [E][N][2], status uint8 [E][N], agent_pos/agent_dir float [E][2], now int32 [E]. */
+int evac_get_state(evac_handle_t h, float* pos, float* dir, uint8_t* status, float* agent_pos,
+                   float* agent_dir, int32_t* now, void* stream);
+int evac_set_state(evac_handle_t h, const float* pos, const float* dir, const uint8_t* status,
+                   const float* agent_pos, const float* agent_dir, const int32_t* now, void* stream);
+
+/* Observation of the current state without stepping (EvacuationEnv._get_observation through the
+ * wrapper chain, env.py:98-104). */
+int evac_observe(evac_handle_t h, float* obs_out, void* stream);
+
+/* Algorithmic HBM bytes of one env-step for this handle (32N+62 for grav, 56N+86
+ * for Box+ohe, ...).  Used by bench.py for roofline accounting. */
+int64_t evac_algorithmic_bytes_per_env_step(evac_handle_t h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVAC_H */

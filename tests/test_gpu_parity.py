@@ -1,0 +1,428 @@
+"""GPU parity: the HIP step path (through the libevac C ABI) against the oracle on identical inputs.
+
+The bar (BASELINE.json north_star): fp32 results within 1e-5 of the NumPy reference on identical
+state / actions / noise; statuses, flags and counts exact.  The oracle runs in the REFERENCE's
+precision (f64 pedestrians) from the same f32-representable inputs the GPU gets.  A threshold
+comparison whose f64 margin is below 1e-6 may legitimately flip in f32 (SURVEY.md 7 'Parity
+definition'); such envs are excluded from the element-wise check and counted.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import evac_oracle as O
+from oracle import philox as P
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5
+TIE = 1e-6
+
+
+@pytest.fixture(scope="module")
+def ea():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("gpu tests need an MI355X (torch.cuda.is_available() is False)")
+    import evacuation_amd
+    from evacuation_amd import _lib
+    _lib.load()
+    return evacuation_amd
+
+
+def cfg_from_params(ea, p: O.OracleParams, **kw):
+    d = {k: getattr(p, k) for k in ("number_of_pedestrians", "width", "height", "step_size", "noise_coef", "eps",
+                                    "enslaving_degree", "is_new_exiting_reward", "is_new_followers_reward",
+                                    "intrinsic_reward_coef", "is_termination_agent_wall_collision",
+                                    "init_reward_each_step", "max_timesteps")}
+    d.update(kw)
+    return ea.EnvConfig(**d)
+
+
+def f32_state(st: O.OracleState) -> O.OracleState:
+    """Round the pedestrian state to f32 (what the GPU holds) but keep the reference's f64 dtype."""
+    s = st.copy()
+    s.pos = s.pos.astype(np.float32).astype(np.float64)
+    s.dir = s.dir.astype(np.float32).astype(np.float64)
+    return s
+
+
+def gpu_step_batch(ea, p, wrap, states, actions, noise, autoreset=False):
+    """Each state is one env of a batch; ONE evac_step launch."""
+    env = ea.BatchedEvacuationEnv(cfg_from_params(ea, p), wrap, num_envs=len(states), autoreset=autoreset)
+    env.set_state(pos=np.stack([s.pos for s in states]).astype(np.float32),
+                  dir=np.stack([s.dir for s in states]).astype(np.float32),
+                  status=np.stack([s.status for s in states]).astype(np.uint8),
+                  agent_pos=np.stack([s.agent_pos for s in states]).astype(np.float32),
+                  agent_dir=np.stack([s.agent_dir for s in states]).astype(np.float32),
+                  now=np.array([s.now for s in states], dtype=np.int32))
+    obs, rew, term, trunc, _ = env.step(np.asarray(actions, dtype=np.float32), noise=np.asarray(noise, dtype=np.float32))
+    st = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+    out = dict(obs=obs.cpu().numpy().copy(), reward=rew.cpu().numpy().copy(), terminated=term.cpu().numpy().astype(bool),
+               truncated=trunc.cpu().numpy().astype(bool), **st)
+    env.close()
+    return out
+
+
+def flat_oracle_obs(st, wrap, eps):
+    o = O.observe(st, wrap.positions, wrap.statuses, wrap.type, alpha=wrap.alpha, eps=eps)
+    if wrap.positions == "grav":
+        return np.concatenate([o["agent_position"], o["grad_potential_exit"], o["grad_potential_pedestrians"]]).astype(np.float64)
+    if wrap.type == "Box":
+        return np.asarray(o, dtype=np.float64).reshape(-1)
+    parts = [o["agent_position"], o["exit_position"], o["pedestrians_positions"].reshape(-1)]
+    if "pedestrians_statuses" in o:
+        parts.append(np.asarray(o["pedestrians_statuses"]).reshape(-1))
+    return np.concatenate(parts).astype(np.float64)
+
+
+def grav_tolerance(st, alpha, eps):
+    """Absolute tolerance for the gravity sums: 1e-5 relative to the sum of |terms| (an f32 sum of
+    terms up to alpha/0.2^(alpha+1) cannot be held to an absolute 1e-5)."""
+    m = st.status == O.VISCEK
+    r = st.agent_pos.astype(np.float64)[None, :] - st.pos[m]
+    scale = 1.0
+    if len(r):
+        nrm = np.linalg.norm(r, axis=1) + eps
+        scale += float(np.sum(alpha / nrm ** (alpha + 1)))
+    re = st.agent_pos.astype(np.float64) - O.EXIT_POSITION
+    nf = float(np.sum(st.status == O.FOLLOWER))
+    scale_exit = 1.0 + nf * alpha / (np.linalg.norm(re) + eps) ** (alpha + 1)
+    return 1e-5 * scale, 1e-5 * scale_exit
+
+
+def compare_step(p, wrap, pre_states, actions, noise, got, min_checked=1):
+    """Oracle (reference precision) from the same f32-representable inputs vs the GPU outputs."""
+    checked = ties = 0
+    worst = 0.0
+    for e, pre in enumerate(pre_states):
+        st = f32_state(pre)
+        pre_pos = st.pos.copy()
+        with np.errstate(all="ignore"):
+            out = O.env_step(p, st, np.asarray(actions[e], dtype=np.float32), np.asarray(noise[e], dtype=np.float32).astype(np.float64))
+        margin = O.threshold_margin(st.pos, st.agent_pos, pre_pos, p.width, p.height, st.status)
+        if np.isfinite(st.pos).all() and margin < TIE:
+            ties += 1
+            continue
+        checked += 1
+        np.testing.assert_array_equal(got["status"][e], st.status, err_msg=f"env {e} status")
+        np.testing.assert_allclose(got["pos"][e], st.pos, rtol=0, atol=ATOL, equal_nan=True, err_msg=f"env {e} pos")
+        np.testing.assert_allclose(got["dir"][e], st.dir, rtol=0, atol=ATOL, equal_nan=True, err_msg=f"env {e} dir")
+        np.testing.assert_allclose(got["agent_pos"][e], st.agent_pos, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(got["agent_dir"][e], st.agent_dir, rtol=0, atol=1e-8)
+        assert got["now"][e] == st.now
+        np.testing.assert_allclose(got["reward"][e], out["reward"], rtol=1e-5, atol=1e-5, equal_nan=True, err_msg=f"env {e} reward")
+        assert bool(got["terminated"][e]) == out["terminated"], f"env {e} terminated"
+        assert bool(got["truncated"][e]) == out["truncated"], f"env {e} truncated"
+        if np.isfinite(st.pos).all():
+            worst = max(worst, float(np.abs(got["pos"][e] - st.pos).max()), float(np.abs(got["dir"][e] - st.dir).max()))
+        ref_obs = flat_oracle_obs(st, wrap, p.eps)
+        if wrap.positions == "grav":
+            tol_p, tol_e = grav_tolerance(st, wrap.alpha, p.eps)
+            np.testing.assert_allclose(got["obs"][e][0:2], ref_obs[0:2], rtol=0, atol=1e-7, equal_nan=True)
+            np.testing.assert_allclose(got["obs"][e][2:4], ref_obs[2:4], rtol=2e-5, atol=tol_e, equal_nan=True, err_msg=f"env {e} grad_exit")
+            np.testing.assert_allclose(got["obs"][e][4:6], ref_obs[4:6], rtol=2e-5, atol=tol_p, equal_nan=True, err_msg=f"env {e} grad_ped")
+        else:
+            np.testing.assert_allclose(got["obs"][e], ref_obs, rtol=0, atol=ATOL, equal_nan=True, err_msg=f"env {e} obs")
+    assert checked >= min_checked, (checked, ties)
+    return checked, ties, worst
+
+
+WRAPS = [dict(positions="grav", alpha=3), dict(positions="grav", alpha=2), dict(positions="grav", alpha=5),
+         dict(positions="grav", alpha=2.5),
+         dict(positions="abs"), dict(positions="rel"), dict(positions="abs", statuses="ohe"),
+         dict(positions="rel", statuses="cat"), dict(positions="rel", statuses="ohe", type="Box"),
+         dict(positions="abs", statuses="cat", type="Box"), dict(positions="rel", statuses="no", type="Box")]
+
+
+@pytest.mark.parametrize("path", H.traj_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_teacher_forced_steps_match_reference_fixtures(ea, path):
+    """Every recorded reference step becomes one env of a batch: same pre-state, action, noise."""
+    d = np.load(path)
+    p = H.load_params(d["params_json"])
+    K = len(d["action"])
+    pre = [H.state_at(d, k) for k in range(K)]
+    total_ties = 0
+    for i, w in enumerate(WRAPS if p.number_of_pedestrians <= 256 else WRAPS[:1] + WRAPS[8:9]):
+        wrap = ea.EnvWrappersConfig(**w)
+        got = gpu_step_batch(ea, p, wrap, pre, d["action"], d["noise"])
+        checked, ties, worst = compare_step(p, wrap, pre, d["action"], d["noise"], got, min_checked=max(1, K - 4))
+        total_ties = max(total_ties, ties)
+        assert worst < 2e-6, worst          # in practice a few f32 ulp
+    assert total_ties <= 4
+
+
+@pytest.mark.parametrize("name,c", list(H.crafted_cases()), ids=[n for n, _ in H.crafted_cases()])
+def test_crafted_edge_cases(ea, name, c):
+    """Leader wall hit, corner reflection, landing on the exit, all-escaped termination, truncation,
+    reward transitions, empty noise draw, NaN poisoning (area.py:101), zero action, zero mean heading."""
+    p = H.load_params(c["params_json"])
+    pre = O.OracleState(c["pre_pos"].copy(), c["pre_dir"].copy(), c["pre_status"].copy(), c["pre_agent_pos"].copy(),
+                        c["pre_agent_dir"].copy(), int(c["pre_now"]))
+    for w in (dict(positions="grav", alpha=3), dict(positions="rel", statuses="ohe", type="Box"), dict(positions="abs", statuses="cat")):
+        wrap = ea.EnvWrappersConfig(**w)
+        got = gpu_step_batch(ea, p, wrap, [pre], [c["action"]], [c["noise"]])
+        compare_step(p, wrap, [pre], [c["action"]], [c["noise"]], got)
+        # and against the reference's own recorded outputs
+        np.testing.assert_array_equal(got["status"][0], c["post_status"])
+        np.testing.assert_allclose(got["pos"][0], c["post_pos"], rtol=0, atol=ATOL, equal_nan=True)
+        np.testing.assert_allclose(got["reward"][0], c["reward"], rtol=1e-5, atol=1e-5, equal_nan=True)
+        assert bool(got["terminated"][0]) == bool(c["terminated"]) and bool(got["truncated"][0]) == bool(c["truncated"])
+
+
+def test_nan_guard_is_opt_in(ea):
+    c = dict(H.crafted_cases())["nan_poison_zero_heading"]
+    p = H.load_params(c["params_json"])
+    env = ea.BatchedEvacuationEnv(cfg_from_params(ea, p, nan_guard=True), ea.EnvWrappersConfig(), num_envs=1, autoreset=False)
+    env.set_state(pos=c["pre_pos"][None].astype(np.float32), dir=c["pre_dir"][None].astype(np.float32),
+                  status=c["pre_status"][None].astype(np.uint8), agent_pos=c["pre_agent_pos"][None],
+                  agent_dir=c["pre_agent_dir"][None], now=np.array([int(c["pre_now"])], dtype=np.int32))
+    env.step(c["action"][None].astype(np.float32), noise=c["noise"][None].astype(np.float32))
+    st = env.get_state()
+    assert np.isfinite(st["pos"].cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("path", H.traj_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_reset_from_injected_draws(ea, path):
+    d = np.load(path)
+    p = H.load_params(d["params_json"])
+    draws = np.concatenate([d["draw_pos"], d["draw_dir"]], axis=1).astype(np.float32)[None]
+    for w in (dict(positions="grav", alpha=3), dict(positions="rel", statuses="ohe", type="Box")):
+        wrap = ea.EnvWrappersConfig(**w)
+        env = ea.BatchedEvacuationEnv(cfg_from_params(ea, p), wrap, num_envs=1, autoreset=False)
+        obs, _ = env.reset(draws=draws)
+        obs = obs.cpu().numpy().copy()
+        st = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+        ref = O.env_reset(p, draws[0, :, 0:2].astype(np.float64), draws[0, :, 2:4].astype(np.float64))
+        np.testing.assert_array_equal(st["pos"][0], ref.pos.astype(np.float32))
+        np.testing.assert_allclose(st["dir"][0], ref.dir, rtol=0, atol=1e-6)
+        if O.threshold_margin(ref.pos, ref.agent_pos, None, p.width, p.height) > TIE:
+            np.testing.assert_array_equal(st["status"][0], ref.status)
+            ref_obs = flat_oracle_obs(ref, wrap, p.eps)
+            if wrap.positions == "grav":
+                tol_p, tol_e = grav_tolerance(ref, wrap.alpha, p.eps)
+                np.testing.assert_allclose(obs[0][4:6], ref_obs[4:6], rtol=2e-5, atol=tol_p)
+                np.testing.assert_allclose(obs[0][0:4], ref_obs[0:4], rtol=2e-5, atol=tol_e)
+            else:
+                np.testing.assert_allclose(obs[0], ref_obs, rtol=0, atol=ATOL)
+        assert (st["agent_pos"] == 0).all() and (st["agent_dir"] == 0).all() and st["now"][0] == 0
+        env.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 33, 64, 65, 100, 256, 300, 512, 600, 1024])
+def test_random_states_all_sizes(ea, n):
+    """Kernel geometry edges (1 wave, 4/8/16-wave workgroups, ragged last wave) on oracle-generated
+    states: random reset, a few oracle steps to mix statuses, then one teacher-forced step."""
+    rng = np.random.default_rng(100 + n)
+    p = O.OracleParams(number_of_pedestrians=n, is_new_exiting_reward=True, intrinsic_reward_coef=0.5, enslaving_degree=0.7)
+    E = 6 if n <= 256 else 3
+    pre, acts, nzs = [], [], []
+    for e in range(E):
+        st = O.env_reset(p, rng.uniform(-1, 1, (n, 2)), rng.uniform(-1, 1, (n, 2)))
+        for _ in range(e * 3):
+            O.env_step(p, st, rng.uniform(-1, 1, 2).astype(np.float32), rng.uniform(-0.1, 0.1, n))
+        pre.append(st)
+        acts.append(rng.uniform(-1, 1, 2).astype(np.float32))
+        nzs.append(rng.uniform(-0.1, 0.1, n).astype(np.float32))
+    for w in (dict(positions="grav", alpha=3), dict(positions="rel", statuses="ohe", type="Box")):
+        wrap = ea.EnvWrappersConfig(**w)
+        got = gpu_step_batch(ea, p, wrap, pre, acts, nzs)
+        compare_step(p, wrap, pre, acts, nzs, got, min_checked=E - 2)
+
+
+def test_free_running_50_steps_vs_reference_fixture(ea):
+    """Same reset draws, actions and per-pedestrian noise as the reference episode; free-running."""
+    d = np.load(os.path.join(H.GOLDEN, "traj_n60_s1_noise05_ens05.npz"))
+    p = H.load_params(d["params_json"])
+    env = ea.BatchedEvacuationEnv(cfg_from_params(ea, p), ea.EnvWrappersConfig(positions="grav", alpha=3), num_envs=1, autoreset=False)
+    draws = np.concatenate([d["draw_pos"], d["draw_dir"]], axis=1).astype(np.float32)[None]
+    env.reset(draws=draws)
+    for k in range(50):
+        obs, r, te, tr, _ = env.step(d["action"][k][None], noise=d["noise"][k][None].astype(np.float32))
+        st = env.get_state()
+        np.testing.assert_allclose(st["pos"].cpu().numpy()[0], d["pos"][k + 1], rtol=0, atol=ATOL, err_msg=f"step {k}")
+        np.testing.assert_array_equal(st["status"].cpu().numpy()[0], d["status"][k + 1])
+        np.testing.assert_allclose(float(r[0]), d["reward"][k], rtol=1e-5, atol=1e-4)
+    env.close()
+
+
+def test_philox_reset_and_noise_are_bit_exact(ea):
+    """Device Philox streams == oracle/philox.py, for a handle with an env_id_offset."""
+    n, E, seed, off = 60, 5, 0x5EED0001, 37
+    p = O.OracleParams(number_of_pedestrians=n)
+    env = ea.BatchedEvacuationEnv(cfg_from_params(ea, p), ea.EnvWrappersConfig(positions="grav"), num_envs=E, seed=seed,
+                                  env_id_offset=off, autoreset=False)
+    env.reset()
+    st = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+    draws = P.reset_draws(seed, off + np.arange(E), n, 0)
+    np.testing.assert_array_equal(st["pos"], draws[..., 0:2])
+    nrm = np.sqrt(draws[..., 2] ** 2 + draws[..., 3] ** 2)
+    np.testing.assert_allclose(st["dir"], draws[..., 2:4] / nrm[..., None], rtol=0, atol=2e-7)
+    # one Philox step == the same step with the oracle's noise injected
+    act = np.tile(np.array([[0.3, -0.8]], dtype=np.float32), (E, 1))
+    env2 = ea.BatchedEvacuationEnv(cfg_from_params(ea, p), ea.EnvWrappersConfig(positions="grav"), num_envs=E, seed=seed,
+                                   env_id_offset=off, autoreset=False)
+    env2.reset()
+    for t in range(6):       # crosses the 4-step Philox block boundary
+        env.step(act)
+        env2.step(act, noise=P.step_noise(seed, off + np.arange(E), n, t, p.noise_coef))
+        a, b = env.get_state(), env2.get_state()
+        for k in a:
+            assert (a[k] == b[k]).all(), (t, k)
+    env.close(); env2.close()
+
+
+def test_rollout_equals_step_by_step_and_oracle(ea):
+    """evac_rollout (T steps, one launch, RandomAgent actions on device) is bit-identical to T
+    evac_step launches fed the same actions, and within 1e-5 of the oracle for the first steps."""
+    n, E, T, seed = 60, 8, 40, 0x5EED0002
+    p = O.OracleParams(number_of_pedestrians=n, is_new_exiting_reward=True, max_timesteps=25)   # truncation + autoreset inside
+    wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
+    a = ea.BatchedEvacuationEnv(cfg_from_params(ea, p), wrap, num_envs=E, seed=seed)
+    b = ea.BatchedEvacuationEnv(cfg_from_params(ea, p), wrap, num_envs=E, seed=seed)
+    a.reset(); b.reset()
+    ro = a.rollout(T, record_actions=True)
+    acts = ro["actions"].cpu().numpy()
+    np.testing.assert_array_equal(acts[0], P.random_action(seed, np.arange(E), 0))
+    np.testing.assert_array_equal(acts[7], P.random_action(seed, np.arange(E), 7))
+    n_done = 0
+    for t in range(T):
+        obs, r, te, tr, info = b.step(ro["actions"][t].contiguous())
+        assert (obs == ro["obs"][t]).all(), t
+        assert (r == ro["reward"][t]).all() and (te == ro["terminated"][t]).all() and (tr == ro["truncated"][t]).all(), t
+        done = (te | tr).bool()
+        n_done += int(done.sum())
+        if done.any():
+            assert (info["episode_stats"][done] == ro["episode_stats"][t][done]).all()
+    assert n_done >= E                                   # every env truncated at least once
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert (sa[k] == sb[k]).all(), k
+    # oracle free-run on env 3 with the same Philox draws
+    e = 3
+    dr = P.reset_draws(seed, [e], n, 0)[0]
+    st = O.env_reset(p, dr[:, 0:2].astype(np.float64), dr[:, 2:4].astype(np.float64))
+    rew = ro["reward"].cpu().numpy()
+    for t in range(20):
+        out = O.env_step(p, st, acts[t, e], P.step_noise(seed, [e], n, t, p.noise_coef)[0].astype(np.float64))
+        np.testing.assert_allclose(rew[t, e], out["reward"], rtol=1e-5, atol=1e-4, err_msg=f"t={t}")
+    a.close(); b.close()
+
+
+def test_autoreset_semantics(ea):
+    """Same-step autoreset (gymnasium 0.29 SyncVectorEnv, rpo_agent.py:193-203): obs is the reset
+    obs, final_observation the terminal one, episode stats recorded, state re-drawn from Philox."""
+    n, E, seed = 30, 4, 99
+    p = O.OracleParams(number_of_pedestrians=n, max_timesteps=3)
+    wrap = ea.EnvWrappersConfig(positions="rel", statuses="ohe", type="Box")
+    env = ea.BatchedEvacuationEnv(cfg_from_params(ea, p), wrap, num_envs=E, seed=seed)
+    twin = ea.BatchedEvacuationEnv(cfg_from_params(ea, p), wrap, num_envs=E, seed=seed, autoreset=False)
+    env.reset(); twin.reset()
+    act = np.tile(np.array([[1.0, 0.5]], dtype=np.float32), (E, 1))
+    ret = np.zeros(E)
+    for t in range(3):
+        obs, r, te, tr, info = env.step(act)
+        o2, r2, _, tr2, _ = twin.step(act)
+        ret += r.cpu().numpy()
+        assert (r == r2).all() and (tr == tr2).all()
+    assert tr.bool().all() and not te.bool().any()
+    assert (info["final_observation"] == o2).all()              # terminal obs preserved
+    stats = info["episode_stats"].cpu().numpy()
+    np.testing.assert_allclose(stats[:, 0], ret, rtol=1e-6)
+    assert (stats[:, 1] == 3).all() and (stats[:, 4:8].sum(axis=1) == n).all()
+    fin = env.final_info_list(info)
+    assert fin[0]["episode"]["l"] == 3 and abs(fin[0]["episode"]["r"] - ret[0]) < 1e-4
+    st = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+    np.testing.assert_array_equal(st["pos"], P.reset_draws(seed, np.arange(E), n, 1)[..., 0:2])   # second reset of each env
+    assert (st["now"] == 0).all() and (st["agent_pos"] == 0).all()
+    assert (env.clock[:, 1] == 2).all() and (env.clock[:, 2] == 3).all()
+    assert (env.observe(out=obs.clone()) == obs).all()          # returned obs == obs of the fresh state
+    env.close(); twin.close()
+
+
+def test_sharded_handles_reproduce_single_handle(ea):
+    """env_id_offset keys the Philox streams by GLOBAL env id: 2 shards == 1 big batch, bit for bit."""
+    n, E, seed, T = 60, 16, 5, 30
+    p = O.OracleParams(number_of_pedestrians=n, max_timesteps=20)
+    wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
+    whole = ea.BatchedEvacuationEnv(cfg_from_params(ea, p), wrap, num_envs=E, seed=seed)
+    lo = ea.BatchedEvacuationEnv(cfg_from_params(ea, p), wrap, num_envs=E // 2, seed=seed, env_id_offset=0)
+    hi = ea.BatchedEvacuationEnv(cfg_from_params(ea, p), wrap, num_envs=E // 2, seed=seed, env_id_offset=E // 2)
+    for e in (whole, lo, hi):
+        e.reset()
+    rw, rl, rh = whole.rollout(T), lo.rollout(T), hi.rollout(T)
+    for k in ("obs", "reward", "terminated", "truncated"):
+        assert (rw[k][:, :E // 2] == rl[k]).all() and (rw[k][:, E // 2:] == rh[k]).all(), k
+
+
+def test_full_size_invariants_c2(ea):
+    """BASELINE config 2 (N=60 x 4096 envs, gravity obs): size-independent properties after a long
+    on-device rollout -- walls, escaped pinned at the exit, status == classifier(position), step
+    length, reward bounds, truncation bookkeeping."""
+    import torch
+    n, E, T = 60, 4096, 300
+    cfg = ea.EnvConfig(number_of_pedestrians=n, is_new_exiting_reward=True, max_timesteps=200)
+    env = ea.BatchedEvacuationEnv(cfg, ea.EnvWrappersConfig(positions="grav", alpha=3), num_envs=E, seed=0x5EED0001)
+    env.reset()
+    ro = env.rollout(T)
+    torch.cuda.synchronize()
+    st = env.get_state()
+    pos, dr, status = st["pos"], st["dir"], st["status"]
+    assert torch.isfinite(pos).all() and torch.isfinite(ro["obs"]).all() and torch.isfinite(ro["reward"]).all()
+    assert (pos.abs() <= 1.0).all()
+    esc = status == 4
+    assert (pos[esc] == torch.tensor([0.0, -1.0], device=pos.device)).all() or (pos[esc] - torch.tensor([0.0, -1.0], device=pos.device)).norm(dim=-1).max() < 0.01
+    # status is a pure function of the position (statuses.py:29-48): recompute with torch f32
+    ap = st["agent_pos"][:, None, :]
+    d_lead = (pos - ap).norm(dim=-1)
+    d_exit = (pos - torch.tensor([0.0, -1.0], device=pos.device)).norm(dim=-1)
+    want = torch.ones_like(status)
+    want[d_lead < 0.2] = 2
+    want[d_exit < 0.4] = 3
+    want[d_exit < 0.01] = 4
+    near_tie = ((d_lead - 0.2).abs() < 1e-6) | ((d_exit - 0.4).abs() < 1e-6) | ((d_exit - 0.01).abs() < 1e-6)
+    assert ((want == status) | near_tie).all()
+    assert set(torch.unique(status).tolist()) <= {1, 2, 3, 4}
+    # Vicsek pedestrians move exactly one step length
+    v = status == 1
+    np.testing.assert_allclose(dr[v].norm(dim=-1).cpu().numpy(), cfg.step_size, rtol=1e-5)
+    # rewards: -1 per step minus wall penalty plus at most N transition bonuses
+    r = ro["reward"]
+    assert r.min() >= -6.0 - 1e-4 and r.max() <= -1.0 + 25.0 * n
+    # every env was truncated at t=199 (0-based) exactly once in the first 200 steps, then again later
+    tr = ro["truncated"].bool()
+    assert tr[199].all() and not tr[:199].any()
+    stats = ro["episode_stats"][199]
+    assert (stats[:, 1] == 200).all() and (stats[:, 4:8].sum(dim=1) == n).all()
+    np.testing.assert_allclose(stats[:, 0].cpu().numpy(), r[:200].sum(dim=0).cpu().numpy(), rtol=1e-4)
+    env.close()
+
+
+def test_single_env_facade_matches_reference_surface(ea):
+    """setup_env() / reset() / step() with NumPy in/out (src/env/__init__.py:18-21, README.md:69-91)."""
+    d = np.load(os.path.join(H.GOLDEN, "traj_n60_s0.npz"))
+    p = H.load_params(d["params_json"])
+    env = ea.setup_env(cfg_from_params(ea, p), ea.EnvWrappersConfig(positions="abs", statuses="ohe"))
+    draws = np.concatenate([d["draw_pos"], d["draw_dir"]], axis=1)
+    obs, info = env.reset(options={"draws": draws})
+    assert info == {} and set(obs) == {"agent_position", "exit_position", "pedestrians_positions", "pedestrians_statuses"}
+    assert obs["pedestrians_positions"].shape == (60, 2) and obs["pedestrians_statuses"].shape == (60, 4)
+    np.testing.assert_allclose(obs["pedestrians_positions"], d["obs_abs_ohe_dict__pedestrians_positions"][0], atol=1e-6)
+    np.testing.assert_array_equal(obs["pedestrians_statuses"], d["obs_abs_ohe_dict__pedestrians_statuses"][0])
+    obs, reward, terminated, truncated, info = env.step(d["action"][0], noise=d["noise"][0])
+    assert isinstance(reward, float) and isinstance(terminated, bool) and isinstance(truncated, bool) and info == {}
+    np.testing.assert_allclose(reward, d["reward"][0], rtol=1e-5)
+    u = env.unwrapped
+    np.testing.assert_allclose(u.pedestrians.positions, d["pos"][1], atol=ATOL)
+    assert [s.value for s in u.pedestrians.statuses] == d["status"][1].tolist()
+    assert u.area.exit.position.tolist() == [0.0, -1.0] and u.area.step_size == p.step_size and u.time.now == 1
+    with pytest.raises(TypeError):
+        env.step([1, 0])                       # integer action: the reference raises too (area.py:190)
+    agent = ea.RandomAgent(env.action_space)
+    for _ in range(3):
+        obs, reward, terminated, truncated, _ = env.step(agent.act(obs))
+    env.close()
+    with pytest.raises(NotImplementedError):
+        ea.setup_env(cfg_from_params(ea, p), ea.EnvWrappersConfig(positions="grav", type="Box"))
