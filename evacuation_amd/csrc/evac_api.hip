@@ -167,6 +167,9 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
     // constants.py:35-38.  Squared radii are rounded from the double product.
     p.r_leader2 = (float)(0.2 * 0.2);
     p.r_ped2 = (float)(0.1 * 0.1);
+    p.r_ped2_big = p.r_ped2 * 0x1.0p100f;   // exact (power-of-two scale)
+    p.inv_n = (float)(1.0 / (double)cfg->number_of_pedestrians);
+    p.inv_200n = (float)(1.0 / (200.0 * (double)cfg->number_of_pedestrians));
     p.r_exit = 0.4f;
     p.r_escape = 0.01f;
     p.obs_pos = cfg->positions;

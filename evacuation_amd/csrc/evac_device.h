@@ -22,6 +22,9 @@ namespace evac {
 constexpr int kViscek = 1, kFollower = 2, kExiting = 3, kEscaped = 4;   // statuses.py:16-27
 constexpr float kExitX = 0.0f, kExitY = -1.0f;                           // area.py:39
 constexpr int kWave = 64;
+// native 16-byte vector: loads/stores of it are single ds_read_b128 / ds_write_b128 (HIP's float4 is
+// copied member-wise and re-merged only to 8-byte alignment, i.e. ds_read2_b64 at half the LDS rate)
+using f4 = float __attribute__((ext_vector_type(4)));
 
 // Philox stream ids (counter word 3)
 constexpr uint32_t kStreamNoise = 0x4e4f4953u;   // 'NOIS'
@@ -35,6 +38,8 @@ struct Params {
     float init_reward, intrinsic_coef;
     int32_t new_exiting_reward, new_followers_reward, term_on_wall, max_timesteps;
     float r_leader2, r_ped2, r_exit, r_escape;     // constants.py:35-38 (squared where compared squared)
+    float r_ped2_big;                               // r_ped2 * 2^100 (exact): see neighbour_weight()
+    float inv_n, inv_200n;                          // 1/N, 1/(200 N)
     int32_t obs_pos, obs_stat, obs_box, obs_dim;
     float alpha, neg_alpha, grav_pow;               // grav_pow = alpha + 2
     int32_t grav_pow_int;                           // alpha+2 if it is an integer in [1,32], else 0
@@ -71,12 +76,41 @@ __device__ __forceinline__ float usym(uint32_t x) { return 2.0f * u01(x) - 1.0f;
 // ------------------------------------------------------------------------------------------------
 // wave-level helpers
 // ------------------------------------------------------------------------------------------------
+// DPP add step: v + (v moved by `ctrl`), lanes without a source (or in rows masked off) add 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+// Sum over the 64 lanes, result wave-uniform (an SGPR).  row_shr 1/2/4/8 leave each row's total in
+// its lane 15; row_bcast:15 / row_bcast:31 fold the rows into lane 63 (the rocPRIM gfx9 scheme).
+// ~2.5x cheaper than six ds_bpermute butterflies (tools/microbench/valu_rates.hip).
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, kWave);
-    return v;
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    v = dpp_add<0x142, 0xa>(v);
+    v = dpp_add<0x143, 0xc>(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ int wave_count(bool p) { return __popcll(__ballot(p)); }
+
+// 1-ulp hardware reciprocal / rsqrt / sqrt (v_rcp_f32, v_rsq_f32, v_sqrt_f32) instead of the ~10
+// instruction IEEE division / sqrt sequences: the parity bar is 1e-5, these are ~1e-7 relative.
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+// Neighbour weight 1.0 if d2 < r2 else 0.0 in ONE full-rate instruction: (r2 - d2) * 2^100 saturated
+// to [0,1] by the VOP3 clamp modifier.  r2*2^100 and d2*2^100 are exact, so the FMA's sign is exactly
+// the sign of r2 - d2; any positive difference (>= 1 ulp of 0.01) times 2^100 saturates to exactly 1;
+// d2 == r2 gives 0 (strict <, as distances.py / area.py:107); NaN and +inf give 0 (DX10 clamp).
+// v_cmp + v_cndmask costs ~3x as much (tools/microbench/valu_rates.hip).
+__device__ __forceinline__ float neighbour_weight(float d2, float r2_big) {
+    float w;
+    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(w) : "v"(d2), "v"(-0x1.0p100f), "v"(r2_big));
+    return w;
+}
 
 // x^k for a wave-uniform small integer k (square-and-multiply; a few ulp)
 __device__ __forceinline__ float powi(float x, int k) {
@@ -137,7 +171,7 @@ struct Geometry {
 
 template <int WPE>
 struct Smem {
-    float4 tile[Geometry<WPE>::kEnvsPerBlock][WPE * kWave];   // (x, y, ux, uy) of every pedestrian
+    f4 tile[Geometry<WPE>::kEnvsPerBlock][WPE * kWave];   // (x, y, ux, uy) of every pedestrian
     float redf[Geometry<WPE>::kEnvsPerBlock][WPE][4];
     int redi[Geometry<WPE>::kEnvsPerBlock][WPE][8];
 };
@@ -196,7 +230,7 @@ __device__ __forceinline__ int classify(const Params& p, float x, float y, float
     const float lx = x - ax, ly = y - ay;
     const float dl2 = lx * lx + ly * ly;
     const float ex = x - kExitX, ey = y - kExitY;
-    de = sqrtf(ex * ex + ey * ey);
+    de = fsqrt(ex * ex + ey * ey);
     int st = kViscek;
     if (dl2 < p.r_leader2) st = kFollower;
     if (de < p.r_exit) st = kExiting;
@@ -210,9 +244,9 @@ __device__ __forceinline__ int classify(const Params& p, float x, float y, float
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void grav_term(const Params& p, float rx, float ry, float& gx, float& gy) {
     // gravity_encoding.py:15-16,35-37:  -alpha / (|R| + eps)^(alpha+2) * R
-    const float nrm = sqrtf(rx * rx + ry * ry) + p.eps;
+    const float nrm = fsqrt(rx * rx + ry * ry) + p.eps;
     const float pw = p.grav_pow_int ? powi(nrm, p.grav_pow_int) : powf(nrm, p.grav_pow);
-    const float c = p.neg_alpha / pw;
+    const float c = p.neg_alpha * frcp(pw);
     gx = c * rx;
     gy = c * ry;
 }
@@ -244,13 +278,13 @@ __device__ __forceinline__ void write_obs(const Params& p, Smem<WPE>& sm, int sl
         return;
     }
     const bool rel = p.obs_pos == EVAC_POS_REL;
-    const float hyp = 1.41421356237f;                                 // wrappers.py:12-18 sqrt(1+1) in f32
+    const float ihyp = 0.70710678118f;                                // wrappers.py:12-18: 1/sqrt(1+1)
     float px = q.x, py = q.y, ex = kExitX, ey = kExitY;
     if (rel) {                                                        // wrappers.py:20-27
-        px = (q.x - e.ax) / hyp;
-        py = (q.y - e.ay) / hyp;
-        ex = (kExitX - e.ax) / hyp;
-        ey = (kExitY - e.ay) / hyp;
+        px = (q.x - e.ax) * ihyp;
+        py = (q.y - e.ay) * ihyp;
+        ex = (kExitX - e.ax) * ihyp;
+        ey = (kExitY - e.ay) * ihyp;
     }
     const int code = 4 - q.st;                                        // wrappers.py:49
     if (p.obs_box) {                                                  // wrappers.py:77-96
@@ -279,7 +313,7 @@ __device__ __forceinline__ void write_obs(const Params& p, Smem<WPE>& sm, int sl
                 row[4] = code == 2 ? 1.0f : 0.0f;
                 row[5] = code == 3 ? 1.0f : 0.0f;
             } else if (p.obs_stat == EVAC_STAT_CAT) {
-                row[2] = (float)code / 4.0f;
+                row[2] = (float)code * 0.25f;
             }
         }
         return;
@@ -302,7 +336,7 @@ __device__ __forceinline__ void write_obs(const Params& p, Smem<WPE>& sm, int sl
             st[4 * i + 2] = code == 2 ? 1.0f : 0.0f;
             st[4 * i + 3] = code == 3 ? 1.0f : 0.0f;
         } else if (p.obs_stat == EVAC_STAT_CAT) {                     // wrappers.py:55-56
-            st[i] = (float)code / 4.0f;
+            st[i] = (float)code * 0.25f;
         }
     }
 }
@@ -318,9 +352,9 @@ __device__ __forceinline__ void reset_env(const Params& p, bool active, float4 d
     e.acc_ret = e.acc_intr = e.acc_stat = 0.0f;
     q.x = draw.x;
     q.y = draw.y;
-    const float nrm = sqrtf(draw.z * draw.z + draw.w * draw.w);        // pedestrians.py:29-31
-    q.dx = draw.z / nrm;
-    q.dy = draw.w / nrm;
+    const float inrm = frsq(draw.z * draw.z + draw.w * draw.w);        // pedestrians.py:29-31
+    q.dx = draw.z * inrm;
+    q.dy = draw.w * inrm;
     float de;
     q.st = active ? classify(p, q.x, q.y, 0.0f, 0.0f, de) : 0;
 }
@@ -356,8 +390,8 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
     float r_agent = 0.0f;
     bool term_agent = false;
     {
-        const float nrm = sqrtf(act_x * act_x + act_y * act_y) + p.eps;   // area.py:190
-        const float nx = act_x / nrm, ny = act_y / nrm;
+        const float inrm = frcp(fsqrt(act_x * act_x + act_y * act_y) + p.eps);   // area.py:190
+        const float nx = act_x * inrm, ny = act_y * inrm;
         e.adx = p.step_size * nx;                                           // area.py:192
         e.ady = p.step_size * ny;
         const float tx = e.ax + e.adx, ty = e.ay + e.ady;                   // area.py:201
@@ -380,10 +414,12 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
     }
     if (q.st == kExiting) {                                                 // area.py:84-90
         const float vx = kExitX - q.x, vy = kExitY - q.y;
-        const float ln = sqrtf(vx * vx + vy * vy);
+        const float l2 = vx * vx + vy * vy;
+        const float ln = fsqrt(l2);
         const float sz = ln > p.step_size ? p.step_size : ln;
-        q.dx = vx / ln * sz;
-        q.dy = vy / ln * sz;
+        const float k = frsq(l2) * sz;                                      // (v / |v|) * min(|v|, step)
+        q.dx = vx * k;
+        q.dy = vy * k;
     }
     const bool efv = active && (q.st == kExiting || q.st == kFollower || q.st == kViscek);   // area.py:99
     const bool fv = active && (q.st == kFollower || q.st == kViscek);                         // area.py:104
@@ -393,16 +429,16 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
     float ux = 0.0f, uy = 0.0f;
     bool bad = false;
     if (efv) {
-        const float nrm = sqrtf(q.dx * q.dx + q.dy * q.dy);
-        ux = q.dx / nrm;
-        uy = q.dy / nrm;
+        const float inrm = frsq(q.dx * q.dx + q.dy * q.dy);               // 0 -> inf, 0 * inf = NaN as 0/0
+        ux = q.dx * inrm;
+        uy = q.dy * inrm;
         bad = (ux != ux) || (uy != uy);
         if (bad && p.nan_guard) ux = uy = 0.0f;
     }
     env_sync<WPE>();   // tile readers of the previous step are done
     // non-moving (escaped / padding) pedestrians are parked far away: they are not columns of the
     // reference's distance matrix (area.py:105-106)
-    sm.tile[slot][wave_in_env * kWave + lane] = make_float4(efv ? q.x : 3.0e38f, q.y, bad ? 0.0f : ux, bad ? 0.0f : uy);
+    sm.tile[slot][wave_in_env * kWave + lane] = f4{efv ? q.x : 3.0e38f, q.y, bad ? 0.0f : ux, bad ? 0.0f : uy};
     // (intersection * u).sum(): NaN * 0 = NaN, so ONE zero-heading pedestrian poisons every row
     // (area.py:118-119).  Reproduced exactly unless nan_guard.
     bool poison = false;
@@ -417,17 +453,23 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
     // mean heading, which arctan2 ignores; it is not needed.
     float sx = 0.0f, sy = 0.0f;
     {
-        const float4* __restrict__ tile = sm.tile[slot];
-        const int n = p.n_ped;
-        const float r2 = p.r_ped2;
-#pragma unroll 4
-        for (int j = 0; j < n; ++j) {
-            const float4 t = tile[j];
-            const float ddx = q.x - t.x, ddy = q.y - t.y;
-            const float d2 = ddx * ddx + ddy * ddy;
-            if (d2 < r2) {
-                sx += t.z;
-                sy += t.w;
+        // Branch-free, 8 peers per batch: the 8 wave-uniform ds_read_b128 broadcasts are issued back to
+        // back (LDS latency paid once per batch, no VALU slot), then 7 full-rate VALU ops per pair.
+        // Padding / parked entries (x = 3e38, u = 0) weigh 0, so the loop runs to a multiple of 8.
+        const f4* __restrict__ tile = sm.tile[slot];
+        const int n8 = (p.n_ped + 7) & ~7;
+        const float r2b = p.r_ped2_big;
+        for (int j = 0; j < n8; j += 8) {
+            f4 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = tile[j + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float ddx = q.x - t[k].x, ddy = q.y - t[k].y;
+                const float d2 = fmaf(ddy, ddy, ddx * ddx);
+                const float w = neighbour_weight(d2, r2b);
+                sx = fmaf(w, t[k].z, sx);
+                sy = fmaf(w, t[k].w, sy);
             }
         }
     }
@@ -438,9 +480,9 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
     if (fv) {
         float cx = 1.0f, cy = 0.0f;
         if (!(sx == 0.0f && sy == 0.0f)) {
-            const float l = sqrtf(sx * sx + sy * sy);
-            cx = sx / l;
-            cy = sy / l;
+            const float il = frsq(sx * sx + sy * sy);
+            cx = sx * il;
+            cy = sy * il;
         }
         float sn, cs;
         noise_sincos(noise, p.small_noise, sn, cs);
@@ -481,12 +523,11 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
     out.n_follower = s.i[4];
     out.n_viscek = s.i[5];
 
-    const float n_f = (float)p.n_ped;
-    const float tf = 1.0f - (float)e.now / (200.0f * n_f);                  // reward.py:26
+    const float tf = 1.0f - (float)e.now * p.inv_200n;                      // reward.py:26
     float r_ped = p.init_reward;
     if (p.new_exiting_reward) r_ped += (15.0f + 10.0f * tf) * (float)s.i[0];
     if (p.new_followers_reward) r_ped += (10.0f + 5.0f * tf) * (float)s.i[1];
-    const float intrinsic = 0.0f - s.f0 / n_f;                              // reward.py:19-21
+    const float intrinsic = 0.0f - s.f0 * p.inv_n;                          // reward.py:19-21
     out.reward = r_agent + r_ped + p.intrinsic_coef * intrinsic;           // env.py:158
     out.terminated = term_agent || (s.i[2] == p.n_ped);                     // area.py:175-178, env.py:171
     e.acc_ret += out.reward;                                                // env.py:168-170

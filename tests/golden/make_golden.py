@@ -191,7 +191,7 @@ def crafted_cases():
     """Hand-built pre-states (N=8) for the edge cases listed in SURVEY.md 8(c).  Statuses are the
     ones the reference's classifier would assign to these positions unless a case says otherwise."""
     N = 8
-    far = np.array([[-0.9 + 0.05 * i, 0.9] for i in range(N)])        # harmless VISCEK filler row
+    far = np.array([[-0.9 + 0.23 * i, 0.9 - 0.013 * i] for i in range(N)])   # harmless VISCEK filler row, no neighbours, no ties
     base_dir = np.tile(_unit([1.0, 0.3]) * 0.01, (N, 1))
     cases = []
 
@@ -274,6 +274,9 @@ def make_crafted(ref):
         with np.errstate(all="ignore"):
             obs = h.observations()
         name = c["name"]
+        if np.isfinite(post["pos"]).all():
+            mg = _margin(pre, post, h.cfg.width, h.cfg.height)
+            assert mg > 1e-5, (name, mg)      # crafted cases must not sit on a threshold
         names.append(name)
         out[f"{name}__params_json"] = json.dumps(_params_dict(h.cfg))
         out[f"{name}__action"] = c["action"]
