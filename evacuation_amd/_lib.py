@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libevac.so")
+# EVAC_LIB overrides the library path (profiling builds made by tools/ablate.sh only)
+LIB_PATH = os.environ.get("EVAC_LIB") or os.path.join(HERE, "libevac.so")
 
 EVAC_OK = 0
 ERR_INVALID_ARGUMENT, ERR_NOT_BOUND, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = -1, -2, -3, -4, -5

@@ -83,14 +83,26 @@ dim3 grid_for(int n_envs) {
     return dim3((unsigned)((n_envs + per - 1) / per));
 }
 
-#define EVAC_DISPATCH(h, KERNEL, stream, ...)                                                                   \
-    do {                                                                                                        \
-        const int wpe_ = waves_per_env((h)->p.n_ped);                                                           \
-        hipStream_t s_ = (hipStream_t)(stream);                                                                 \
-        if (wpe_ == 1) hipLaunchKernelGGL(evac::KERNEL<1>, grid_for<1>((h)->p.n_envs), dim3(evac::Geometry<1>::kBlock), 0, s_, __VA_ARGS__);      \
-        else if (wpe_ == 4) hipLaunchKernelGGL(evac::KERNEL<4>, grid_for<4>((h)->p.n_envs), dim3(evac::Geometry<4>::kBlock), 0, s_, __VA_ARGS__); \
-        else if (wpe_ == 8) hipLaunchKernelGGL(evac::KERNEL<8>, grid_for<8>((h)->p.n_envs), dim3(evac::Geometry<8>::kBlock), 0, s_, __VA_ARGS__); \
-        else hipLaunchKernelGGL(evac::KERNEL<16>, grid_for<16>((h)->p.n_envs), dim3(evac::Geometry<16>::kBlock), 0, s_, __VA_ARGS__);             \
+#define EVAC_LAUNCH(h, KERNEL, WPE_, GRAV_, s_, ...) \
+    hipLaunchKernelGGL((evac::KERNEL<WPE_, GRAV_>), grid_for<WPE_>((h)->p.n_envs), dim3(evac::Geometry<WPE_>::kBlock), 0, s_, __VA_ARGS__)
+
+// kernel variant = (waves per env) x (gravity observation | generic positions/statuses observation)
+#define EVAC_DISPATCH(h, KERNEL, stream, ...)                                         \
+    do {                                                                              \
+        const int wpe_ = waves_per_env((h)->p.n_ped);                                 \
+        const bool grav_ = (h)->p.obs_pos == EVAC_POS_GRAV;                           \
+        hipStream_t s_ = (hipStream_t)(stream);                                       \
+        if (grav_) {                                                                  \
+            if (wpe_ == 1) EVAC_LAUNCH(h, KERNEL, 1, true, s_, __VA_ARGS__);          \
+            else if (wpe_ == 4) EVAC_LAUNCH(h, KERNEL, 4, true, s_, __VA_ARGS__);     \
+            else if (wpe_ == 8) EVAC_LAUNCH(h, KERNEL, 8, true, s_, __VA_ARGS__);     \
+            else EVAC_LAUNCH(h, KERNEL, 16, true, s_, __VA_ARGS__);                   \
+        } else {                                                                      \
+            if (wpe_ == 1) EVAC_LAUNCH(h, KERNEL, 1, false, s_, __VA_ARGS__);         \
+            else if (wpe_ == 4) EVAC_LAUNCH(h, KERNEL, 4, false, s_, __VA_ARGS__);    \
+            else if (wpe_ == 8) EVAC_LAUNCH(h, KERNEL, 8, false, s_, __VA_ARGS__);    \
+            else EVAC_LAUNCH(h, KERNEL, 16, false, s_, __VA_ARGS__);                  \
+        }                                                                             \
     } while (0)
 
 }  // namespace

@@ -17,6 +17,13 @@
 
 #include "../../include/evac.h"
 
+// Profiling-only phase ablation (tools/ablate.sh builds side libraries with -DEVAC_ABLATE=mask; the
+// shipped library is always built with 0).  1: no pair loop, 2: no observation epilogue,
+// 4: no Philox (constant action / noise), 8: no status/reward reductions, 16: no per-step stores.
+#ifndef EVAC_ABLATE
+#define EVAC_ABLATE 0
+#endif
+
 namespace evac {
 
 constexpr int kViscek = 1, kFollower = 2, kExiting = 3, kEscaped = 4;   // statuses.py:16-27
@@ -251,10 +258,10 @@ __device__ __forceinline__ void grav_term(const Params& p, float rx, float ry, f
     gy = c * ry;
 }
 
-template <int WPE>
+template <int WPE, bool GRAV>
 __device__ __forceinline__ void write_obs(const Params& p, Smem<WPE>& sm, int slot, int wave_in_env, int lane,
                                           int i, bool active, const Ped& q, const Env& e, float* __restrict__ obs) {
-    if (p.obs_pos == EVAC_POS_GRAV) {
+    if constexpr (GRAV) {
         Sums s{};
         float gx = 0.0f, gy = 0.0f;
         const bool visc = active && q.st == kViscek;
@@ -277,6 +284,7 @@ __device__ __forceinline__ void write_obs(const Params& p, Smem<WPE>& sm, int sl
         }
         return;
     }
+    if constexpr (GRAV) return;   // (unreachable; keeps the generic epilogue out of the gravity kernels)
     const bool rel = p.obs_pos == EVAC_POS_REL;
     const float ihyp = 0.70710678118f;                                // wrappers.py:12-18: 1/sqrt(1+1)
     float px = q.x, py = q.y, ex = kExitX, ey = kExitY;
@@ -374,13 +382,28 @@ __device__ __forceinline__ float2 philox_action(const Params& p, uint32_t env_gi
     return make_float2(usym(r.x), usym(r.y));
 }
 
+// One (i, j) pair of the neighbour sum: 4 ops for the squared distance, 1 saturating FMA for the 0/1
+// weight, 2 FMAs (packed by the compiler) for the heading sum.
+__device__ __forceinline__ void pair_accumulate(float xi, float yi, f4 t, float r2b, float& sx, float& sy) {
+    const float ddx = xi - t.x, ddy = yi - t.y;
+    const float d2 = fmaf(ddy, ddy, ddx * ddx);
+    const float w = neighbour_weight(d2, r2b);
+    sx = fmaf(w, t.z, sx);
+    sy = fmaf(w, t.w, sy);
+}
+
 // ------------------------------------------------------------------------------------------------
 // One env step: env.py:141-171.  All lanes of the env call this together.
 // ------------------------------------------------------------------------------------------------
+// area.py:189-192: a /= |a| + eps ; agent.direction = step_size * a
+__device__ __forceinline__ float2 agent_direction(const Params& p, float act_x, float act_y) {
+    const float inrm = frcp(fsqrt(act_x * act_x + act_y * act_y) + p.eps);   // area.py:190
+    return make_float2(p.step_size * (act_x * inrm), p.step_size * (act_y * inrm));
+}
+
 template <int WPE>
 __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slot, int wave_in_env, int lane, int i,
-                                         bool active, Ped& q, Env& e, float act_x, float act_y, float noise,
-                                         StepOut& out) {
+                                         bool active, Ped& q, Env& e, float2 adir, float noise, StepOut& out) {
     // ---- Time.step: area.py:53-59 ----
     e.now += 1;
     e.total += 1u;
@@ -390,10 +413,8 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
     float r_agent = 0.0f;
     bool term_agent = false;
     {
-        const float inrm = frcp(fsqrt(act_x * act_x + act_y * act_y) + p.eps);   // area.py:190
-        const float nx = act_x * inrm, ny = act_y * inrm;
-        e.adx = p.step_size * nx;                                           // area.py:192
-        e.ady = p.step_size * ny;
+        e.adx = adir.x;                                                     // area.py:192
+        e.ady = adir.y;
         const float tx = e.ax + e.adx, ty = e.ay + e.ady;                   // area.py:201
         const bool hit = tx < -p.width || tx > p.width || ty < -p.height || ty > p.height;
         if (!hit) {
@@ -457,19 +478,20 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
         // back (LDS latency paid once per batch, no VALU slot), then 7 full-rate VALU ops per pair.
         // Padding / parked entries (x = 3e38, u = 0) weigh 0, so the loop runs to a multiple of 8.
         const f4* __restrict__ tile = sm.tile[slot];
-        const int n8 = (p.n_ped + 7) & ~7;
+        const int n8 = (p.n_ped + 3) & ~3;   // batches of 8, the last one may be a half batch
         const float r2b = p.r_ped2_big;
-        for (int j = 0; j < n8; j += 8) {
+        for (int j = 0; j < ((EVAC_ABLATE & 1) ? 0 : n8); j += 8) {
             f4 t[8];
+            if (j + 8 <= n8) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = tile[j + k];
+                for (int k = 0; k < 8; ++k) t[k] = tile[j + k];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float ddx = q.x - t[k].x, ddy = q.y - t[k].y;
-                const float d2 = fmaf(ddy, ddy, ddx * ddx);
-                const float w = neighbour_weight(d2, r2b);
-                sx = fmaf(w, t[k].z, sx);
-                sy = fmaf(w, t[k].w, sy);
+                for (int k = 0; k < 8; ++k) pair_accumulate(q.x, q.y, t[k], r2b, sx, sy);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pair_accumulate(q.x, q.y, t[k], r2b, sx, sy);
             }
         }
     }
@@ -517,7 +539,7 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
         (old_st == kViscek || old_st == kFollower) && new_st == kExiting,    // reward.py:35-39
         old_st == kViscek && new_st == kFollower,                             // reward.py:43-46
         new_st == kEscaped, new_st == kExiting, new_st == kFollower, new_st == kViscek, false, false};
-    env_reduce<WPE>(sm, slot, wave_in_env, lane, s, pred);
+    if constexpr (!(EVAC_ABLATE & 8)) env_reduce<WPE>(sm, slot, wave_in_env, lane, s, pred);
     out.n_escaped = s.i[2];
     out.n_exiting = s.i[3];
     out.n_follower = s.i[4];
@@ -525,8 +547,8 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
 
     const float tf = 1.0f - (float)e.now * p.inv_200n;                      // reward.py:26
     float r_ped = p.init_reward;
-    if (p.new_exiting_reward) r_ped += (15.0f + 10.0f * tf) * (float)s.i[0];
-    if (p.new_followers_reward) r_ped += (10.0f + 5.0f * tf) * (float)s.i[1];
+    if (p.new_exiting_reward && s.i[0]) r_ped += (15.0f + 10.0f * tf) * (float)s.i[0];      // uniform branches:
+    if (p.new_followers_reward && s.i[1]) r_ped += (10.0f + 5.0f * tf) * (float)s.i[1];     // usually no transition
     const float intrinsic = 0.0f - s.f0 * p.inv_n;                          // reward.py:19-21
     out.reward = r_agent + r_ped + p.intrinsic_coef * intrinsic;           // env.py:158
     out.terminated = term_agent || (s.i[2] == p.n_ped);                     // area.py:175-178, env.py:171
@@ -599,7 +621,7 @@ struct Who {
 // ------------------------------------------------------------------------------------------------
 // Kernels
 // ------------------------------------------------------------------------------------------------
-template <int WPE>
+template <int WPE, bool GRAV>
 __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_step(
     Params p, const float2* __restrict__ actions, const float* __restrict__ noise_in, float* __restrict__ obs_out,
     float* __restrict__ reward_out, uint8_t* __restrict__ term_out, uint8_t* __restrict__ trunc_out, int autoreset,
@@ -616,15 +638,15 @@ __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_step(
     float nz = 0.0f;
     if (active) nz = noise_in ? noise_in[(size_t)w.env * p.n_ped + w.i] : philox_noise(p, gid, w.i, e.total);
     StepOut o;
-    step_env<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, a.x, a.y, nz, o);
+    step_env<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, agent_direction(p, a.x, a.y), nz, o);
     const bool done = o.terminated || o.truncated;
     float* obs = obs_out + (size_t)w.env * p.obs_dim;
     if (done && autoreset) {
-        if (final_obs) write_obs<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, final_obs + (size_t)w.env * p.obs_dim);
+        if (final_obs) write_obs<WPE, GRAV>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, final_obs + (size_t)w.env * p.obs_dim);
         if (final_stats && w.i == 0) write_stats(final_stats + w.env, e, o);
         reset_env(p, active, philox_reset_draw(p, gid, w.i, e.n_resets), q, e);
     }
-    write_obs<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, obs);
+    write_obs<WPE, GRAV>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, obs);
     store_env(p, w.env, w.i, active, q, e);
     if (w.i == 0) {
         reward_out[w.env] = o.reward;
@@ -634,7 +656,7 @@ __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_step(
 }
 
 // T steps per launch, state in registers (rpo_agent.py:180-203 rollout loop, RandomAgent or given actions).
-template <int WPE>
+template <int WPE, bool GRAV>
 __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_rollout(
     Params p, int n_steps, const float2* __restrict__ actions, float2* __restrict__ actions_out,
     float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ term_out,
@@ -650,27 +672,44 @@ __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_rollout(
     const size_t E = (size_t)p.n_envs;
     uint4 nzr = make_uint4(0, 0, 0, 0);
     bool have = false;
+    // RandomAgent actions and the leader directions they give (area.py:189-192) are produced 64 steps at a
+    // time, one step per LANE (a per-wave scalar Philox would cost ~100 SALU instructions every step),
+    // and fetched per step with v_readlane.
+    float2 lane_act = make_float2(0.f, 0.f), lane_adir = make_float2(0.f, 0.f);
     for (int t = 0; t < n_steps; ++t) {
-        float2 a;
-        if (actions) a = actions[(size_t)t * E + w.env];
-        else a = philox_action(p, gid, e.total);
+        const int slot64 = t & 63;
+        if (slot64 == 0) {
+            if (actions) {
+                if (t + w.lane < n_steps) lane_act = actions[(size_t)(t + w.lane) * E + w.env];
+            } else if constexpr (EVAC_ABLATE & 4) {
+                lane_act = make_float2(0.3f, -0.7f);
+            } else {
+                lane_act = philox_action(p, gid, e.total + (uint32_t)w.lane);   // e.total grows by exactly 1 per step
+            }
+            lane_adir = agent_direction(p, lane_act.x, lane_act.y);
+        }
+        float2 a, adir;
+        a.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lane_act.x), slot64));
+        a.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lane_act.y), slot64));
+        adir.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lane_adir.x), slot64));
+        adir.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lane_adir.y), slot64));
         if (actions_out && w.i == 0) actions_out[(size_t)t * E + w.env] = a;
         // one Philox call serves four consecutive steps of this pedestrian
         const uint32_t sel = e.total & 3u;
-        if (!have || sel == 0u) {
+        if ((!have || sel == 0u) && !(EVAC_ABLATE & 4)) {
             nzr = philox4x32_10(make_uint4(gid, (uint32_t)w.i, e.total >> 2, kStreamNoise), p.seed_lo, p.seed_hi);
             have = true;
         }
         const uint32_t wsel = sel == 0 ? nzr.x : (sel == 1 ? nzr.y : (sel == 2 ? nzr.z : nzr.w));
         const float nz = (u01(wsel) - 0.5f) * p.noise_coef;
         StepOut o;
-        step_env<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, a.x, a.y, nz, o);
+        step_env<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, adir, nz, o);
         if (o.terminated || o.truncated) {
             if (final_stats && w.i == 0) write_stats(final_stats + (size_t)t * E + w.env, e, o);
             reset_env(p, active, philox_reset_draw(p, gid, w.i, e.n_resets), q, e);
         }
-        write_obs<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, obs_out + ((size_t)t * E + w.env) * p.obs_dim);
-        if (w.i == 0) {
+        if constexpr (!(EVAC_ABLATE & 2)) write_obs<WPE, GRAV>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, obs_out + ((size_t)t * E + w.env) * p.obs_dim);
+        if (w.i == 0 && !(EVAC_ABLATE & 16)) {
             reward_out[(size_t)t * E + w.env] = o.reward;
             term_out[(size_t)t * E + w.env] = o.terminated ? 1 : 0;
             trunc_out[(size_t)t * E + w.env] = o.truncated ? 1 : 0;
@@ -679,7 +718,7 @@ __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_rollout(
     store_env(p, w.env, w.i, active, q, e);
 }
 
-template <int WPE>
+template <int WPE, bool GRAV>
 __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_reset(Params p, const uint8_t* __restrict__ mask,
                                                                 const float4* __restrict__ draws,
                                                                 float* __restrict__ obs_out) {
@@ -695,11 +734,11 @@ __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_reset(Params p, const
     float4 d = make_float4(0.f, 0.f, 1.f, 0.f);
     if (active) d = draws ? draws[(size_t)w.env * p.n_ped + w.i] : philox_reset_draw(p, gid, w.i, e.n_resets);
     reset_env(p, active, d, q, e);
-    if (obs_out) write_obs<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, obs_out + (size_t)w.env * p.obs_dim);
+    if (obs_out) write_obs<WPE, GRAV>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, obs_out + (size_t)w.env * p.obs_dim);
     store_env(p, w.env, w.i, active, q, e);
 }
 
-template <int WPE>
+template <int WPE, bool GRAV>
 __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_observe(Params p, float* __restrict__ obs_out) {
     __shared__ Smem<WPE> sm;
     const Who<WPE> w;
@@ -708,7 +747,7 @@ __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_observe(Params p, flo
     Ped q;
     Env e;
     load_env(p, w.env, w.i, active, q, e);
-    write_obs<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, obs_out + (size_t)w.env * p.obs_dim);
+    write_obs<WPE, GRAV>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, obs_out + (size_t)w.env * p.obs_dim);
 }
 
 // state exchange in the reference's shapes

@@ -6,7 +6,7 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
-constexpr int ITERS = 2048;
+constexpr int ITERS = 32768;
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k(float* out, int n_iter, float seed) {
@@ -71,6 +71,14 @@ __global__ __launch_bounds__(256) void k(float* out, int n_iter, float seed) {
             a5 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a5), 0x143, 0xf, 0xf, false));
             a6 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a6), 0x111, 0xf, 0xf, false));
             a7 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a7), 0x112, 0xf, 0xf, false));
+        } else if constexpr (KIND == 10) {  // 8 DEPENDENT v_fma_f32 (one chain)
+            asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                         "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                         : "+v"(a0) : "v"(b), "v"(c));
+        } else if constexpr (KIND == 11) {  // 2 chains x 4
+            asm volatile("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n"
+                         "v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n"
+                         : "+v"(a0), "+v"(a1) : "v"(b), "v"(c));
         } else if constexpr (KIND == 9) {   // 8 ds_bpermute (shfl_xor)
             a0 += __shfl_xor(a0, 32); a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 32); a3 += __shfl_xor(a3, 16);
             a4 += __shfl_xor(a4, 32); a5 += __shfl_xor(a5, 16); a6 += __shfl_xor(a6, 32); a7 += __shfl_xor(a7, 16);
@@ -102,8 +110,10 @@ int run(const char* name, int ops_per_iter, int blocks, float* d) {
 int main() {
     float* d;
     CHECK(hipMalloc(&d, sizeof(float) * 256 * 8192));
-    for (int blocks : {1024, 2048, 8192}) {   // 4 / 8 / 8+ waves per SIMD
+    for (int blocks : {256, 512, 1024, 2048, 4096}) {   // 1 / 2 / 4 / 8 / 16 waves per SIMD
         run<0>("v_fma_f32", 8, blocks, d);
+        run<10>("v_fma_f32 dependent chain", 8, blocks, d);
+        run<11>("v_fma_f32 2 chains", 8, blocks, d);
         run<1>("v_pk_fma_f32", 4, blocks, d);
         run<6>("v_fma_f32 clamp", 8, blocks, d);
         run<2>("v_mul_lo_u32", 8, blocks, d);

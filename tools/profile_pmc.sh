@@ -1,0 +1,23 @@
+#!/bin/bash
+# rocprofv3 passes for the bench workload (run ON the GPU box via gpurun).  Separate --pmc passes
+# (never combined with trace domains other than --kernel-trace), outputs under gpurun_out/<tag>/.
+# usage: tools/profile_pmc.sh <tag> [bench args...]
+set -u
+TAG=${1:-prof}; shift || true
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+ARGS="--no-cpu-baseline --steps 400 --warmup 100 $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/stats.log" 2>&1
+i=0
+for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
+            "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT" \
+            "SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_INSTS_VALU_TRANS SQ_LDS_IDX_ACTIVE SQ_INSTS_FLAT" \
+            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d "$OUT/pmc$i" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc$i.log" 2>&1
+done
+cd "$ROOT"
+python3 tools/summarize_pmc.py "$OUT" > "$OUT/summary.txt" 2>&1
+cat "$OUT/summary.txt"
