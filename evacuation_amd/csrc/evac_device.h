@@ -180,6 +180,7 @@ template <int WPE>
 struct Smem {
     f4 tile[Geometry<WPE>::kEnvsPerBlock][WPE * kWave];   // (x, y, ux, uy) of every pedestrian
     float redf[Geometry<WPE>::kEnvsPerBlock][WPE][4];
+    int cols[Geometry<WPE>::kEnvsPerBlock][WPE];              // moving pedestrians per wave (tile compaction)
     int redi[Geometry<WPE>::kEnvsPerBlock][WPE][8];
 };
 
@@ -457,9 +458,32 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
         if (bad && p.nan_guard) ux = uy = 0.0f;
     }
     env_sync<WPE>();   // tile readers of the previous step are done
-    // non-moving (escaped / padding) pedestrians are parked far away: they are not columns of the
-    // reference's distance matrix (area.py:105-106)
-    sm.tile[slot][wave_in_env * kWave + lane] = f4{efv ? q.x : 3.0e38f, q.y, bad ? 0.0f : ux, bad ? 0.0f : uy};
+    // The tile holds ONLY the moving pedestrians, compacted in ascending pedestrian order -- the columns
+    // pos[efv] of the reference's distance matrix (area.py:99-106).  Under a RandomAgent most pedestrians
+    // have escaped by mid-episode, so the all-pairs loop shrinks from N to n_efv iterations.
+    int n_cols;
+    {
+        const unsigned long long m = __ballot(efv);
+        const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        int base = 0;
+        n_cols = __popcll(m);
+        if constexpr (WPE > 1) {
+            if (lane == 0) sm.cols[slot][wave_in_env] = n_cols;
+            __syncthreads();
+            int tot = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < WPE; ++w2) {
+                const int c = sm.cols[slot][w2];
+                base += (w2 < wave_in_env) ? c : 0;
+                tot += c;
+            }
+            n_cols = tot;
+        }
+        if (efv) sm.tile[slot][base + below] = f4{q.x, q.y, bad ? 0.0f : ux, bad ? 0.0f : uy};
+        // padding up to the batch size of the loop: weight 0 (x = 3e38 -> d2 = inf), heading 0
+        const int tid = wave_in_env * kWave + lane;
+        if (tid >= n_cols) sm.tile[slot][tid] = f4{3.0e38f, 0.0f, 0.0f, 0.0f};
+    }
     // (intersection * u).sum(): NaN * 0 = NaN, so ONE zero-heading pedestrian poisons every row
     // (area.py:118-119).  Reproduced exactly unless nan_guard.
     bool poison = false;
@@ -472,13 +496,17 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
 
     // ---- all-pairs neighbour sum: area.py:105-119.  The count n_intersections only rescales the
     // mean heading, which arctan2 ignores; it is not needed.
+    // rows of the distance matrix exist only for FOLLOWER/VISCEK pedestrians (area.py:104)
+    bool any_fv;
+    if constexpr (WPE == 1) any_fv = __ballot(fv) != 0ull;
+    else any_fv = true;   // (a workgroup-wide OR would cost a barrier; the loop is short when n_cols is)
     float sx = 0.0f, sy = 0.0f;
     {
         // Branch-free, 8 peers per batch: the 8 wave-uniform ds_read_b128 broadcasts are issued back to
         // back (LDS latency paid once per batch, no VALU slot), then 7 full-rate VALU ops per pair.
         // Padding / parked entries (x = 3e38, u = 0) weigh 0, so the loop runs to a multiple of 8.
         const f4* __restrict__ tile = sm.tile[slot];
-        const int n8 = (p.n_ped + 3) & ~3;   // batches of 8, the last one may be a half batch
+        const int n8 = __builtin_amdgcn_readfirstlane(any_fv ? ((n_cols + 3) & ~3) : 0);   // batches of 8 (+ a half batch); no rows -> no loop
         const float r2b = p.r_ped2_big;
         for (int j = 0; j < ((EVAC_ABLATE & 1) ? 0 : n8); j += 8) {
             f4 t[8];
