@@ -127,15 +127,14 @@ def main():
     inner = max(1, min(args.inner, K)) if args.mode == "rollout" else 1
     do_gather = world > 1 and not args.no_gather
 
-    # preallocated, reused output chunk (the trainer's rollout buffer, rpo_agent.py:158-163)
+    # preallocated, reused output chunks (the trainer's rollout buffer, rpo_agent.py:158-163): the kernel
+    # writes one packed slab [T, E, D+3] = [obs | reward | terminated | truncated], which is also the
+    # all-gather message
     def alloc(T):
-        return {"obs": torch.empty((T, E, D), dtype=torch.float32, device=device),
-                "reward": torch.empty((T, E), dtype=torch.float32, device=device),
-                "terminated": torch.empty((T, E), dtype=torch.uint8, device=device),
-                "truncated": torch.empty((T, E), dtype=torch.uint8, device=device),
+        return {"slab": torch.empty((T, E, D + 3), dtype=torch.float32, device=device),
                 "episode_stats": torch.zeros((T, E, 8), dtype=torch.float32, device=device)}
     bufs = [alloc(inner), alloc(inner)]
-    slabs = [torch.empty((inner, E, D + 3), dtype=torch.float32, device=device) for _ in range(2)]
+    tails = {}
     gathered = [torch.empty((world, inner, E, D + 3), dtype=torch.float32, device=device) for _ in range(2)] if do_gather else None
     comm = torch.cuda.Stream(device=device) if do_gather else None
     step_actions = torch.rand((E, 2), device=device) * 2 - 1
@@ -157,26 +156,23 @@ def main():
                 ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
                 ev0.record()
             if args.mode == "rollout":
-                if t == inner:
-                    loc.rollout(t, out=b)
-                else:
-                    loc.rollout(t, out={kk: v[:t] for kk, v in b.items()})
+                if t != inner:
+                    b = tails.setdefault(t, alloc(t))
+                loc.rollout(t, out=b)
             else:
                 loc.step(step_actions)
             if events is not None:
                 ev1.record()
                 events.append((ev0, ev1, t))
             if do_gather and args.mode == "rollout" and t == inner:
-                slab = pack_outputs(b["obs"], b["reward"], b["terminated"], b["truncated"], out=slabs[k & 1])
                 ready = torch.cuda.Event(); ready.record()
                 with torch.cuda.stream(comm):
                     comm.wait_event(ready)
-                    all_gather_envs(slab, out=gathered[k & 1])
+                    all_gather_envs(b["slab"], out=gathered[k & 1])
                     fin = torch.cuda.Event(); fin.record(comm)
                 pend[k & 1] = fin
             elif do_gather:
-                slab = pack_outputs(loc.obs, loc.reward, loc.terminated, loc.truncated) if args.mode == "step" else \
-                    pack_outputs(b["obs"][:t], b["reward"][:t], b["terminated"][:t], b["truncated"][:t])
+                slab = pack_outputs(loc.obs, loc.reward, loc.terminated, loc.truncated) if args.mode == "step" else b["slab"]
                 all_gather_envs(slab)
             done += t
             k += 1

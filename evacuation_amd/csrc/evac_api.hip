@@ -256,18 +256,16 @@ int evac_step(evac_handle_t h, const float* actions, const float* noise, float* 
     return check_launch(h, "evac_step");
 }
 
-int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* actions_out, float* obs_out,
-                 float* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
+int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* actions_out, float* slab_out,
                  evac_episode_stats_t* final_stats, void* stream) {
     EVAC_REQUIRE_BOUND(h, "evac_rollout");
     if (n_steps < 1) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_rollout: n_steps must be >= 1");
-    if (!obs_out || !reward_out || !terminated_out || !truncated_out)
-        return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_rollout: obs/reward/terminated/truncated must be non-NULL");
+    if (!slab_out) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_rollout: slab_out must be non-NULL");
     if (((uintptr_t)actions | (uintptr_t)actions_out) & 7u)
         return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_rollout: actions buffers must be 8-byte aligned");
     DeviceGuard g(h->device);
-    EVAC_DISPATCH(h, k_rollout, stream, h->p, (int)n_steps, (const float2*)actions, (float2*)actions_out, obs_out,
-                  reward_out, terminated_out, truncated_out, final_stats);
+    EVAC_DISPATCH(h, k_rollout, stream, h->p, (int)n_steps, (const float2*)actions, (float2*)actions_out, slab_out,
+                  final_stats);
     return check_launch(h, "evac_rollout");
 }
 
@@ -303,5 +301,15 @@ int evac_set_state(evac_handle_t h, const float* pos, const float* dir, const ui
                        (const float2*)agent_dir, now);
     return check_launch(h, "evac_set_state");
 }
+
+#ifdef EVAC_STAMP
+// diagnostic build only: read and clear the per-phase cycle sums
+int evac_debug_stamps(unsigned long long* out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return EVAC_ERR_HIP;
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return EVAC_ERR_HIP;
+    return EVAC_OK;
+}
+#endif
 
 }  // extern "C"

@@ -24,11 +24,31 @@
 #define EVAC_ABLATE 0
 #endif
 
+// Diagnostic build only (-DEVAC_STAMP, tools/stamps.sh): s_memtime stamps around the phases of a step,
+// summed per phase over all waves into g_stamps.  No stamp executes in the shipped library.
+#ifdef EVAC_STAMP
+__device__ unsigned long long g_stamps[16];
+#define EVAC_T(k)                                                                         \
+    do {                                                                                  \
+        unsigned long long now_;                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        stamp_acc[k] += now_ - stamp_last;                                                \
+        stamp_last = now_;                                                                \
+    } while (0)
+#define EVAC_STAMP_ARGS , stamp_acc, stamp_last
+#else
+#define EVAC_T(k) do { } while (0)
+#define EVAC_STAMP_ARGS
+#endif
+
 namespace evac {
 
 constexpr int kViscek = 1, kFollower = 2, kExiting = 3, kEscaped = 4;   // statuses.py:16-27
 constexpr float kExitX = 0.0f, kExitY = -1.0f;                           // area.py:39
 constexpr int kWave = 64;
+constexpr int kStageSteps = 7, kGravRow = 9;   // 7 steps x (6 obs + reward + terminated + truncated) = 63 words <= 64 lanes
 // native 16-byte vector: loads/stores of it are single ds_read_b128 / ds_write_b128 (HIP's float4 is
 // copied member-wise and re-merged only to 8-byte alignment, i.e. ds_read2_b64 at half the LDS rate)
 using f4 = float __attribute__((ext_vector_type(4)));
@@ -119,13 +139,17 @@ __device__ __forceinline__ float neighbour_weight(float d2, float r2_big) {
     return w;
 }
 
-// x^k for a wave-uniform small integer k (square-and-multiply; a few ulp)
+// x^k for a wave-uniform integer k in [1,32]: straight-line binary powering (no loop, no branches;
+// the selects take a wave-uniform condition).  A few ulp.
 __device__ __forceinline__ float powi(float x, int k) {
-    float r = 1.0f;
-    while (k) {
-        if (k & 1) r *= x;
-        x *= x;
-        k >>= 1;
+    const float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8;
+    float r = (k & 1) ? x : 1.0f;
+    r *= (k & 2) ? x2 : 1.0f;
+    r *= (k & 4) ? x4 : 1.0f;
+    if (k & 24) {   // rare: alpha >= 6
+        r *= (k & 8) ? x8 : 1.0f;
+        r *= (k & 16) ? x16 : 1.0f;
+        if (k & 32) r *= x16 * x16;
     }
     return r;
 }
@@ -167,6 +191,7 @@ struct StepOut {
     float reward;
     bool terminated, truncated;
     int n_escaped, n_exiting, n_follower, n_viscek;
+    float gx, gy, ex, ey;   // gravity observation of the post-step state (GRAV kernels): ped sums, exit term * n_followers
 };
 
 template <int WPE>
@@ -181,6 +206,9 @@ struct Smem {
     f4 tile[Geometry<WPE>::kEnvsPerBlock][WPE * kWave];   // (x, y, ux, uy) of every pedestrian
     float redf[Geometry<WPE>::kEnvsPerBlock][WPE][4];
     int cols[Geometry<WPE>::kEnvsPerBlock][WPE];              // moving pedestrians per wave (tile compaction)
+    float exitg[Geometry<WPE>::kEnvsPerBlock][2];            // gravity exit term from the lane that computed it (WPE > 1)
+    // rollout outputs of up to kStageSteps steps, flushed with ONE 64-lane store (GRAV kernels)
+    float stage[Geometry<WPE>::kEnvsPerBlock][7][12];
     int redi[Geometry<WPE>::kEnvsPerBlock][WPE][8];
 };
 
@@ -259,29 +287,36 @@ __device__ __forceinline__ void grav_term(const Params& p, float rx, float ry, f
     gy = c * ry;
 }
 
+// Gravity observation of the CURRENT state by a full reduction: used by reset / observe and after an
+// in-kernel autoreset (the per-step path gets the same numbers fused into step_env's reduction).
+// o6 = [agent(2), grad_potential_exit(2), grad_potential_pedestrians(2)], wave-uniform.
+template <int WPE>
+__device__ __forceinline__ void grav_observation(const Params& p, Smem<WPE>& sm, int slot, int wave_in_env, int lane,
+                                                 bool active, const Ped& q, const Env& e, float (&o6)[6]) {
+    Sums s{};
+    float gx = 0.0f, gy = 0.0f;
+    const bool visc = active && q.st == kViscek;
+    grav_term(p, e.ax - q.x, e.ay - q.y, gx, gy);                   // gravity_encoding.py:8-25
+    s.f0 = visc ? gx : 0.0f;
+    s.f1 = visc ? gy : 0.0f;
+    s.f2 = 0.0f;
+    const bool pred[8] = {active && q.st == kFollower, false, false, false, false, false, false, false};
+    env_reduce<WPE>(sm, slot, wave_in_env, lane, s, pred);
+    float ex, ey;
+    grav_term(p, e.ax - kExitX, e.ay - kExitY, ex, ey);              // gravity_encoding.py:28-38
+    const float nf = (float)s.i[0];
+    o6[0] = e.ax; o6[1] = e.ay; o6[2] = ex * nf; o6[3] = ey * nf; o6[4] = s.f0; o6[5] = s.f1;
+}
+
 template <int WPE, bool GRAV>
 __device__ __forceinline__ void write_obs(const Params& p, Smem<WPE>& sm, int slot, int wave_in_env, int lane,
                                           int i, bool active, const Ped& q, const Env& e, float* __restrict__ obs) {
     if constexpr (GRAV) {
-        Sums s{};
-        float gx = 0.0f, gy = 0.0f;
-        const bool visc = active && q.st == kViscek;
-        if (visc) grav_term(p, e.ax - q.x, e.ay - q.y, gx, gy);     // gravity_encoding.py:8-25
-        s.f0 = gx;
-        s.f1 = gy;
-        s.f2 = 0.0f;
-        bool pred[8] = {active && q.st == kFollower, false, false, false, false, false, false, false};
-        env_reduce<WPE>(sm, slot, wave_in_env, lane, s, pred);
+        float o6[6];
+        grav_observation<WPE>(p, sm, slot, wave_in_env, lane, active, q, e, o6);
         if (i == 0) {
-            float ex, ey;
-            grav_term(p, e.ax - kExitX, e.ay - kExitY, ex, ey);      // gravity_encoding.py:28-38
-            const float nf = (float)s.i[0];
-            obs[0] = e.ax;
-            obs[1] = e.ay;
-            obs[2] = ex * nf;
-            obs[3] = ey * nf;
-            obs[4] = s.f0;
-            obs[5] = s.f1;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) obs[k] = o6[k];
         }
         return;
     }
@@ -402,75 +437,75 @@ __device__ __forceinline__ float2 agent_direction(const Params& p, float act_x, 
     return make_float2(p.step_size * (act_x * inrm), p.step_size * (act_y * inrm));
 }
 
-template <int WPE>
+template <int WPE, bool GRAV>
 __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slot, int wave_in_env, int lane, int i,
-                                         bool active, Ped& q, Env& e, float2 adir, float noise, StepOut& out) {
+                                         bool active, Ped& q, Env& e, float2 adir, float noise, StepOut& out
+#ifdef EVAC_STAMP
+                                         , unsigned long long (&stamp_acc)[16], unsigned long long& stamp_last
+#endif
+) {
+    // The body is branch-free: every lane runs every instruction and the results are merged with
+    // selects.  Divergent `if` blocks cost s_and_saveexec / s_cbranch pairs and fence the scheduler;
+    // with 4 waves per SIMD at C2 the per-wave instruction stream is what bounds the step.
+
     // ---- Time.step: area.py:53-59 ----
     e.now += 1;
     e.total += 1u;
     out.truncated = e.now >= p.max_timesteps;
 
     // ---- Area.agent_step: area.py:182-210 (wave-uniform, every lane computes the same values) ----
-    float r_agent = 0.0f;
-    bool term_agent = false;
-    {
-        e.adx = adir.x;                                                     // area.py:192
-        e.ady = adir.y;
-        const float tx = e.ax + e.adx, ty = e.ay + e.ady;                   // area.py:201
-        const bool hit = tx < -p.width || tx > p.width || ty < -p.height || ty > p.height;
-        if (!hit) {
-            e.ax = tx;                                                      // area.py:195
-            e.ay = ty;
-        } else {
-            r_agent = -5.0f;                                                // area.py:198
-            term_agent = p.term_on_wall != 0;
-        }
-    }
+    e.adx = adir.x;                                                         // area.py:192
+    e.ady = adir.y;
+    const float tx = e.ax + e.adx, ty = e.ay + e.ady;                       // area.py:201
+    const bool hit = tx < -p.width || tx > p.width || ty < -p.height || ty > p.height;
+    e.ax = hit ? e.ax : tx;                                                 // area.py:195
+    e.ay = hit ? e.ay : ty;
+    const float r_agent = hit ? -5.0f : 0.0f;                               // area.py:198
+    const bool term_agent = hit && p.term_on_wall != 0;
 
     // ---- Area.pedestrians_step: area.py:76-180 ----
     const int old_st = q.st;
-    if (q.st == kEscaped) {                                                 // area.py:79-81
-        q.dx = q.dy = 0.0f;
-        q.x = kExitX;
-        q.y = kExitY;
-    }
-    if (q.st == kExiting) {                                                 // area.py:84-90
+    const bool esc = q.st == kEscaped, exi = q.st == kExiting;
+    q.x = esc ? kExitX : q.x;                                               // area.py:79-81
+    q.y = esc ? kExitY : q.y;
+    q.dx = esc ? 0.0f : q.dx;
+    q.dy = esc ? 0.0f : q.dy;
+    {                                                                       // area.py:84-90
         const float vx = kExitX - q.x, vy = kExitY - q.y;
         const float l2 = vx * vx + vy * vy;
-        const float ln = fsqrt(l2);
+        const float il = frsq(l2);
+        const float ln = l2 * il;                                           // |v|
         const float sz = ln > p.step_size ? p.step_size : ln;
-        const float k = frsq(l2) * sz;                                      // (v / |v|) * min(|v|, step)
-        q.dx = vx * k;
-        q.dy = vy * k;
+        const float k = il * sz;                                            // (v / |v|) * min(|v|, step)
+        q.dx = exi ? vx * k : q.dx;
+        q.dy = exi ? vy * k : q.dy;
     }
-    const bool efv = active && (q.st == kExiting || q.st == kFollower || q.st == kViscek);   // area.py:99
-    const bool fv = active && (q.st == kFollower || q.st == kViscek);                         // area.py:104
+    const bool efv = active && !esc && q.st != 0;                           // area.py:99  (E | F | V)
+    const bool fv = active && (q.st == kFollower || q.st == kViscek);       // area.py:104
     const bool fol = active && q.st == kFollower;
 
-    // unit headings of the moving pedestrians: area.py:100-101 (0/0 -> NaN, see below)
-    float ux = 0.0f, uy = 0.0f;
-    bool bad = false;
-    if (efv) {
-        const float inrm = frsq(q.dx * q.dx + q.dy * q.dy);               // 0 -> inf, 0 * inf = NaN as 0/0
-        ux = q.dx * inrm;
-        uy = q.dy * inrm;
-        bad = (ux != ux) || (uy != uy);
-        if (bad && p.nan_guard) ux = uy = 0.0f;
-    }
+    // unit headings of the moving pedestrians: area.py:100-101.  0 * rsq(0) = 0 * inf = NaN, as 0/0.
+    const float inrm = frsq(q.dx * q.dx + q.dy * q.dy);
+    float ux = q.dx * inrm, uy = q.dy * inrm;
+    const bool bad = efv && ((ux != ux) || (uy != uy));
+    ux = bad ? 0.0f : ux;
+    uy = bad ? 0.0f : uy;
+    EVAC_T(1);   // leader + per-lane pre-pair work
     env_sync<WPE>();   // tile readers of the previous step are done
-    // The tile holds ONLY the moving pedestrians, compacted in ascending pedestrian order -- the columns
-    // pos[efv] of the reference's distance matrix (area.py:99-106).  Under a RandomAgent most pedestrians
-    // have escaped by mid-episode, so the all-pairs loop shrinks from N to n_efv iterations.
+    // The tile holds the moving pedestrians first, compacted in ascending pedestrian order -- the columns
+    // pos[efv] of the reference's distance matrix (area.py:99-106) -- then the others as padding with
+    // weight 0 (x = 3e38 -> d2 = inf) and heading 0.  Every lane writes exactly one entry.  Under a
+    // RandomAgent most pedestrians have escaped by mid-episode, so the all-pairs loop shrinks from N to
+    // n_efv iterations.
     int n_cols;
     {
         const unsigned long long m = __ballot(efv);
-        const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        int base = 0;
+        int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         n_cols = __popcll(m);
         if constexpr (WPE > 1) {
             if (lane == 0) sm.cols[slot][wave_in_env] = n_cols;
             __syncthreads();
-            int tot = 0;
+            int tot = 0, base = 0;
 #pragma unroll
             for (int w2 = 0; w2 < WPE; ++w2) {
                 const int c = sm.cols[slot][w2];
@@ -478,11 +513,11 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
                 tot += c;
             }
             n_cols = tot;
+            before += base;                                                 // moving pedestrians before this one
         }
-        if (efv) sm.tile[slot][base + below] = f4{q.x, q.y, bad ? 0.0f : ux, bad ? 0.0f : uy};
-        // padding up to the batch size of the loop: weight 0 (x = 3e38 -> d2 = inf), heading 0
         const int tid = wave_in_env * kWave + lane;
-        if (tid >= n_cols) sm.tile[slot][tid] = f4{3.0e38f, 0.0f, 0.0f, 0.0f};
+        const int idx = efv ? before : n_cols + (tid - before);             // a bijection onto [0, WPE*64)
+        sm.tile[slot][idx] = f4{efv ? q.x : 3.0e38f, q.y, efv ? ux : 0.0f, efv ? uy : 0.0f};
     }
     // (intersection * u).sum(): NaN * 0 = NaN, so ONE zero-heading pedestrian poisons every row
     // (area.py:118-119).  Reproduced exactly unless nan_guard.
@@ -496,6 +531,7 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
 
     // ---- all-pairs neighbour sum: area.py:105-119.  The count n_intersections only rescales the
     // mean heading, which arctan2 ignores; it is not needed.
+    EVAC_T(2);   // tile write + poison vote
     // rows of the distance matrix exist only for FOLLOWER/VISCEK pedestrians (area.py:104)
     bool any_fv;
     if constexpr (WPE == 1) any_fv = __ballot(fv) != 0ull;
@@ -504,7 +540,6 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
     {
         // Branch-free, 8 peers per batch: the 8 wave-uniform ds_read_b128 broadcasts are issued back to
         // back (LDS latency paid once per batch, no VALU slot), then 7 full-rate VALU ops per pair.
-        // Padding / parked entries (x = 3e38, u = 0) weigh 0, so the loop runs to a multiple of 8.
         const f4* __restrict__ tile = sm.tile[slot];
         const int n8 = __builtin_amdgcn_readfirstlane(any_fv ? ((n_cols + 3) & ~3) : 0);   // batches of 8 (+ a half batch); no rows -> no loop
         const float r2b = p.r_ped2_big;
@@ -523,51 +558,94 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
             }
         }
     }
-    if (poison) sx = sy = __builtin_nanf("");
+    EVAC_T(3);   // all-pairs loop
+    const float qnan = __builtin_nanf("");
+    sx = poison ? qnan : sx;
+    sy = poison ? qnan : sy;
 
     // ---- new heading = mean heading rotated by the noise: area.py:120-136.
     // cos/sin(arctan2(my,mx)+eta) = rotation of (mx,my)/|m| by eta; arctan2(0,0) = 0.
-    if (fv) {
-        float cx = 1.0f, cy = 0.0f;
-        if (!(sx == 0.0f && sy == 0.0f)) {
-            const float il = frsq(sx * sx + sy * sy);
-            cx = sx * il;
-            cy = sy * il;
-        }
+    {
+        const bool zero_mean = sx == 0.0f && sy == 0.0f;
+        const float il = frsq(sx * sx + sy * sy);
+        const float cx = zero_mean ? 1.0f : sx * il;
+        const float cy = zero_mean ? 0.0f : sy * il;
         float sn, cs;
         noise_sincos(noise, p.small_noise, sn, cs);
-        q.dx = (cx * cs - cy * sn) * p.step_size;
-        q.dy = (cy * cs + cx * sn) * p.step_size;
+        const float ndx = (cx * cs - cy * sn) * p.step_size;
+        const float ndy = (cy * cs + cx * sn) * p.step_size;
+        q.dx = fv ? ndx : q.dx;                                             // area.py:136
+        q.dy = fv ? ndy : q.dy;
+        const float bdx = p.ens * e.adx + p.one_minus_ens * q.dx;           // area.py:139-142
+        const float bdy = p.ens * e.ady + p.one_minus_ens * q.dy;
+        q.dx = fol ? bdx : q.dx;
+        q.dy = fol ? bdy : q.dy;
+        q.x += efv ? q.dx : 0.0f;                                           // area.py:145
+        q.y += efv ? q.dy : 0.0f;
     }
-    if (fol) {                                                              // area.py:139-142
-        q.dx = p.ens * e.adx + p.one_minus_ens * q.dx;
-        q.dy = p.ens * e.ady + p.one_minus_ens * q.dy;
-    }
-    if (efv) {                                                              // area.py:145
-        q.x += q.dx;
-        q.y += q.dy;
-    }
-    {                                                                       // area.py:148-152 (NaN-propagating clip)
-        const float cx = q.x < -p.width ? -p.width : (q.x > p.width ? p.width : q.x);
-        const float cy = q.y < -p.height ? -p.height : (q.y > p.height ? p.height : q.y);
+    {   // area.py:148-152.  med3 of a NaN is not NaN, but then miss = NaN - finite = NaN, so the position,
+        // the `miss != 0` test and the flipped direction come out exactly as with np.clip.
+        const float cx = __builtin_amdgcn_fmed3f(q.x, -p.width, p.width);
+        const float cy = __builtin_amdgcn_fmed3f(q.y, -p.height, p.height);
         const float mx = q.x - cx, my = q.y - cy;
-        q.x -= 2.0f * mx;
-        q.y -= 2.0f * my;
-        if (mx != 0.0f) q.dx = -q.dx;
-        if (my != 0.0f) q.dy = -q.dy;
+        q.x = fmaf(-2.0f, mx, q.x);                                         // 2*miss is exact: same rounding as pos - 2*miss
+        q.y = fmaf(-2.0f, my, q.y);
+        q.dx = (mx != 0.0f) ? -q.dx : q.dx;
+        q.dy = (my != 0.0f) ? -q.dy : q.dy;
     }
 
+    EVAC_T(4);   // heading, blend, move, reflect
     // ---- statuses, rewards, termination: area.py:155-178, statuses.py:29-48, reward.py:19-47 ----
-    float de = 0.0f;
-    const int new_st = active ? classify(p, q.x, q.y, e.ax, e.ay, de) : 0;
+    float de;
+    const int cls = classify(p, q.x, q.y, e.ax, e.ay, de);
+    const int new_st = active ? cls : 0;
     q.st = new_st;
     Sums s{};
     s.f0 = active ? de : 0.0f;
+    // gravity observation of the post-step state, fused into the same reduction (gravity_encoding.py:8-38).
+    // The first idle lane (i == N, if the env does not fill its waves) evaluates the exit term with the
+    // very same instructions instead of a separate single-lane block.
+    bool exit_lane = false;
+    float gx = 0.0f, gy = 0.0f;
+    if constexpr (GRAV) {
+        exit_lane = i == p.n_ped;
+        const float px = exit_lane ? kExitX : q.x, py = exit_lane ? kExitY : q.y;
+        grav_term(p, e.ax - px, e.ay - py, gx, gy);
+        const bool visc = new_st == kViscek;
+        s.f1 = visc ? gx : 0.0f;
+        s.f2 = visc ? gy : 0.0f;
+    }
     const bool pred[8] = {
         (old_st == kViscek || old_st == kFollower) && new_st == kExiting,    // reward.py:35-39
         old_st == kViscek && new_st == kFollower,                             // reward.py:43-46
         new_st == kEscaped, new_st == kExiting, new_st == kFollower, new_st == kViscek, false, false};
+    float ex = 0.0f, ey = 0.0f;
+    if constexpr (GRAV && WPE > 1) {
+        if (exit_lane) {
+            sm.exitg[slot][0] = gx;
+            sm.exitg[slot][1] = gy;
+        }
+    }
     if constexpr (!(EVAC_ABLATE & 8)) env_reduce<WPE>(sm, slot, wave_in_env, lane, s, pred);
+    if constexpr (GRAV) {
+        if (p.n_ped < WPE * kWave) {          // wave-uniform
+            if constexpr (WPE == 1) {
+                ex = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gx), p.n_ped));
+                ey = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gy), p.n_ped));
+            } else {
+                ex = sm.exitg[slot][0];       // written before env_reduce's barriers
+                ey = sm.exitg[slot][1];
+            }
+        } else {                              // the env fills its waves: no idle lane
+            grav_term(p, e.ax - kExitX, e.ay - kExitY, ex, ey);
+        }
+        const float nf = (float)s.i[4];
+        out.ex = ex * nf;
+        out.ey = ey * nf;
+        out.gx = s.f1;
+        out.gy = s.f2;
+    }
+    EVAC_T(5);   // classify + reductions
     out.n_escaped = s.i[2];
     out.n_exiting = s.i[3];
     out.n_follower = s.i[4];
@@ -583,6 +661,7 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
     e.acc_ret += out.reward;                                                // env.py:168-170
     e.acc_intr += intrinsic;
     e.acc_stat += r_agent + r_ped;
+    EVAC_T(6);   // rewards, flags
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -666,15 +745,38 @@ __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_step(
     float nz = 0.0f;
     if (active) nz = noise_in ? noise_in[(size_t)w.env * p.n_ped + w.i] : philox_noise(p, gid, w.i, e.total);
     StepOut o;
-    step_env<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, agent_direction(p, a.x, a.y), nz, o);
+#ifdef EVAC_STAMP
+    unsigned long long stamp_acc[16] = {};
+    unsigned long long stamp_last = 0;
+#endif
+    step_env<WPE, GRAV>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, agent_direction(p, a.x, a.y), nz, o EVAC_STAMP_ARGS);
     const bool done = o.terminated || o.truncated;
     float* obs = obs_out + (size_t)w.env * p.obs_dim;
+    float o6[6] = {e.ax, e.ay, o.ex, o.ey, o.gx, o.gy};   // GRAV: the observation came out of step_env's reduction
     if (done && autoreset) {
-        if (final_obs) write_obs<WPE, GRAV>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, final_obs + (size_t)w.env * p.obs_dim);
+        if (final_obs) {
+            float* fo = final_obs + (size_t)w.env * p.obs_dim;
+            if constexpr (GRAV) {
+                if (w.i == 0) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) fo[k] = o6[k];
+                }
+            } else {
+                write_obs<WPE, GRAV>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, fo);
+            }
+        }
         if (final_stats && w.i == 0) write_stats(final_stats + w.env, e, o);
         reset_env(p, active, philox_reset_draw(p, gid, w.i, e.n_resets), q, e);
+        if constexpr (GRAV) grav_observation<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, active, q, e, o6);
     }
-    write_obs<WPE, GRAV>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, obs);
+    if constexpr (GRAV) {
+        if (w.i == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) obs[k] = o6[k];
+        }
+    } else {
+        write_obs<WPE, GRAV>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, obs);
+    }
     store_env(p, w.env, w.i, active, q, e);
     if (w.i == 0) {
         reward_out[w.env] = o.reward;
@@ -684,11 +786,14 @@ __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_step(
 }
 
 // T steps per launch, state in registers (rpo_agent.py:180-203 rollout loop, RandomAgent or given actions).
+// Output: ONE packed f32 slab [T][E][D+3] = [obs(D) | reward | terminated | truncated] -- a single message
+// for the all-gather and a single coalesced store stream for the kernel.  GRAV kernels stage the 9 words
+// of up to 7 steps in LDS and flush them with one 64-lane store (five single-lane stores per step cost a
+// third of the step before: profiles/r01_e_*).
 template <int WPE, bool GRAV>
 __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_rollout(
     Params p, int n_steps, const float2* __restrict__ actions, float2* __restrict__ actions_out,
-    float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ term_out,
-    uint8_t* __restrict__ trunc_out, evac_episode_stats_t* __restrict__ final_stats) {
+    float* __restrict__ slab_out, evac_episode_stats_t* __restrict__ final_stats) {
     __shared__ Smem<WPE> sm;
     const Who<WPE> w;
     if (w.env >= p.n_envs) return;
@@ -698,12 +803,24 @@ __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_rollout(
     load_env(p, w.env, w.i, active, q, e);
     const uint32_t gid = p.env_id_offset + (uint32_t)w.env;
     const size_t E = (size_t)p.n_envs;
+    const int row = p.obs_dim + 3;
     uint4 nzr = make_uint4(0, 0, 0, 0);
     bool have = false;
     // RandomAgent actions and the leader directions they give (area.py:189-192) are produced 64 steps at a
     // time, one step per LANE (a per-wave scalar Philox would cost ~100 SALU instructions every step),
     // and fetched per step with v_readlane.
     float2 lane_act = make_float2(0.f, 0.f), lane_adir = make_float2(0.f, 0.f);
+    // flush mapping of the staged outputs: lane l carries word l % 9 of staged step l / 9
+    const int fl_s = w.lane / kGravRow, fl_k = w.lane - fl_s * kGravRow;
+    int staged = 0, stage_t0 = 0;
+    // Retire the state loads HERE, or their first use inside the loop puts `s_waitcnt vmcnt(0)` -- which
+    // also waits for the previous step's stores -- into every iteration.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
+#ifdef EVAC_STAMP
+    unsigned long long stamp_acc[16] = {};
+    unsigned long long stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
     for (int t = 0; t < n_steps; ++t) {
         const int slot64 = t & 63;
         if (slot64 == 0) {
@@ -731,18 +848,51 @@ __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_rollout(
         const uint32_t wsel = sel == 0 ? nzr.x : (sel == 1 ? nzr.y : (sel == 2 ? nzr.z : nzr.w));
         const float nz = (u01(wsel) - 0.5f) * p.noise_coef;
         StepOut o;
-        step_env<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, adir, nz, o);
-        if (o.terminated || o.truncated) {
+        EVAC_T(0);   // action fetch + noise Philox
+        step_env<WPE, GRAV>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, adir, nz, o EVAC_STAMP_ARGS);
+        float o6[6] = {e.ax, e.ay, o.ex, o.ey, o.gx, o.gy};
+        if (o.terminated || o.truncated) {   // wave-/workgroup-uniform, rare
             if (final_stats && w.i == 0) write_stats(final_stats + (size_t)t * E + w.env, e, o);
             reset_env(p, active, philox_reset_draw(p, gid, w.i, e.n_resets), q, e);
+            if constexpr (GRAV) grav_observation<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, active, q, e, o6);
         }
-        if constexpr (!(EVAC_ABLATE & 2)) write_obs<WPE, GRAV>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, obs_out + ((size_t)t * E + w.env) * p.obs_dim);
-        if (w.i == 0 && !(EVAC_ABLATE & 16)) {
-            reward_out[(size_t)t * E + w.env] = o.reward;
-            term_out[(size_t)t * E + w.env] = o.terminated ? 1 : 0;
-            trunc_out[(size_t)t * E + w.env] = o.truncated ? 1 : 0;
+        float* rowp = slab_out + ((size_t)t * E + w.env) * row;
+        const float f_term = o.terminated ? 1.0f : 0.0f, f_trunc = o.truncated ? 1.0f : 0.0f;
+        if constexpr (GRAV) {
+            if constexpr (!(EVAC_ABLATE & 16)) {
+                if (staged == 0) stage_t0 = t;
+                if (w.i == 0) {
+                    float* st = sm.stage[w.slot][staged];
+                    *(f4*)(st + 0) = f4{o6[0], o6[1], o6[2], o6[3]};
+                    *(f4*)(st + 4) = f4{o6[4], o6[5], o.reward, f_term};
+                    st[8] = f_trunc;
+                }
+                ++staged;
+                if (staged == kStageSteps || t == n_steps - 1) {
+                    if (w.wave_in_env == 0) {   // the wave that staged them: in-order LDS, no barrier needed
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        if (fl_s < staged) {
+                            const float v = sm.stage[w.slot][fl_s][fl_k];
+                            slab_out[((size_t)(stage_t0 + fl_s) * E + w.env) * kGravRow + fl_k] = v;
+                        }
+                    }
+                    staged = 0;
+                }
+            }
+        } else {
+            if constexpr (!(EVAC_ABLATE & 2)) write_obs<WPE, GRAV>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, rowp);
+            if (w.i == 0 && !(EVAC_ABLATE & 16)) {
+                rowp[p.obs_dim + 0] = o.reward;
+                rowp[p.obs_dim + 1] = f_term;
+                rowp[p.obs_dim + 2] = f_trunc;
+            }
         }
+        EVAC_T(7);   // autoreset check, observation epilogue, output stores
     }
+#ifdef EVAC_STAMP
+    if (w.lane == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_stamps[k], stamp_acc[k]);
+#endif
     store_env(p, w.env, w.i, active, q, e);
 }
 

@@ -116,7 +116,7 @@ class ShardedEvacuationEnv:
         ``pending = (gathered [world,T,E_local,D+3], event)``; pass it back as ``prev`` (or call
         ``wait``) before reading it.  The gather of chunk k overlaps the compute of chunk k+1."""
         ro = self.local.rollout(n_steps, actions=actions)
-        slab = pack_outputs(ro["obs"], ro["reward"], ro["terminated"], ro["truncated"])
+        slab = ro["slab"]            # the kernel already wrote the packed [obs | reward | flags] record
         if self.world_size == 1:
             return ro, (slab.unsqueeze(0), None)
         ready = torch.cuda.Event()

@@ -190,24 +190,24 @@ class BatchedEvacuationEnv:
 
     def rollout(self, n_steps: int, actions=None, record_actions: bool = False, out: Optional[TDict] = None):
         """``n_steps`` env steps in ONE kernel launch with the state held in registers (the
-        rollout loop rpo_agent.py:180-203 with given or RandomAgent actions).  Returns time-major
-        device tensors: obs [T,E,D], reward [T,E], terminated/truncated [T,E] (uint8),
-        episode_stats [T,E,8] (rows valid where an episode ended), actions [T,E,2] if recorded."""
-        T, E = int(n_steps), self.num_envs
+        rollout loop rpo_agent.py:180-203 with given or RandomAgent actions).  The kernel writes one
+        packed time-major slab ``[T,E,D+3] = [obs | reward | terminated | truncated]`` (f32); the
+        returned dict holds it as ``slab`` plus zero-copy views ``obs [T,E,D]``, ``reward [T,E]``,
+        ``terminated`` / ``truncated [T,E]`` (f32 0/1), and ``episode_stats [T,E,8]`` (rows valid where an
+        episode ended), ``actions [T,E,2]`` if recorded.  Pass a previous result as ``out`` to reuse it."""
+        T, E, D = int(n_steps), self.num_envs, self.obs_dim
         dev = self.device
         if out is None:
-            out = {
-                "obs": torch.empty((T, E, self.obs_dim), dtype=torch.float32, device=dev),
-                "reward": torch.empty((T, E), dtype=torch.float32, device=dev),
-                "terminated": torch.empty((T, E), dtype=torch.uint8, device=dev),
-                "truncated": torch.empty((T, E), dtype=torch.uint8, device=dev),
-                "episode_stats": torch.zeros((T, E, len(STATS_FIELDS)), dtype=torch.float32, device=dev),
-            }
+            out = {"slab": torch.empty((T, E, D + 3), dtype=torch.float32, device=dev),
+                   "episode_stats": torch.zeros((T, E, len(STATS_FIELDS)), dtype=torch.float32, device=dev)}
             if record_actions:
                 out["actions"] = torch.empty((T, E, 2), dtype=torch.float32, device=dev)
+        slab = self._check_tensor(out["slab"], (T, E, D + 3), torch.float32, "slab")
+        if "obs" not in out:
+            out["obs"], out["reward"] = slab[..., :D], slab[..., D]
+            out["terminated"], out["truncated"] = slab[..., D + 1], slab[..., D + 2]
         act = self._as_device(actions, (T, E, 2), torch.float32, "actions")
-        _lib.check(self.lib.evac_rollout(self._h, T, _ptr(act), _ptr(out.get("actions")), _ptr(out["obs"]),
-                                         _ptr(out["reward"]), _ptr(out["terminated"]), _ptr(out["truncated"]),
+        _lib.check(self.lib.evac_rollout(self._h, T, _ptr(act), _ptr(out.get("actions")), _ptr(slab),
                                          _ptr(out.get("episode_stats")), self._stream()), self._h)
         return out
 

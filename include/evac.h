@@ -144,13 +144,13 @@ int evac_step(evac_handle_t h, const float* actions, const float* noise_or_null,
 /* T consecutive steps in ONE launch with the env state held in registers/LDS (the trainer's rollout
  * loop rpo_agent.py:180-203 with the policy replaced by caller-provided or RandomAgent actions,
  * random_agent.py:8-9).  Always autoresets.  Buffers are time-major:
- *   actions_or_null  float [T][E][2]   NULL = draw U(-1,1)^2 on device (Philox)
- *   actions_out_or_null float [T][E][2] records the actions actually used
- *   obs_out float [T][E][D]; reward_out float [T][E]; terminated_out/truncated_out uint8 [T][E]
+ *   actions_or_null     float [T][E][2]   NULL = draw U(-1,1)^2 on device (Philox)
+ *   actions_out_or_null float [T][E][2]   records the actions actually used
+ *   slab_out            float [T][E][D+3] = [obs(D) | reward | terminated (0/1) | truncated (0/1)] per env-step:
+ *                       one packed record (what the trainer's rollout buffers and the all-gather consume)
  *   final_stats_or_null [T][E] (rows of envs that finished at step t) */
 int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions_or_null, float* actions_out_or_null,
-                 float* obs_out, float* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
-                 evac_episode_stats_t* final_stats_or_null, void* stream);
+                 float* slab_out, evac_episode_stats_t* final_stats_or_null, void* stream);
 
 /* State exchange in the reference's own shapes (needed for parity tests, checkpoints):
  * pos/dir float [E][N][2], status uint8 [E][N], agent_pos/agent_dir float [E][2], now int32 [E]. */

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Per-phase s_memtime breakdown of k_rollout (diagnostic build, never shipped).
+#   bash tools/stamps.sh build      (here)      ;   gpurun -- bash tools/stamps.sh run
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+if [ "${1:-build}" = "build" ]; then
+  mkdir -p "$ROOT/tools/ablate_libs"
+  hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -fPIC -shared -DEVAC_STAMP \
+    "$ROOT/evacuation_amd/csrc/evac_api.hip" -o "$ROOT/tools/ablate_libs/libevac_stamp.so" && echo built
+else
+  EVAC_LIB="$ROOT/tools/ablate_libs/libevac_stamp.so" python3 - <<PY
+import ctypes as C, sys, torch
+sys.path.insert(0, "$ROOT")
+import evacuation_amd as ea
+from evacuation_amd import _lib
+lib = _lib.load()
+n, E, T = int("${2:-60}"), int("${3:-4096}"), 100
+env = ea.BatchedEvacuationEnv(ea.EnvConfig(number_of_pedestrians=n, is_new_exiting_reward=True), ea.EnvWrappersConfig(positions="grav"), num_envs=E, seed=1)
+env.reset()
+buf = (C.c_ulonglong * 16)()
+names = ["0 action fetch + noise Philox", "1 leader + pre-pair per-lane", "2 tile write + vote", "3 all-pairs loop",
+         "4 heading/blend/move/reflect", "5 classify + reductions", "6 rewards/flags", "7 reset check + obs + stores"]
+for phase in range(4):
+    env.rollout(T * 5); torch.cuda.synchronize()
+    lib.evac_debug_stamps(buf)
+    env.rollout(T); torch.cuda.synchronize()
+    lib.evac_debug_stamps(buf)
+    waves = E * max(1, (n + 63) // 64 if n <= 64 else (4 if n <= 256 else 8 if n <= 512 else 16))
+    tot = sum(buf[:8])
+    print(f"-- steps {phase*600+500}..{phase*600+600}: {tot / waves / T:.0f} cycles per wave-step")
+    for k in range(8):
+        print(f"   {names[k]:34s} {buf[k] / waves / T:8.1f} cycles/wave-step  {100.0 * buf[k] / tot:5.1f} %")
+PY
+fi
