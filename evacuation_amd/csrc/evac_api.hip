@@ -194,7 +194,10 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
     const float gp = cfg->alpha + 2.0f;
     p.grav_pow_int = (gp == std::floor(gp) && gp >= 1.0f && gp <= 32.0f) ? (int)gp : 0;
     p.nan_guard = cfg->nan_guard != 0;
-    p.small_noise = std::fabs(cfg->noise_coef) * 0.5f <= 0.78539816f;
+    {
+        const float half = std::fabs(cfg->noise_coef) * 0.5f;
+        p.small_noise = half <= 0.2f ? 2 : (half <= 0.78539816f ? 1 : 0);
+    }
     p.seed_lo = (uint32_t)(seed & 0xffffffffull);
     p.seed_hi = (uint32_t)(seed >> 32);
     p.env_id_offset = (uint32_t)env_id_offset;

@@ -70,7 +70,7 @@ struct Params {
     int32_t obs_pos, obs_stat, obs_box, obs_dim;
     float alpha, neg_alpha, grav_pow;               // grav_pow = alpha + 2
     int32_t grav_pow_int;                           // alpha+2 if it is an integer in [1,32], else 0
-    int32_t nan_guard, small_noise;                 // small_noise: noise_coef/2 <= pi/4 -> polynomial sincos
+    int32_t nan_guard, small_noise;                 // small_noise: 2 = |eta| <= 0.2 (short Taylor), 1 = |eta| <= pi/4 (long Taylor), 0 = ocml sincosf
     uint32_t seed_lo, seed_hi, env_id_offset;
     // bound state
     float4* ped;
@@ -154,10 +154,19 @@ __device__ __forceinline__ float powi(float x, int k) {
     return r;
 }
 
-// sin/cos of the angular noise.  |a| <= pi/4 when small_noise: Taylor to x^9 / x^10 (remainder
-// < 2e-9 relative), otherwise the ocml routines with full range reduction.
-__device__ __forceinline__ void noise_sincos(float a, int small_noise, float& s, float& c) {
-    if (small_noise) {
+// sin/cos of the angular noise eta in [-noise_coef/2, noise_coef/2] (wave-uniform regime choice):
+//   |eta| <= 0.2   (noise_coef <= 0.4, the reference's default is 0.2): Taylor to x^5 / x^4, remainder < 3e-9
+//   |eta| <= pi/4  : Taylor to x^9 / x^10, remainder < 2e-9 relative
+//   otherwise      : ocml sincosf with full range reduction
+__device__ __forceinline__ void noise_sincos(float a, int regime, float& s, float& c) {
+    if (regime == 2) {
+        const float z = a * a;
+        float ps = fmaf(z, 8.3333333e-3f, -1.6666667e-1f);
+        ps = ps * z;
+        s = fmaf(ps, a, a);
+        float pc = fmaf(z, 4.1666667e-2f, -0.5f);
+        c = fmaf(pc, z, 1.0f);
+    } else if (regime == 1) {
         const float z = a * a;
         float ps = fmaf(z, 2.7557319e-6f, -1.9841270e-4f);
         ps = fmaf(ps, z, 8.3333333e-3f);
@@ -262,9 +271,11 @@ __device__ __forceinline__ void env_reduce(Smem<WPE>& sm, int slot, int wave_in_
 
 // statuses.py:29-48 -- pure function of the position, the leader position and the exit.
 // `de` returns the distance to the exit (reused by the intrinsic reward, distances.py:51-56).
-__device__ __forceinline__ int classify(const Params& p, float x, float y, float ax, float ay, float& de) {
-    const float lx = x - ax, ly = y - ay;
-    const float dl2 = lx * lx + ly * ly;
+__device__ __forceinline__ int classify(const Params& p, float x, float y, float ax, float ay, float& de,
+                                        float& lx, float& ly, float& dl2) {
+    lx = x - ax;
+    ly = y - ay;
+    dl2 = lx * lx + ly * ly;
     const float ex = x - kExitX, ey = y - kExitY;
     de = fsqrt(ex * ex + ey * ey);
     int st = kViscek;
@@ -278,13 +289,16 @@ __device__ __forceinline__ int classify(const Params& p, float x, float y, float
 // Observation epilogue: env.py:98-104 through the wrapper chain of wrappers/config.py:46-93.
 // `viscek_gx/gy`, `n_follower` come from the caller's reduction when positions == grav.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void grav_term(const Params& p, float rx, float ry, float& gx, float& gy) {
-    // gravity_encoding.py:15-16,35-37:  -alpha / (|R| + eps)^(alpha+2) * R
-    const float nrm = fsqrt(rx * rx + ry * ry) + p.eps;
+// gravity_encoding.py:15-16,35-37:  -alpha / (|R| + eps)^(alpha+2) * R, with |R|^2 given
+__device__ __forceinline__ void grav_term2(const Params& p, float rx, float ry, float r2, float& gx, float& gy) {
+    const float nrm = fsqrt(r2) + p.eps;
     const float pw = p.grav_pow_int ? powi(nrm, p.grav_pow_int) : powf(nrm, p.grav_pow);
     const float c = p.neg_alpha * frcp(pw);
     gx = c * rx;
     gy = c * ry;
+}
+__device__ __forceinline__ void grav_term(const Params& p, float rx, float ry, float& gx, float& gy) {
+    grav_term2(p, rx, ry, rx * rx + ry * ry, gx, gy);
 }
 
 // Gravity observation of the CURRENT state by a full reduction: used by reset / observe and after an
@@ -400,7 +414,8 @@ __device__ __forceinline__ void reset_env(const Params& p, bool active, float4 d
     q.dx = draw.z * inrm;
     q.dy = draw.w * inrm;
     float de;
-    q.st = active ? classify(p, q.x, q.y, 0.0f, 0.0f, de) : 0;
+    float lx, ly, dl2;
+    q.st = active ? classify(p, q.x, q.y, 0.0f, 0.0f, de, lx, ly, dl2) : 0;
 }
 
 __device__ __forceinline__ float4 philox_reset_draw(const Params& p, uint32_t env_gid, int i, int n_resets) {
@@ -457,7 +472,7 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
     e.adx = adir.x;                                                         // area.py:192
     e.ady = adir.y;
     const float tx = e.ax + e.adx, ty = e.ay + e.ady;                       // area.py:201
-    const bool hit = tx < -p.width || tx > p.width || ty < -p.height || ty > p.height;
+    const bool hit = fabsf(tx) > p.width || fabsf(ty) > p.height;           // area.py:203-206: < -W or > W
     e.ax = hit ? e.ax : tx;                                                 // area.py:195
     e.ay = hit ? e.ay : ty;
     const float r_agent = hit ? -5.0f : 0.0f;                               // area.py:198
@@ -470,7 +485,7 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
     q.y = esc ? kExitY : q.y;
     q.dx = esc ? 0.0f : q.dx;
     q.dy = esc ? 0.0f : q.dy;
-    {                                                                       // area.py:84-90
+    if (__ballot(exi) != 0ull) {                                            // area.py:84-90 (area.py:85 `if any(exiting)`)
         const float vx = kExitX - q.x, vy = kExitY - q.y;
         const float l2 = vx * vx + vy * vy;
         const float il = frsq(l2);
@@ -485,11 +500,15 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
     const bool fol = active && q.st == kFollower;
 
     // unit headings of the moving pedestrians: area.py:100-101.  0 * rsq(0) = 0 * inf = NaN, as 0/0.
+    // A NaN heading is written to the tile as it is: w * NaN = NaN even for w = 0, so it poisons every
+    // pedestrian's sum -- exactly the reference's (intersection * u).sum() with NaN * 0 = NaN
+    // (area.py:118-119).  nan_guard (non-reference) zeroes it instead.
     const float inrm = frsq(q.dx * q.dx + q.dy * q.dy);
     float ux = q.dx * inrm, uy = q.dy * inrm;
-    const bool bad = efv && ((ux != ux) || (uy != uy));
-    ux = bad ? 0.0f : ux;
-    uy = bad ? 0.0f : uy;
+    if (p.nan_guard) {          // wave-uniform
+        ux = (ux != ux) ? 0.0f : ux;
+        uy = (uy != uy) ? 0.0f : uy;
+    }
     EVAC_T(1);   // leader + per-lane pre-pair work
     env_sync<WPE>();   // tile readers of the previous step are done
     // The tile holds the moving pedestrians first, compacted in ascending pedestrian order -- the columns
@@ -519,15 +538,7 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
         const int idx = efv ? before : n_cols + (tid - before);             // a bijection onto [0, WPE*64)
         sm.tile[slot][idx] = f4{efv ? q.x : 3.0e38f, q.y, efv ? ux : 0.0f, efv ? uy : 0.0f};
     }
-    // (intersection * u).sum(): NaN * 0 = NaN, so ONE zero-heading pedestrian poisons every row
-    // (area.py:118-119).  Reproduced exactly unless nan_guard.
-    bool poison = false;
-    if constexpr (WPE == 1) {
-        if (!p.nan_guard) poison = __ballot(bad) != 0ull;
-        env_sync<WPE>();
-    } else {
-        poison = __syncthreads_or((bad && !p.nan_guard) ? 1 : 0) != 0;   // barrier + OR over the env's waves
-    }
+    env_sync<WPE>();   // tile complete
 
     // ---- all-pairs neighbour sum: area.py:105-119.  The count n_intersections only rescales the
     // mean heading, which arctan2 ignores; it is not needed.
@@ -559,9 +570,6 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
         }
     }
     EVAC_T(3);   // all-pairs loop
-    const float qnan = __builtin_nanf("");
-    sx = poison ? qnan : sx;
-    sy = poison ? qnan : sy;
 
     // ---- new heading = mean heading rotated by the noise: area.py:120-136.
     // cos/sin(arctan2(my,mx)+eta) = rotation of (mx,my)/|m| by eta; arctan2(0,0) = 0.
@@ -596,29 +604,32 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
 
     EVAC_T(4);   // heading, blend, move, reflect
     // ---- statuses, rewards, termination: area.py:155-178, statuses.py:29-48, reward.py:19-47 ----
-    float de;
-    const int cls = classify(p, q.x, q.y, e.ax, e.ay, de);
+    // The first idle lane (i == N, if the env does not fill its waves) stands on the exit: it evaluates the
+    // gravity exit term (gravity_encoding.py:28-38) with the very same instructions as the pedestrians'
+    // terms instead of a separate single-lane block.  Its classifier result is discarded (inactive).
+    const bool exit_lane = GRAV && i == p.n_ped;
+    const float px = exit_lane ? kExitX : q.x, py = exit_lane ? kExitY : q.y;
+    float de, lx, ly, dl2;
+    const int cls = classify(p, px, py, e.ax, e.ay, de, lx, ly, dl2);
     const int new_st = active ? cls : 0;
     q.st = new_st;
     Sums s{};
     s.f0 = active ? de : 0.0f;
-    // gravity observation of the post-step state, fused into the same reduction (gravity_encoding.py:8-38).
-    // The first idle lane (i == N, if the env does not fill its waves) evaluates the exit term with the
-    // very same instructions instead of a separate single-lane block.
-    bool exit_lane = false;
+    // gravity observation of the post-step state, fused into the same reduction (gravity_encoding.py:8-25);
+    // R = agent - pos = -(pos - agent) reuses the classifier's offset and squared distance.
     float gx = 0.0f, gy = 0.0f;
     if constexpr (GRAV) {
-        exit_lane = i == p.n_ped;
-        const float px = exit_lane ? kExitX : q.x, py = exit_lane ? kExitY : q.y;
-        grav_term(p, e.ax - px, e.ay - py, gx, gy);
+        grav_term2(p, -lx, -ly, dl2, gx, gy);
         const bool visc = new_st == kViscek;
         s.f1 = visc ? gx : 0.0f;
         s.f2 = visc ? gy : 0.0f;
     }
+    // per-step counts: the two reward transitions, escaped (termination) and followers (gravity exit term);
+    // exiting / viscek counts are only part of the episode record and are taken at episode end.
     const bool pred[8] = {
         (old_st == kViscek || old_st == kFollower) && new_st == kExiting,    // reward.py:35-39
         old_st == kViscek && new_st == kFollower,                             // reward.py:43-46
-        new_st == kEscaped, new_st == kExiting, new_st == kFollower, new_st == kViscek, false, false};
+        new_st == kEscaped, false, new_st == kFollower, false, false, false};
     float ex = 0.0f, ey = 0.0f;
     if constexpr (GRAV && WPE > 1) {
         if (exit_lane) {
@@ -647,9 +658,8 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
     }
     EVAC_T(5);   // classify + reductions
     out.n_escaped = s.i[2];
-    out.n_exiting = s.i[3];
     out.n_follower = s.i[4];
-    out.n_viscek = s.i[5];
+    out.n_exiting = out.n_viscek = 0;   // filled by finish_counts() when the episode ends
 
     const float tf = 1.0f - (float)e.now * p.inv_200n;                      // reward.py:26
     float r_ped = p.init_reward;
@@ -695,6 +705,16 @@ __device__ __forceinline__ void store_env(const Params& p, int env, int i, bool 
     }
 }
 
+// exiting / viscek counts of the final state for the episode record (env.py:120-123); called by all lanes
+// of the env when an episode ends (rare), so the per-step reduction does not carry them.
+template <int WPE>
+__device__ __forceinline__ void finish_counts(Smem<WPE>& sm, int slot, int wave_in_env, int lane, const Ped& q, StepOut& o) {
+    Sums s{};
+    const bool pred[8] = {q.st == kExiting, q.st == kViscek, false, false, false, false, false, false};
+    env_reduce<WPE>(sm, slot, wave_in_env, lane, s, pred);
+    o.n_exiting = s.i[0];
+    o.n_viscek = s.i[1];
+}
 __device__ __forceinline__ void write_stats(evac_episode_stats_t* dst, const Env& e, const StepOut& o) {
     dst->episode_reward = e.acc_ret;
     dst->episode_length = (float)e.now;
@@ -765,7 +785,10 @@ __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_step(
                 write_obs<WPE, GRAV>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, fo);
             }
         }
-        if (final_stats && w.i == 0) write_stats(final_stats + w.env, e, o);
+        if (final_stats) {
+            finish_counts<WPE>(sm, w.slot, w.wave_in_env, w.lane, q, o);
+            if (w.i == 0) write_stats(final_stats + w.env, e, o);
+        }
         reset_env(p, active, philox_reset_draw(p, gid, w.i, e.n_resets), q, e);
         if constexpr (GRAV) grav_observation<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, active, q, e, o6);
     }
@@ -852,7 +875,10 @@ __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_rollout(
         step_env<WPE, GRAV>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, adir, nz, o EVAC_STAMP_ARGS);
         float o6[6] = {e.ax, e.ay, o.ex, o.ey, o.gx, o.gy};
         if (o.terminated || o.truncated) {   // wave-/workgroup-uniform, rare
-            if (final_stats && w.i == 0) write_stats(final_stats + (size_t)t * E + w.env, e, o);
+            if (final_stats) {
+                finish_counts<WPE>(sm, w.slot, w.wave_in_env, w.lane, q, o);
+                if (w.i == 0) write_stats(final_stats + (size_t)t * E + w.env, e, o);
+            }
             reset_env(p, active, philox_reset_draw(p, gid, w.i, e.n_resets), q, e);
             if constexpr (GRAV) grav_observation<WPE>(p, sm, w.slot, w.wave_in_env, w.lane, active, q, e, o6);
         }
