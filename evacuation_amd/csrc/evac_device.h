@@ -120,6 +120,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     v = dpp_add<0x143, 0xc>(v);
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// Three sums at once, the three DPP chains interleaved step by step: a DPP source written by the previous
+// VALU instruction costs wait states (the compiler pads a single chain with s_nop); with three independent
+// chains in lock-step the hazard is covered by real work.
+__device__ __forceinline__ void wave_sum3(float& a, float& b, float& c) {
+#define EVAC_DPP3(CTRL, MASK) a = dpp_add<CTRL, MASK>(a); b = dpp_add<CTRL, MASK>(b); c = dpp_add<CTRL, MASK>(c);
+    EVAC_DPP3(0x111, 0xf)
+    EVAC_DPP3(0x112, 0xf)
+    EVAC_DPP3(0x114, 0xf)
+    EVAC_DPP3(0x118, 0xf)
+    EVAC_DPP3(0x142, 0xa)
+    EVAC_DPP3(0x143, 0xc)
+#undef EVAC_DPP3
+    a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
+    b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 63));
+    c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), 63));
+}
 __device__ __forceinline__ int wave_count(bool p) { return __popcll(__ballot(p)); }
 
 // 1-ulp hardware reciprocal / rsqrt / sqrt (v_rcp_f32, v_rsq_f32, v_sqrt_f32) instead of the ~10
@@ -241,9 +257,7 @@ struct Sums {
 template <int WPE>
 __device__ __forceinline__ void env_reduce(Smem<WPE>& sm, int slot, int wave_in_env, int lane, Sums& s,
                                            const bool (&pred)[8]) {
-    s.f0 = wave_sum(s.f0);
-    s.f1 = wave_sum(s.f1);
-    s.f2 = wave_sum(s.f2);
+    wave_sum3(s.f0, s.f1, s.f2);
 #pragma unroll
     for (int k = 0; k < 8; ++k) s.i[k] = wave_count(pred[k]);
     if constexpr (WPE > 1) {
