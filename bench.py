@@ -102,11 +102,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; evacuation_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device(f"cuda:{local_rank}")
+    dev_index = int(os.environ.get("EVAC_BENCH_FORCE_DEVICE", local_rank))   # testing aid: several ranks on one GPU
+    torch.cuda.set_device(dev_index)
+    device = torch.device(f"cuda:{dev_index}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("EVAC_BENCH_BACKEND", "nccl")                 # "nccl" IS RCCL on ROCm; gloo = testing aid
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import evacuation_amd as ea
     from evacuation_amd.distributed import ShardedEvacuationEnv
@@ -186,6 +191,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Exercise the collective once before anything is timed.  If RCCL cannot gather on this node the
+    # benchmark degrades to independent shards (and says so) instead of dying without a number.
+    gather_note = None
+    if do_gather:
+        ok = torch.ones(1, device=device)
+        try:
+            all_gather_envs(bufs[0]["slab"], out=gathered[0])
+            torch.cuda.synchronize()
+        except Exception as exc:  # noqa: BLE001
+            ok.zero_()
+            gather_note = f"all-gather disabled: {type(exc).__name__}: {exc}"[:200]
+        try:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() == 0:
+                do_gather = False
+        except Exception as exc:  # noqa: BLE001
+            do_gather = False
+            gather_note = gather_note or f"all-reduce failed: {type(exc).__name__}"
+        if not do_gather and gather_note is None:
+            gather_note = "all-gather disabled: failed on another rank"
+
     run(W)                                                    # untimed warm-up
     barrier()
     events = []
@@ -241,6 +267,7 @@ def main():
                        "obs": wrap_kw, "actions": "RandomAgent U(-1,1)^2 drawn on device (Philox4x32-10)",
                        "mode": args.mode, "steps_per_launch": inner, "launches": launches,
                        "parallelism": f"env-sharded x{world}" + (", RCCL all-gather of [obs|reward|flags] per chunk" if do_gather else ""),
+                       "gather_note": gather_note,
                        "max_timesteps": 2000, "autoreset": True},
             "agent_updates_per_s": value * n_ped,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
