@@ -222,7 +222,10 @@ struct StepOut {
 template <int WPE>
 struct Geometry {
     static constexpr int kThreadsPerEnv = WPE * kWave;
-    static constexpr int kBlock = (kThreadsPerEnv < 256) ? 256 : kThreadsPerEnv;
+#ifndef EVAC_BLOCK1
+#define EVAC_BLOCK1 256
+#endif
+    static constexpr int kBlock = (kThreadsPerEnv < EVAC_BLOCK1) ? EVAC_BLOCK1 : kThreadsPerEnv;
     static constexpr int kEnvsPerBlock = kBlock / kThreadsPerEnv;
 };
 
