@@ -426,3 +426,38 @@ def test_single_env_facade_matches_reference_surface(ea):
     env.close()
     with pytest.raises(NotImplementedError):
         ea.setup_env(cfg_from_params(ea, p), ea.EnvWrappersConfig(positions="grav", type="Box"))
+
+
+def test_philox_rollouts_are_statistically_equivalent_to_the_reference_rng(ea):
+    """trajectories diverge chaotically, so Philox-mode rollouts are compared with
+    oracle episodes driven by NumPy's RNG (the reference's own noise / reset / RandomAgent distributions)
+    through distributions: status counts and mean reward after 150 and 400 steps."""
+    import torch
+    n, E_gpu, E_cpu = 60, 2048, 48
+    p = O.OracleParams(number_of_pedestrians=n, is_new_exiting_reward=True, max_timesteps=100000)
+    env = ea.BatchedEvacuationEnv(cfg_from_params(ea, p), ea.EnvWrappersConfig(positions="grav"), num_envs=E_gpu, seed=1234)
+    env.reset()
+    rng = np.random.default_rng(7)
+    cpu = [O.env_reset(p, rng.uniform(-1, 1, (n, 2)), rng.uniform(-1, 1, (n, 2))) for _ in range(E_cpu)]
+    cpu_rew = np.zeros(E_cpu)
+    t_prev = 0
+    for t_check in (150, 400):
+        ro = env.rollout(t_check - t_prev)
+        gpu_rew = ro["reward"].mean().item()
+        for e, st in enumerate(cpu):
+            acc = 0.0
+            for _ in range(t_check - t_prev):
+                acc += O.env_step(p, st, rng.uniform(-1, 1, 2).astype(np.float32), O.draw_step_noise(p, st, rng))["reward"]
+            cpu_rew[e] = acc / (t_check - t_prev)
+        t_prev = t_check
+        s = env.get_state()["status"]
+        gpu_counts = torch.stack([(s == k).sum(dim=1).float() for k in (1, 2, 3, 4)], dim=1).cpu().numpy()   # [E,4]
+        cpu_counts = np.array([[np.sum(st.status == k) for k in (1, 2, 3, 4)] for st in cpu], dtype=np.float64)
+        for k, name in enumerate(("viscek", "follower", "exiting", "escaped")):
+            g, c = gpu_counts[:, k], cpu_counts[:, k]
+            se = np.sqrt(g.var() / len(g) + c.var() / len(c)) + 1e-9
+            z = (g.mean() - c.mean()) / se
+            assert abs(z) < 4.5, (t_check, name, g.mean(), c.mean(), z)
+        se = cpu_rew.std() / np.sqrt(E_cpu) + 1e-9
+        assert abs(gpu_rew - cpu_rew.mean()) < 5 * se + 0.02, (t_check, gpu_rew, cpu_rew.mean(), se)
+    env.close()
