@@ -8,7 +8,7 @@ from .config import EnvConfig, EnvWrappersConfig
 from .statuses import Status
 
 __all__ = ["EnvConfig", "EnvWrappersConfig", "Status", "setup_env", "EvacuationEnv", "BatchedEvacuationEnv",
-           "ShardedEvacuationEnv", "RandomAgent"]
+           "ShardedEvacuationEnv", "NormalizedVectorEnv", "RandomAgent"]
 
 
 def __getattr__(name):   # lazy: keeps `import evacuation_amd` light and torch-free for config users
@@ -21,6 +21,9 @@ def __getattr__(name):   # lazy: keeps `import evacuation_amd` light and torch-f
     if name == "ShardedEvacuationEnv":
         from .distributed import ShardedEvacuationEnv
         return ShardedEvacuationEnv
+    if name == "NormalizedVectorEnv":
+        from .wrappers import NormalizedVectorEnv
+        return NormalizedVectorEnv
     if name == "RandomAgent":
         from .agents import RandomAgent
         return RandomAgent

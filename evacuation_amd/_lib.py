@@ -26,7 +26,7 @@ class EvacConfig(C.Structure):
         ("is_new_followers_reward", C.c_int32), ("intrinsic_reward_coef", C.c_float),
         ("is_termination_agent_wall_collision", C.c_int32), ("init_reward_each_step", C.c_float),
         ("max_timesteps", C.c_int32), ("positions", C.c_int32), ("statuses", C.c_int32),
-        ("type", C.c_int32), ("alpha", C.c_float), ("nan_guard", C.c_int32),
+        ("type", C.c_int32), ("alpha", C.c_float), ("nan_guard", C.c_int32), ("clip_action", C.c_int32),
     ]
 
 
@@ -56,6 +56,10 @@ SIGNATURES = {
     "evac_set_state": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "evac_observe": (C.c_int, [_P, _P, _P]),
     "evac_algorithmic_bytes_per_env_step": (C.c_int64, [_P]),
+    "evac_norm_state_doubles": (C.c_int64, [_P]),
+    "evac_norm_init": (C.c_int, [_P, _P, _P]),
+    "evac_norm_reset": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, _P]),
+    "evac_norm_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
 }
 
 _lib = None

@@ -44,6 +44,8 @@ class EnvConfig:
     path_logs: str = "saved_data/logs"
     # extension (not in the reference): see include/evac.h evac_config_t.nan_guard
     nan_guard: bool = False
+    # extension: gym.wrappers.ClipAction of the trainer's wrapper chain (rpo_agent.py:27) fused into the step
+    clip_action: bool = False
 
     def __post_init__(self):
         # config.py:97-100
@@ -103,6 +105,7 @@ def to_c_config(env: EnvConfig, wrap: EnvWrappersConfig) -> "_lib.EvacConfig":
     c.type = _lib.TYPE[wrap.type]
     c.alpha = float(wrap.alpha)
     c.nan_guard = int(bool(env.nan_guard))
+    c.clip_action = int(bool(env.clip_action))
     return c
 
 

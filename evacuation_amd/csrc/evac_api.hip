@@ -194,6 +194,7 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
     const float gp = cfg->alpha + 2.0f;
     p.grav_pow_int = (gp == std::floor(gp) && gp >= 1.0f && gp <= 32.0f) ? (int)gp : 0;
     p.nan_guard = cfg->nan_guard != 0;
+    p.clip_action = cfg->clip_action != 0;
     {
         const float half = std::fabs(cfg->noise_coef) * 0.5f;
         p.small_noise = half <= 0.2f ? 2 : (half <= 0.78539816f ? 1 : 0);
@@ -303,6 +304,46 @@ int evac_set_state(evac_handle_t h, const float* pos, const float* dir, const ui
                        (const float2*)pos, (const float2*)dir, status, (const float2*)agent_pos,
                        (const float2*)agent_dir, now);
     return check_launch(h, "evac_set_state");
+}
+
+int64_t evac_norm_state_doubles(evac_handle_t h) { return h ? 3ll * h->p.obs_dim + 4 : -1; }
+
+int evac_norm_init(evac_handle_t h, double* norm_state, void* stream) {
+    if (!h) return EVAC_ERR_INVALID_ARGUMENT;
+    if (!norm_state) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_norm_init: norm_state is NULL");
+    DeviceGuard g(h->device);
+    hipLaunchKernelGGL(evac::k_norm_init, dim3(1024), dim3(256), 0, (hipStream_t)stream, h->p.n_envs, h->p.obs_dim, norm_state);
+    return check_launch(h, "evac_norm_init");
+}
+
+static unsigned norm_grid(const evac::Params& p) {
+    const size_t n = (size_t)p.n_envs * (p.obs_dim + 1);
+    const size_t b = (n + 255) / 256;
+    return (unsigned)(b < 4096 ? (b ? b : 1) : 4096);
+}
+
+int evac_norm_reset(evac_handle_t h, const uint8_t* mask, float* obs, double* norm_state, float obs_clip, float epsilon,
+                    void* stream) {
+    if (!h) return EVAC_ERR_INVALID_ARGUMENT;
+    if (!obs || !norm_state) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_norm_reset: obs / norm_state is NULL");
+    DeviceGuard g(h->device);
+    hipLaunchKernelGGL(evac::k_norm_step, dim3(norm_grid(h->p)), dim3(256), 0, (hipStream_t)stream, h->p.n_envs, h->p.obs_dim,
+                       obs, (float*)nullptr, (float*)nullptr, (const uint8_t*)nullptr, (const uint8_t*)nullptr, mask, norm_state,
+                       0.0f, obs_clip, 0.0f, epsilon, 1);
+    return check_launch(h, "evac_norm_reset");
+}
+
+int evac_norm_step(evac_handle_t h, float* obs, float* final_obs, float* reward, const uint8_t* terminated,
+                   const uint8_t* truncated, double* norm_state, float gamma, float obs_clip, float reward_clip,
+                   float epsilon, void* stream) {
+    if (!h) return EVAC_ERR_INVALID_ARGUMENT;
+    if (!obs || !reward || !terminated || !truncated || !norm_state)
+        return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_norm_step: obs/reward/terminated/truncated/norm_state must be non-NULL");
+    DeviceGuard g(h->device);
+    hipLaunchKernelGGL(evac::k_norm_step, dim3(norm_grid(h->p)), dim3(256), 0, (hipStream_t)stream, h->p.n_envs, h->p.obs_dim,
+                       obs, final_obs, reward, terminated, truncated, (const uint8_t*)nullptr, norm_state, gamma, obs_clip,
+                       reward_clip, epsilon, 0);
+    return check_launch(h, "evac_norm_step");
 }
 
 #ifdef EVAC_STAMP

@@ -70,6 +70,7 @@ struct Params {
     int32_t obs_pos, obs_stat, obs_box, obs_dim;
     float alpha, neg_alpha, grav_pow;               // grav_pow = alpha + 2
     int32_t grav_pow_int;                           // alpha+2 if it is an integer in [1,32], else 0
+    int32_t clip_action;
     int32_t nan_guard, small_noise;                 // small_noise: 2 = |eta| <= 0.2 (short Taylor), 1 = |eta| <= pi/4 (long Taylor), 0 = ocml sincosf
     uint32_t seed_lo, seed_hi, env_id_offset;
     // bound state
@@ -465,6 +466,10 @@ __device__ __forceinline__ void pair_accumulate(float xi, float yi, f4 t, float 
 // ------------------------------------------------------------------------------------------------
 // area.py:189-192: a /= |a| + eps ; agent.direction = step_size * a
 __device__ __forceinline__ float2 agent_direction(const Params& p, float act_x, float act_y) {
+    if (p.clip_action) {                                  // gym.wrappers.ClipAction (rpo_agent.py:27), wave-uniform
+        act_x = __builtin_amdgcn_fmed3f(act_x, -1.0f, 1.0f);
+        act_y = __builtin_amdgcn_fmed3f(act_y, -1.0f, 1.0f);
+    }
     const float inrm = frcp(fsqrt(act_x * act_x + act_y * act_y) + p.eps);   // area.py:190
     return make_float2(p.step_size * (act_x * inrm), p.step_size * (act_y * inrm));
 }
@@ -1006,6 +1011,78 @@ __global__ void k_set_state(Params p, const float2* pos, const float2* dir, cons
                 c.x = now[k];
                 p.clock[k] = c;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The trainer's per-env wrapper chain as a device epilogue (rpo_agent.py:24-33): NormalizeObservation,
+// clip, NormalizeReward(gamma), clip.  gymnasium's RunningMeanStd update for a batch of one sample,
+// float64 like gymnasium's.  norm_state per env: obs_mean[D] | obs_var[D] | obs_count[D] | ret_mean |
+// ret_var | ret_count | returns  (the count is replicated per feature so that threads never share a word).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rms_update1(double& mean, double& var, double& count, double x) {
+    const double delta = x - mean;
+    const double tot = count + 1.0;
+    const double new_mean = mean + delta / tot;
+    const double m2 = var * count + delta * delta * count / tot;
+    mean = new_mean;
+    var = m2 / tot;
+    count = tot;
+}
+__device__ __forceinline__ float norm_clip(double x, double mean, double var, double eps, float clip) {
+    const double v = (x - mean) / sqrt(var + eps);
+    return (float)fmin(fmax(v, -(double)clip), (double)clip);
+}
+
+__global__ void k_norm_init(int n_envs, int D, double* __restrict__ st) {
+    const int W = 3 * D + 4;
+    const size_t n = (size_t)n_envs * W;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(k % W);
+        double v = 0.0;                                   // means, returns
+        if (c >= D && c < 2 * D) v = 1.0;                 // obs_var
+        else if (c >= 2 * D && c < 3 * D) v = 1e-4;       // obs_count (RunningMeanStd epsilon)
+        else if (c == 3 * D + 1) v = 1.0;                 // ret_var
+        else if (c == 3 * D + 2) v = 1e-4;                // ret_count
+        st[k] = v;
+    }
+}
+
+// One thread per (env, feature) plus one per env for the reward.  On a finished env (same-step autoreset)
+// the terminal observation is normalised first (and counted), then the reset observation -- the order in
+// which SyncVectorEnv runs the wrapped step() and reset().
+__global__ void k_norm_step(int n_envs, int D, float* __restrict__ obs, float* __restrict__ final_obs,
+                            float* __restrict__ reward, const uint8_t* __restrict__ terminated,
+                            const uint8_t* __restrict__ truncated, const uint8_t* __restrict__ reset_mask,
+                            double* __restrict__ st, float gamma, float obs_clip, float reward_clip, float eps,
+                            int reset_only) {
+    const int W = 3 * D + 4;
+    const size_t n = (size_t)n_envs * (D + 1);
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(k / (D + 1)), d = (int)(k % (D + 1));
+        double* s = st + (size_t)e * W;
+        if (reset_only && reset_mask && !reset_mask[e]) continue;
+        if (d < D) {
+            double mean = s[d], var = s[D + d], cnt = s[2 * D + d];
+            const bool done = !reset_only && ((terminated && terminated[e]) || (truncated && truncated[e]));
+            if (done && final_obs) {
+                const double x = final_obs[(size_t)e * D + d];
+                rms_update1(mean, var, cnt, x);
+                final_obs[(size_t)e * D + d] = norm_clip(x, mean, var, eps, obs_clip);
+            }
+            const double x = obs[(size_t)e * D + d];
+            rms_update1(mean, var, cnt, x);
+            obs[(size_t)e * D + d] = norm_clip(x, mean, var, eps, obs_clip);
+            s[d] = mean; s[D + d] = var; s[2 * D + d] = cnt;
+        } else if (!reset_only) {
+            double mean = s[3 * D], var = s[3 * D + 1], cnt = s[3 * D + 2], ret = s[3 * D + 3];
+            const double r = reward[e];
+            ret = ret * (double)gamma * (1.0 - ((terminated && terminated[e]) ? 1.0 : 0.0)) + r;
+            rms_update1(mean, var, cnt, ret);
+            const double v = r / sqrt(var + (double)eps);
+            reward[e] = (float)fmin(fmax(v, -(double)reward_clip), (double)reward_clip);
+            s[3 * D] = mean; s[3 * D + 1] = var; s[3 * D + 2] = cnt; s[3 * D + 3] = ret;
         }
     }
 }

@@ -80,6 +80,8 @@ typedef struct evac_config {
     /* 0 (default): bit-faithful to the reference, where a zero heading (0/0, area.py:101) poisons every
      * FOLLOWER/VISCEK pedestrian with NaN.  1: a zero heading contributes nothing (non-reference). */
     int32_t nan_guard;
+    /* gym.wrappers.ClipAction of the trainer's wrapper chain (rpo_agent.py:27): clip actions to [-1,1] first */
+    int32_t clip_action;
 } evac_config_t;
 
 /* Written for envs whose episode ended this step (env.py:115-125 logging dict). */
@@ -166,6 +168,24 @@ int evac_observe(evac_handle_t h, float* obs_out, void* stream);
 /* Algorithmic HBM bytes of one env-step for this handle (32N+62 for grav, 56N+86
  * for Box+ohe, ...).  Used by bench.py for roofline accounting. */
 int64_t evac_algorithmic_bytes_per_env_step(evac_handle_t h);
+
+/* ---- The trainer's per-env wrapper chain on device (rpo_agent.py:24-33) ----
+ * NormalizeObservation -> clip(obs, +-obs_clip) -> NormalizeReward(gamma) -> clip(reward, +-reward_clip), one set
+ * of running statistics per env (gymnasium wrappers/normalize.py RunningMeanStd, float64), applied IN PLACE to
+ * the outputs of evac_step / evac_reset.  ClipAction is evac_config_t.clip_action; FlattenObservation is the
+ * flat observation layout; RecordEpisodeStatistics is evac_episode_stats_t.
+ *   norm_state  double [E][evac_norm_state_doubles(h)] = obs_mean[D] | obs_var[D] | obs_count[D] | ret_mean |
+ *               ret_var | ret_count | returns   (caller-owned, initialise with evac_norm_init)
+ * evac_norm_step: for envs that finished (terminated|truncated, same-step autoreset) final_obs (the terminal
+ * observation, may be NULL) is normalised and counted first, then obs (the reset observation) -- the order in
+ * which SyncVectorEnv calls the wrapped step() and reset(). */
+int64_t evac_norm_state_doubles(evac_handle_t h);
+int evac_norm_init(evac_handle_t h, double* norm_state, void* stream);
+int evac_norm_reset(evac_handle_t h, const uint8_t* mask_or_null, float* obs, double* norm_state, float obs_clip,
+                    float epsilon, void* stream);
+int evac_norm_step(evac_handle_t h, float* obs, float* final_obs_or_null, float* reward, const uint8_t* terminated,
+                   const uint8_t* truncated, double* norm_state, float gamma, float obs_clip, float reward_clip,
+                   float epsilon, void* stream);
 
 #ifdef __cplusplus
 }
