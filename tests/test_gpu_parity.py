@@ -461,3 +461,29 @@ def test_philox_rollouts_are_statistically_equivalent_to_the_reference_rng(ea):
         se = cpu_rew.std() / np.sqrt(E_cpu) + 1e-9
         assert abs(gpu_rew - cpu_rew.mean()) < 5 * se + 0.02, (t_check, gpu_rew, cpu_rew.mean(), se)
     env.close()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(noise_coef=2.5, step_size=0.03, enslaving_degree=0.3),                 # ocml sincosf regime
+    dict(noise_coef=1.2, width=1.5, height=0.7, eps=1e-3),                      # long Taylor regime, non-unit room
+    dict(noise_coef=0.05, step_size=0.1, intrinsic_reward_coef=2.0, init_reward_each_step=0.0,
+         is_new_followers_reward=False, is_new_exiting_reward=True),
+], ids=["big_noise", "mid_noise_room", "coarse_step"])
+def test_unusual_parameters_take_the_rare_code_paths(ea, kw):
+    """Teacher-forced parity on oracle-generated states for parameter values that select the kernel's
+    rarely used branches (sincos regimes 0/1, powf for non-integer alpha, walls != 1, large eps)."""
+    n, E = 47, 10
+    rng = np.random.default_rng(int(1000 * kw["noise_coef"]) + 17)          # fixed per case (str hashes are salted)
+    p = O.OracleParams(number_of_pedestrians=n, **kw)
+    pre, acts, nzs = [], [], []
+    for e in range(E):
+        st = O.env_reset(p, rng.uniform(-1, 1, (n, 2)), rng.uniform(-1, 1, (n, 2)))
+        for _ in range(2 + 4 * e):
+            O.env_step(p, st, rng.uniform(-1, 1, 2).astype(np.float32), rng.uniform(-p.noise_coef / 2, p.noise_coef / 2, n))
+        pre.append(st)
+        acts.append(rng.uniform(-1, 1, 2).astype(np.float32))
+        nzs.append(rng.uniform(-p.noise_coef / 2, p.noise_coef / 2, n).astype(np.float32))
+    for w in (dict(positions="grav", alpha=2.5), dict(positions="grav", alpha=7), dict(positions="rel", statuses="cat")):
+        wrap = ea.EnvWrappersConfig(**w)
+        got = gpu_step_batch(ea, p, wrap, pre, acts, nzs)
+        compare_step(p, wrap, pre, acts, nzs, got, min_checked=E - 3)
