@@ -246,6 +246,27 @@ def main():
         dt = time.perf_counter() - t1
         step_api = {"env_steps_per_s": E * n_api / dt, "us_per_step": dt / n_api * 1e6,
                     "note": "one evac_step launch per step from Python/ctypes, single GPU, no gather"}
+        try:    # the same step captured once into a hipGraph and replayed (what a graph-captured trainer loop pays)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    for _ in range(10):
+                        loc.step(step_actions)
+            torch.cuda.current_stream().wait_stream(side)
+            for _ in range(5):
+                graph.replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n_api // 10):
+                graph.replay()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            step_api["hipgraph_us_per_step"] = dt / (n_api // 10 * 10) * 1e6
+            step_api["hipgraph_env_steps_per_s"] = E * (n_api // 10 * 10) / dt
+        except Exception as exc:  # noqa: BLE001
+            step_api["hipgraph_error"] = f"{type(exc).__name__}: {exc}"[:160]
 
     if rank == 0:
         traffic = None

@@ -487,3 +487,38 @@ def test_unusual_parameters_take_the_rare_code_paths(ea, kw):
         wrap = ea.EnvWrappersConfig(**w)
         got = gpu_step_batch(ea, p, wrap, pre, acts, nzs)
         compare_step(p, wrap, pre, acts, nzs, got, min_checked=E - 3)
+
+
+def test_step_is_hipgraph_capturable(ea):
+    """evac_step only enqueues work on the caller's stream (no sync, no allocation), so a trainer can
+    capture `policy -> env.step` into a hipGraph; replays must equal eager steps bit for bit."""
+    import torch
+    n, E, seed = 60, 64, 11
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=9)
+    wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
+    a = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed)
+    b = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed)
+    a.reset(); b.reset()
+    act = torch.zeros((E, 2), dtype=torch.float32, device=a.device)
+    acts = torch.rand((20, E, 2), device=a.device) * 2 - 1
+    act.copy_(acts[0])
+    a.step(act)                                  # warm-up outside capture
+    b.step(acts[0].contiguous())
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        act.copy_(acts[1])
+        with torch.cuda.graph(g, stream=s):
+            a.step(act)
+    torch.cuda.current_stream().wait_stream(s)
+    b_out = []
+    for t in range(1, 20):
+        act.copy_(acts[t])
+        g.replay()
+        o, r, te, tr, _ = b.step(acts[t].contiguous())
+        torch.cuda.synchronize()
+        assert (a.obs == o).all() and (a.reward == r).all() and (a.terminated == te).all() and (a.truncated == tr).all(), t
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert (sa[k] == sb[k]).all(), k
