@@ -51,7 +51,7 @@ SIGNATURES = {
     "evac_bind_state": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "evac_reset": (C.c_int, [_P, _P, _P, _P, _P]),
     "evac_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
-    "evac_rollout": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
+    "evac_rollout": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P]),
     "evac_get_state": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "evac_set_state": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "evac_observe": (C.c_int, [_P, _P, _P]),

@@ -261,15 +261,21 @@ int evac_step(evac_handle_t h, const float* actions, const float* noise, float* 
 }
 
 int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* actions_out, float* slab_out,
-                 evac_episode_stats_t* final_stats, void* stream) {
+                 evac_episode_stats_t* final_stats, int32_t capture_envs, float* capture, void* stream) {
     EVAC_REQUIRE_BOUND(h, "evac_rollout");
     if (n_steps < 1) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_rollout: n_steps must be >= 1");
     if (!slab_out) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_rollout: slab_out must be non-NULL");
     if (((uintptr_t)actions | (uintptr_t)actions_out) & 7u)
         return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_rollout: actions buffers must be 8-byte aligned");
     DeviceGuard g(h->device);
-    EVAC_DISPATCH(h, k_rollout, stream, h->p, (int)n_steps, (const float2*)actions, (float2*)actions_out, slab_out,
-                  final_stats);
+    if (capture && (capture_envs < 1 || capture_envs > h->p.n_envs))
+        return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_rollout: capture_envs must be in [1, num_envs] when capture is given");
+    if (capture)
+        EVAC_DISPATCH(h, k_rollout_capture, stream, h->p, (int)n_steps, (const float2*)actions, (float2*)actions_out, slab_out,
+                      final_stats, (int)capture_envs, capture);
+    else
+        EVAC_DISPATCH(h, k_rollout, stream, h->p, (int)n_steps, (const float2*)actions, (float2*)actions_out, slab_out,
+                      final_stats);
     return check_launch(h, "evac_rollout");
 }
 

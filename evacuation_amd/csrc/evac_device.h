@@ -835,11 +835,11 @@ __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_step(
 // for the all-gather and a single coalesced store stream for the kernel.  GRAV kernels stage the 9 words
 // of up to 7 steps in LDS and flush them with one 64-lane store (five single-lane stores per step cost a
 // third of the step before: profiles/r01_e_*).
-template <int WPE, bool GRAV>
-__global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_rollout(
-    Params p, int n_steps, const float2* __restrict__ actions, float2* __restrict__ actions_out,
-    float* __restrict__ slab_out, evac_episode_stats_t* __restrict__ final_stats) {
-    __shared__ Smem<WPE> sm;
+template <int WPE, bool GRAV, bool CAPTURE>
+__device__ __forceinline__ void rollout_body(
+    Smem<WPE>& sm, const Params& p, int n_steps, const float2* __restrict__ actions, float2* __restrict__ actions_out,
+    float* __restrict__ slab_out, evac_episode_stats_t* __restrict__ final_stats, int capture_envs,
+    float* __restrict__ capture) {
     const Who<WPE> w;
     if (w.env >= p.n_envs) return;
     const bool active = w.i < p.n_ped;
@@ -895,6 +895,21 @@ __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_rollout(
         StepOut o;
         EVAC_T(0);   // action fetch + noise Philox
         step_env<WPE, GRAV>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, adir, nz, o EVAC_STAMP_ARGS);
+        // trajectory capture for rendering (Pedestrians.save / Agent.save, pedestrians.py:33-35, area.py:32-33):
+        // the post-step, pre-reset state of the first `capture_envs` envs; row N holds the leader.
+        if (CAPTURE && w.env < capture_envs) {   // wave-/workgroup-uniform; compiled out of the default kernel
+            float* cp = capture + (((size_t)t * capture_envs + w.env) * (p.n_ped + 1)) * 3;
+            if (active) {
+                cp[3 * w.i + 0] = q.x;
+                cp[3 * w.i + 1] = q.y;
+                cp[3 * w.i + 2] = (float)q.st;
+            }
+            if (w.i == 0) {
+                cp[3 * p.n_ped + 0] = e.ax;
+                cp[3 * p.n_ped + 1] = e.ay;
+                cp[3 * p.n_ped + 2] = 0.0f;
+            }
+        }
         float o6[6] = {e.ax, e.ay, o.ex, o.ey, o.gx, o.gy};
         if (o.terminated || o.truncated) {   // wave-/workgroup-uniform, rare
             if (final_stats) {
@@ -942,6 +957,23 @@ __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_rollout(
         for (int k = 0; k < 8; ++k) atomicAdd(&g_stamps[k], stamp_acc[k]);
 #endif
     store_env(p, w.env, w.i, active, q, e);
+}
+
+// The default face carries no capture code at all; the capture face is used by rollout(capture_envs=K).
+template <int WPE, bool GRAV>
+__global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_rollout(
+    Params p, int n_steps, const float2* __restrict__ actions, float2* __restrict__ actions_out,
+    float* __restrict__ slab_out, evac_episode_stats_t* __restrict__ final_stats) {
+    __shared__ Smem<WPE> sm;
+    rollout_body<WPE, GRAV, false>(sm, p, n_steps, actions, actions_out, slab_out, final_stats, 0, nullptr);
+}
+template <int WPE, bool GRAV>
+__global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_rollout_capture(
+    Params p, int n_steps, const float2* __restrict__ actions, float2* __restrict__ actions_out,
+    float* __restrict__ slab_out, evac_episode_stats_t* __restrict__ final_stats, int capture_envs,
+    float* __restrict__ capture) {
+    __shared__ Smem<WPE> sm;
+    rollout_body<WPE, GRAV, true>(sm, p, n_steps, actions, actions_out, slab_out, final_stats, capture_envs, capture);
 }
 
 template <int WPE, bool GRAV>

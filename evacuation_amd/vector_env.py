@@ -188,13 +188,17 @@ class BatchedEvacuationEnv:
             infos = {"final_observation": self.final_obs, "episode_stats": self.final_stats}
         return self.obs, self.reward, self.terminated, self.truncated, infos
 
-    def rollout(self, n_steps: int, actions=None, record_actions: bool = False, out: Optional[TDict] = None):
+    def rollout(self, n_steps: int, actions=None, record_actions: bool = False, out: Optional[TDict] = None,
+                capture_envs: int = 0):
         """``n_steps`` env steps in ONE kernel launch with the state held in registers (the
         rollout loop rpo_agent.py:180-203 with given or RandomAgent actions).  The kernel writes one
         packed time-major slab ``[T,E,D+3] = [obs | reward | terminated | truncated]`` (f32); the
         returned dict holds it as ``slab`` plus zero-copy views ``obs [T,E,D]``, ``reward [T,E]``,
         ``terminated`` / ``truncated [T,E]`` (f32 0/1), and ``episode_stats [T,E,8]`` (rows valid where an
-        episode ended), ``actions [T,E,2]`` if recorded.  Pass a previous result as ``out`` to reuse it."""
+        episode ended), ``actions [T,E,2]`` if recorded.  Pass a previous result as ``out`` to reuse it.
+        ``capture_envs=K`` additionally records the trajectories of the first K envs for rendering
+        (what ``Pedestrians.save`` / ``Agent.save`` keep in the reference): ``trajectory [T,K,N+1,3]`` with
+        views ``positions [T,K,N,2]``, ``statuses [T,K,N]`` and ``agent_positions [T,K,2]``."""
         T, E, D = int(n_steps), self.num_envs, self.obs_dim
         dev = self.device
         if out is None:
@@ -202,13 +206,22 @@ class BatchedEvacuationEnv:
                    "episode_stats": torch.zeros((T, E, len(STATS_FIELDS)), dtype=torch.float32, device=dev)}
             if record_actions:
                 out["actions"] = torch.empty((T, E, 2), dtype=torch.float32, device=dev)
+            if capture_envs:
+                out["trajectory"] = torch.empty((T, int(capture_envs), self.n_ped + 1, 3), dtype=torch.float32, device=dev)
         slab = self._check_tensor(out["slab"], (T, E, D + 3), torch.float32, "slab")
         if "obs" not in out:
             out["obs"], out["reward"] = slab[..., :D], slab[..., D]
             out["terminated"], out["truncated"] = slab[..., D + 1], slab[..., D + 2]
         act = self._as_device(actions, (T, E, 2), torch.float32, "actions")
+        traj = out.get("trajectory")
+        k_cap = 0
+        if traj is not None:
+            k_cap = int(traj.shape[1])
+            self._check_tensor(traj, (T, k_cap, self.n_ped + 1, 3), torch.float32, "trajectory")
+            out["positions"], out["statuses"] = traj[:, :, :self.n_ped, 0:2], traj[:, :, :self.n_ped, 2]
+            out["agent_positions"] = traj[:, :, self.n_ped, 0:2]
         _lib.check(self.lib.evac_rollout(self._h, T, _ptr(act), _ptr(out.get("actions")), _ptr(slab),
-                                         _ptr(out.get("episode_stats")), self._stream()), self._h)
+                                         _ptr(out.get("episode_stats")), k_cap, _ptr(traj), self._stream()), self._h)
         return out
 
     def observe(self, out: Optional[torch.Tensor] = None):

@@ -150,9 +150,14 @@ int evac_step(evac_handle_t h, const float* actions, const float* noise_or_null,
  *   actions_out_or_null float [T][E][2]   records the actions actually used
  *   slab_out            float [T][E][D+3] = [obs(D) | reward | terminated (0/1) | truncated (0/1)] per env-step:
  *                       one packed record (what the trainer's rollout buffers and the all-gather consume)
- *   final_stats_or_null [T][E] (rows of envs that finished at step t) */
+ *   final_stats_or_null [T][E] (rows of envs that finished at step t)
+ *   capture_or_null     float [T][capture_envs][N+1][3]: trajectory capture for rendering (the memory that
+ *                       Pedestrians.save / Agent.save keep, pedestrians.py:33-35, area.py:32-33, consumed by
+ *                       save_animation env.py:241-324): rows 0..N-1 = (x, y, status) of every pedestrian of the
+ *                       first `capture_envs` envs after the step (before an autoreset), row N = (leader x, y, 0) */
 int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions_or_null, float* actions_out_or_null,
-                 float* slab_out, evac_episode_stats_t* final_stats_or_null, void* stream);
+                 float* slab_out, evac_episode_stats_t* final_stats_or_null, int32_t capture_envs,
+                 float* capture_or_null, void* stream);
 
 /* State exchange in the reference's own shapes (needed for parity tests, checkpoints):
  * pos/dir float [E][N][2], status uint8 [E][N], agent_pos/agent_dir float [E][2], now int32 [E]. */

@@ -522,3 +522,23 @@ def test_step_is_hipgraph_capturable(ea):
     sa, sb = a.get_state(), b.get_state()
     for k in sa:
         assert (sa[k] == sb[k]).all(), k
+
+
+def test_trajectory_capture_matches_stepwise_state(ea):
+    """the rollout's capture buffer holds what Pedestrians.save / Agent.save would
+    have stored after every step -- checked against get_state() of a twin env stepped one step at a time."""
+    import torch
+    n, E, T, K, seed = 60, 6, 12, 3, 77
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=1000)
+    wrap = ea.EnvWrappersConfig(positions="grav")
+    a = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed)
+    b = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed)
+    a.reset(); b.reset()
+    ro = a.rollout(T, record_actions=True, capture_envs=K)
+    assert ro["positions"].shape == (T, K, n, 2) and ro["statuses"].shape == (T, K, n) and ro["agent_positions"].shape == (T, K, 2)
+    for t in range(T):
+        b.step(ro["actions"][t].contiguous())
+        st = b.get_state()
+        assert (ro["positions"][t] == st["pos"][:K]).all(), t
+        assert (ro["statuses"][t] == st["status"][:K].float()).all(), t
+        assert (ro["agent_positions"][t] == st["agent_pos"][:K]).all(), t
