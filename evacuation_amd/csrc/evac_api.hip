@@ -172,18 +172,13 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
     p.one_minus_ens = (float)(1.0 - (double)cfg->enslaving_degree);   // area.py:141 computes (1. - e) in double
     p.init_reward = cfg->init_reward_each_step;
     p.intrinsic_coef = cfg->intrinsic_reward_coef;
-    p.new_exiting_reward = cfg->is_new_exiting_reward != 0;
-    p.new_followers_reward = cfg->is_new_followers_reward != 0;
-    p.term_on_wall = cfg->is_termination_agent_wall_collision != 0;
+    p.flags = (cfg->is_new_exiting_reward ? evac::kFlagNewExitingReward : 0u) |
+              (cfg->is_new_followers_reward ? evac::kFlagNewFollowersReward : 0u) |
+              (cfg->is_termination_agent_wall_collision ? evac::kFlagTermOnWall : 0u) |
+              (cfg->nan_guard ? evac::kFlagNanGuard : 0u) | (cfg->clip_action ? evac::kFlagClipAction : 0u);
     p.max_timesteps = cfg->max_timesteps;
-    // constants.py:35-38.  Squared radii are rounded from the double product.
-    p.r_leader2 = (float)(0.2 * 0.2);
-    p.r_ped2 = (float)(0.1 * 0.1);
-    p.r_ped2_big = p.r_ped2 * 0x1.0p100f;   // exact (power-of-two scale)
     p.inv_n = (float)(1.0 / (double)cfg->number_of_pedestrians);
     p.inv_200n = (float)(1.0 / (200.0 * (double)cfg->number_of_pedestrians));
-    p.r_exit = 0.4f;
-    p.r_escape = 0.01f;
     p.obs_pos = cfg->positions;
     p.obs_stat = cfg->statuses;
     p.obs_box = cfg->type == EVAC_TYPE_BOX;
@@ -193,8 +188,6 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
     p.grav_pow = cfg->alpha + 2.0f;
     const float gp = cfg->alpha + 2.0f;
     p.grav_pow_int = (gp == std::floor(gp) && gp >= 1.0f && gp <= 32.0f) ? (int)gp : 0;
-    p.nan_guard = cfg->nan_guard != 0;
-    p.clip_action = cfg->clip_action != 0;
     {
         const float half = std::fabs(cfg->noise_coef) * 0.5f;
         p.small_noise = half <= 0.2f ? 2 : (half <= 0.78539816f ? 1 : 0);

@@ -47,6 +47,13 @@ namespace evac {
 
 constexpr int kViscek = 1, kFollower = 2, kExiting = 3, kEscaped = 4;   // statuses.py:16-27
 constexpr float kExitX = 0.0f, kExitY = -1.0f;                           // area.py:39
+// constants.py:35-38 (not configurable in the reference either).  Squared radii are rounded from the double
+// product; kRPed2Big = r_ped^2 * 2^100 exactly (see neighbour_weight).
+constexpr float kRLeader2 = (float)(0.2 * 0.2), kRPed2 = (float)(0.1 * 0.1), kRExit = 0.4f, kREscape = 0.01f;
+constexpr float kRPed2Big = kRPed2 * 0x1.0p100f;
+// boolean options packed into Params::flags (one SGPR instead of seven)
+constexpr uint32_t kFlagNewExitingReward = 1u, kFlagNewFollowersReward = 2u, kFlagTermOnWall = 4u, kFlagNanGuard = 8u,
+                   kFlagClipAction = 16u;
 constexpr int kWave = 64;
 constexpr int kStageSteps = 7, kGravRow = 9;   // 7 steps x (6 obs + reward + terminated + truncated) = 63 words <= 64 lanes
 // native 16-byte vector: loads/stores of it are single ds_read_b128 / ds_write_b128 (HIP's float4 is
@@ -63,15 +70,13 @@ struct Params {
     float width, height, step_size, noise_coef, eps;
     float ens, one_minus_ens;
     float init_reward, intrinsic_coef;
-    int32_t new_exiting_reward, new_followers_reward, term_on_wall, max_timesteps;
-    float r_leader2, r_ped2, r_exit, r_escape;     // constants.py:35-38 (squared where compared squared)
-    float r_ped2_big;                               // r_ped2 * 2^100 (exact): see neighbour_weight()
+    int32_t max_timesteps;
+    uint32_t flags;                                 // kFlag*
     float inv_n, inv_200n;                          // 1/N, 1/(200 N)
     int32_t obs_pos, obs_stat, obs_box, obs_dim;
     float alpha, neg_alpha, grav_pow;               // grav_pow = alpha + 2
     int32_t grav_pow_int;                           // alpha+2 if it is an integer in [1,32], else 0
-    int32_t clip_action;
-    int32_t nan_guard, small_noise;                 // small_noise: 2 = |eta| <= 0.2 (short Taylor), 1 = |eta| <= pi/4 (long Taylor), 0 = ocml sincosf
+    int32_t small_noise;                 // small_noise: 2 = |eta| <= 0.2 (short Taylor), 1 = |eta| <= pi/4 (long Taylor), 0 = ocml sincosf
     uint32_t seed_lo, seed_hi, env_id_offset;
     // bound state
     float4* ped;
@@ -297,9 +302,9 @@ __device__ __forceinline__ int classify(const Params& p, float x, float y, float
     const float ex = x - kExitX, ey = y - kExitY;
     de = fsqrt(ex * ex + ey * ey);
     int st = kViscek;
-    if (dl2 < p.r_leader2) st = kFollower;
-    if (de < p.r_exit) st = kExiting;
-    if (de < p.r_escape) st = kEscaped;
+    if (dl2 < kRLeader2) st = kFollower;
+    if (de < kRExit) st = kExiting;
+    if (de < kREscape) st = kEscaped;
     return st;
 }
 
@@ -466,7 +471,7 @@ __device__ __forceinline__ void pair_accumulate(float xi, float yi, f4 t, float 
 // ------------------------------------------------------------------------------------------------
 // area.py:189-192: a /= |a| + eps ; agent.direction = step_size * a
 __device__ __forceinline__ float2 agent_direction(const Params& p, float act_x, float act_y) {
-    if (p.clip_action) {                                  // gym.wrappers.ClipAction (rpo_agent.py:27), wave-uniform
+    if (p.flags & kFlagClipAction) {                                  // gym.wrappers.ClipAction (rpo_agent.py:27), wave-uniform
         act_x = __builtin_amdgcn_fmed3f(act_x, -1.0f, 1.0f);
         act_y = __builtin_amdgcn_fmed3f(act_y, -1.0f, 1.0f);
     }
@@ -498,7 +503,7 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
     e.ax = hit ? e.ax : tx;                                                 // area.py:195
     e.ay = hit ? e.ay : ty;
     const float r_agent = hit ? -5.0f : 0.0f;                               // area.py:198
-    const bool term_agent = hit && p.term_on_wall != 0;
+    const bool term_agent = hit && (p.flags & kFlagTermOnWall) != 0;
 
     // ---- Area.pedestrians_step: area.py:76-180 ----
     const int old_st = q.st;
@@ -527,7 +532,7 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
     // (area.py:118-119).  nan_guard (non-reference) zeroes it instead.
     const float inrm = frsq(q.dx * q.dx + q.dy * q.dy);
     float ux = q.dx * inrm, uy = q.dy * inrm;
-    if (p.nan_guard) {          // wave-uniform
+    if (p.flags & kFlagNanGuard) {          // wave-uniform
         ux = (ux != ux) ? 0.0f : ux;
         uy = (uy != uy) ? 0.0f : uy;
     }
@@ -575,7 +580,7 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
         // back (LDS latency paid once per batch, no VALU slot), then 7 full-rate VALU ops per pair.
         const f4* __restrict__ tile = sm.tile[slot];
         const int n8 = __builtin_amdgcn_readfirstlane(any_fv ? ((n_cols + 3) & ~3) : 0);   // batches of 8 (+ a half batch); no rows -> no loop
-        const float r2b = p.r_ped2_big;
+        const float r2b = kRPed2Big;
         for (int j = 0; j < ((EVAC_ABLATE & 1) ? 0 : n8); j += 8) {
             f4 t[8];
             if (j + 8 <= n8) {
@@ -685,8 +690,8 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
 
     const float tf = 1.0f - (float)e.now * p.inv_200n;                      // reward.py:26
     float r_ped = p.init_reward;
-    if (p.new_exiting_reward && s.i[0]) r_ped += (15.0f + 10.0f * tf) * (float)s.i[0];      // uniform branches:
-    if (p.new_followers_reward && s.i[1]) r_ped += (10.0f + 5.0f * tf) * (float)s.i[1];     // usually no transition
+    if ((p.flags & kFlagNewExitingReward) && s.i[0]) r_ped += (15.0f + 10.0f * tf) * (float)s.i[0];      // uniform branches:
+    if ((p.flags & kFlagNewFollowersReward) && s.i[1]) r_ped += (10.0f + 5.0f * tf) * (float)s.i[1];     // usually no transition
     const float intrinsic = 0.0f - s.f0 * p.inv_n;                          // reward.py:19-21
     out.reward = r_agent + r_ped + p.intrinsic_coef * intrinsic;           // env.py:158
     out.terminated = term_agent || (s.i[2] == p.n_ped);                     // area.py:175-178, env.py:171
