@@ -91,6 +91,11 @@ struct Params {
 // against the Random123 known-answer vectors.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
+#ifndef EVAC_NO_KEY_BARRIER
+    // Keep the ten round keys from being hoisted out of the caller's loop as 20 live SGPRs (the step loop is
+    // already over the scalar-register budget); recomputing them is 20 s_add per call.
+    asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
