@@ -263,12 +263,11 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
     DeviceGuard g(h->device);
     if (capture && (capture_envs < 1 || capture_envs > h->p.n_envs))
         return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_rollout: capture_envs must be in [1, num_envs] when capture is given");
-    if (capture)
+    if (capture || actions_out)
         EVAC_DISPATCH(h, k_rollout_capture, stream, h->p, (int)n_steps, (const float2*)actions, (float2*)actions_out, slab_out,
                       final_stats, (int)capture_envs, capture);
     else
-        EVAC_DISPATCH(h, k_rollout, stream, h->p, (int)n_steps, (const float2*)actions, (float2*)actions_out, slab_out,
-                      final_stats);
+        EVAC_DISPATCH(h, k_rollout, stream, h->p, (int)n_steps, (const float2*)actions, slab_out, final_stats);
     return check_launch(h, "evac_rollout");
 }
 

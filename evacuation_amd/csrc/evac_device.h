@@ -888,12 +888,14 @@ __device__ __forceinline__ void rollout_body(
             }
             lane_adir = agent_direction(p, lane_act.x, lane_act.y);
         }
-        float2 a, adir;
-        a.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lane_act.x), slot64));
-        a.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lane_act.y), slot64));
+        float2 a = make_float2(0.f, 0.f), adir;
+        if constexpr (CAPTURE) {
+            a.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lane_act.x), slot64));
+            a.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lane_act.y), slot64));
+        }
         adir.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lane_adir.x), slot64));
         adir.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lane_adir.y), slot64));
-        if (actions_out && w.i == 0) actions_out[(size_t)t * E + w.env] = a;
+        if (CAPTURE && actions_out && w.i == 0) actions_out[(size_t)t * E + w.env] = a;   // diagnostic face only
         // one Philox call serves four consecutive steps of this pedestrian
         const uint32_t sel = e.total & 3u;
         if ((!have || sel == 0u) && !(EVAC_ABLATE & 4)) {
@@ -907,7 +909,7 @@ __device__ __forceinline__ void rollout_body(
         step_env<WPE, GRAV>(p, sm, w.slot, w.wave_in_env, w.lane, w.i, active, q, e, adir, nz, o EVAC_STAMP_ARGS);
         // trajectory capture for rendering (Pedestrians.save / Agent.save, pedestrians.py:33-35, area.py:32-33):
         // the post-step, pre-reset state of the first `capture_envs` envs; row N holds the leader.
-        if (CAPTURE && w.env < capture_envs) {   // wave-/workgroup-uniform; compiled out of the default kernel
+        if (CAPTURE && capture && w.env < capture_envs) {   // wave-/workgroup-uniform; compiled out of the default kernel
             float* cp = capture + (((size_t)t * capture_envs + w.env) * (p.n_ped + 1)) * 3;
             if (active) {
                 cp[3 * w.i + 0] = q.x;
@@ -969,13 +971,14 @@ __device__ __forceinline__ void rollout_body(
     store_env(p, w.env, w.i, active, q, e);
 }
 
-// The default face carries no capture code at all; the capture face is used by rollout(capture_envs=K).
+// The default face carries no capture / action-recording code at all; the diagnostic face is used by
+// rollout(capture_envs=K) and rollout(record_actions=True).
 template <int WPE, bool GRAV>
 __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_rollout(
-    Params p, int n_steps, const float2* __restrict__ actions, float2* __restrict__ actions_out,
-    float* __restrict__ slab_out, evac_episode_stats_t* __restrict__ final_stats) {
+    Params p, int n_steps, const float2* __restrict__ actions, float* __restrict__ slab_out,
+    evac_episode_stats_t* __restrict__ final_stats) {
     __shared__ Smem<WPE> sm;
-    rollout_body<WPE, GRAV, false>(sm, p, n_steps, actions, actions_out, slab_out, final_stats, 0, nullptr);
+    rollout_body<WPE, GRAV, false>(sm, p, n_steps, actions, nullptr, slab_out, final_stats, 0, nullptr);
 }
 template <int WPE, bool GRAV>
 __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_rollout_capture(
