@@ -55,6 +55,8 @@ def parse_args():
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of the outputs (N>1)")
+    ap.add_argument("--gather", default="obs", choices=["obs", "slab"],
+                    help="what the ranks all-gather per chunk: the observation batch (north_star) or the whole packed record")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
     return ap.parse_args()
@@ -140,7 +142,17 @@ def main():
                 "episode_stats": torch.zeros((T, E, 8), dtype=torch.float32, device=device)}
     bufs = [alloc(inner), alloc(inner)]
     tails = {}
-    gathered = [torch.empty((world, inner, E, D + 3), dtype=torch.float32, device=device) for _ in range(2)] if do_gather else None
+    GW = D if args.gather == "obs" else D + 3                 # gathered words per env-step
+    gathered = [torch.empty((world, inner, E, GW), dtype=torch.float32, device=device) for _ in range(2)] if do_gather else None
+    gsrc = [torch.empty((inner, E, GW), dtype=torch.float32, device=device) for _ in range(2)] if (do_gather and args.gather == "obs") else None
+
+    def gather_message(b, k):
+        """The contiguous tensor this rank contributes: the slab itself, or its observation columns copied out
+        (on the stream the caller is in -- the comm stream, off the compute stream's critical path)."""
+        if args.gather == "slab":
+            return b["slab"]
+        gsrc[k & 1].copy_(b["slab"][..., :D])
+        return gsrc[k & 1]
     comm = torch.cuda.Stream(device=device) if do_gather else None
     step_actions = torch.rand((E, 2), device=device) * 2 - 1
 
@@ -173,12 +185,15 @@ def main():
                 ready = torch.cuda.Event(); ready.record()
                 with torch.cuda.stream(comm):
                     comm.wait_event(ready)
-                    all_gather_envs(b["slab"], out=gathered[k & 1])
+                    all_gather_envs(gather_message(b, k), out=gathered[k & 1])
                     fin = torch.cuda.Event(); fin.record(comm)
                 pend[k & 1] = fin
             elif do_gather:
-                slab = pack_outputs(loc.obs, loc.reward, loc.terminated, loc.truncated) if args.mode == "step" else b["slab"]
-                all_gather_envs(slab)
+                if args.mode == "step":
+                    msg = loc.obs if args.gather == "obs" else pack_outputs(loc.obs, loc.reward, loc.terminated, loc.truncated)
+                else:
+                    msg = b["slab"][..., :D].contiguous() if args.gather == "obs" else b["slab"]
+                all_gather_envs(msg)
             done += t
             k += 1
         for p in pend:
@@ -197,7 +212,7 @@ def main():
     if do_gather:
         ok = torch.ones(1, device=device)
         try:
-            all_gather_envs(bufs[0]["slab"], out=gathered[0])
+            all_gather_envs(gather_message(bufs[0], 0), out=gathered[0])
             torch.cuda.synchronize()
         except Exception as exc:  # noqa: BLE001
             ok.zero_()
@@ -287,7 +302,7 @@ def main():
             "config": {"workload": desc, "n_pedestrians": n_ped, "envs_per_gpu": E, "total_envs": total_envs,
                        "obs": wrap_kw, "actions": "RandomAgent U(-1,1)^2 drawn on device (Philox4x32-10)",
                        "mode": args.mode, "steps_per_launch": inner, "launches": launches,
-                       "parallelism": f"env-sharded x{world}" + (", RCCL all-gather of [obs|reward|flags] per chunk" if do_gather else ""),
+                       "parallelism": f"env-sharded x{world}" + (f", RCCL all-gather of the {'observation batch' if args.gather == 'obs' else '[obs|reward|flags] records'} per {inner}-step chunk, overlapped on a side stream" if do_gather else ""),
                        "gather_note": gather_note,
                        "max_timesteps": 2000, "autoreset": True},
             "agent_updates_per_s": value * n_ped,
