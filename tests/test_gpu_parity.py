@@ -542,3 +542,43 @@ def test_trajectory_capture_matches_stepwise_state(ea):
         assert (ro["positions"][t] == st["pos"][:K]).all(), t
         assert (ro["statuses"][t] == st["status"][:K].float()).all(), t
         assert (ro["agent_positions"][t] == st["agent_pos"][:K]).all(), t
+
+
+def test_c_abi_error_codes(ea):
+    """include/evac.h conventions: negative status + message, never a crash or a silent no-op."""
+    import ctypes as C
+    import torch
+    from evacuation_amd import _lib
+    from evacuation_amd.config import to_c_config
+    lib = _lib.load()
+    c = to_c_config(ea.EnvConfig(number_of_pedestrians=60), ea.EnvWrappersConfig(positions="grav"))
+    h = C.c_void_p()
+    assert lib.evac_create(C.byref(c), 0, 0, 0, 0, C.byref(h)) == _lib.ERR_INVALID_ARGUMENT          # num_envs < 1
+    assert lib.evac_create(C.byref(c), 4, 99, 0, 0, C.byref(h)) == _lib.ERR_INVALID_ARGUMENT         # no such device
+    assert lib.evac_create(C.byref(c), 4, 0, 0, 2**32 - 2, C.byref(h)) == _lib.ERR_INVALID_ARGUMENT  # env ids overflow
+    assert lib.evac_create(C.byref(c), 4, 0, 7, 0, C.byref(h)) == 0 and h.value
+    buf = torch.zeros(4096, dtype=torch.float32, device="cuda")
+    u8 = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    p, q = C.c_void_p(buf.data_ptr()), C.c_void_p(u8.data_ptr())
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.evac_step(h, p, None, p, p, q, q, 0, None, None, s) == _lib.ERR_NOT_BOUND
+    assert b"evac_bind_state" in lib.evac_last_error(h)
+    assert lib.evac_reset(h, None, None, None, s) == _lib.ERR_NOT_BOUND
+    assert lib.evac_rollout(h, 1, None, None, p, None, 0, None, s) == _lib.ERR_NOT_BOUND
+    assert lib.evac_bind_state(h, p, q, None, p, p) == _lib.ERR_INVALID_ARGUMENT                      # NULL buffer
+    assert lib.evac_bind_state(h, C.c_void_p(buf.data_ptr() + 4), q, p, p, p) == _lib.ERR_INVALID_ARGUMENT   # alignment
+    env = ea.BatchedEvacuationEnv(ea.EnvConfig(number_of_pedestrians=60), ea.EnvWrappersConfig(positions="grav"), num_envs=4)
+    env.reset()
+    hh = env._h
+    assert lib.evac_step(hh, None, None, p, p, q, q, 0, None, None, s) == _lib.ERR_INVALID_ARGUMENT  # actions NULL
+    assert lib.evac_rollout(hh, 0, None, None, p, None, 0, None, s) == _lib.ERR_INVALID_ARGUMENT      # n_steps < 1
+    assert lib.evac_rollout(hh, 1, None, None, None, None, 0, None, s) == _lib.ERR_INVALID_ARGUMENT   # slab NULL
+    assert lib.evac_rollout(hh, 1, None, None, p, None, 9, p, s) == _lib.ERR_INVALID_ARGUMENT         # capture_envs > E
+    with pytest.raises(ValueError):
+        env.step(torch.zeros((3, 2), device="cuda"))                                                  # wrong batch size
+    with pytest.raises(_lib.EvacError):
+        _lib.check(lib.evac_observe(hh, None, s), hh)
+    assert lib.evac_status_string(-2) == b"state buffers not bound"
+    torch.cuda.synchronize()
+    lib.evac_destroy(h)
+    env.close()
