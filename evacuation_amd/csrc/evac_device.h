@@ -50,7 +50,8 @@ constexpr float kExitX = 0.0f, kExitY = -1.0f;                           // area
 // constants.py:35-38 (not configurable in the reference either).  Squared radii are rounded from the double
 // product; kRPed2Big = r_ped^2 * 2^100 exactly (see neighbour_weight).
 constexpr float kRLeader2 = (float)(0.2 * 0.2), kRPed2 = (float)(0.1 * 0.1), kRExit = 0.4f, kREscape = 0.01f;
-constexpr float kRPed2Big = kRPed2 * 0x1.0p100f;
+constexpr float kTileScale = 0x1.0p40f;                 // tile coordinates are stored times 2^40 (exact)
+constexpr float kRPed2Big = kRPed2 * 0x1.0p80f;        // r_ped^2 * 2^80, exact: the pair test in scaled units
 // boolean options packed into Params::flags (one SGPR instead of seven)
 constexpr uint32_t kFlagNewExitingReward = 1u, kFlagNewFollowersReward = 2u, kFlagTermOnWall = 4u, kFlagNanGuard = 8u,
                    kFlagClipAction = 16u;
@@ -155,14 +156,17 @@ __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x)
 __device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
-// Neighbour weight 1.0 if d2 < r2 else 0.0 in ONE full-rate instruction: (r2 - d2) * 2^100 saturated
-// to [0,1] by the VOP3 clamp modifier.  r2*2^100 and d2*2^100 are exact, so the FMA's sign is exactly
-// the sign of r2 - d2; any positive difference (>= 1 ulp of 0.01) times 2^100 saturates to exactly 1;
-// d2 == r2 gives 0 (strict <, as distances.py / area.py:107); NaN and +inf give 0 (DX10 clamp).
-// v_cmp + v_cndmask costs ~3x as much (tools/microbench/valu_rates.hip).
-__device__ __forceinline__ float neighbour_weight(float d2, float r2_big) {
+// Neighbour weight 1.0 if |p_i - p_j|^2 < r^2 else 0.0 without a compare: with coordinates pre-scaled by
+// S = 2^40 (exact), r^2 S^2 - DX^2 - DY^2 = (r^2 - d^2) * 2^80 is evaluated by two FMAs, the second saturating
+// to [0,1] through the VOP3 clamp modifier.  Any non-zero difference of two f32 numbers near 0.01 is at least
+// ~1e-9, times 2^80 it is far above 1, so the result is exactly 1 or 0; an exact tie gives 0 (strict <, as
+// distances.py / area.py:107); NaN gives 0 (DX10 clamp); padding entries carry X = +inf -> -inf -> 0.
+// Two roundings sit between the true r^2 - d^2 and its sign -- the same tie sensitivity (~1e-9 in d) as
+// computing d^2 in f32 at all.  v_cmp + v_cndmask would cost ~3 slots (tools/microbench/valu_rates.hip).
+__device__ __forceinline__ float neighbour_weight(float DX, float DY, float r2_big) {
+    const float a = fmaf(-DY, DY, r2_big);
     float w;
-    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(w) : "v"(d2), "v"(-0x1.0p100f), "v"(r2_big));
+    asm("v_fma_f32 %0, -%1, %1, %2 clamp" : "=v"(w) : "v"(DX), "v"(a));
     return w;
 }
 
@@ -461,12 +465,10 @@ __device__ __forceinline__ float2 philox_action(const Params& p, uint32_t env_gi
     return make_float2(usym(r.x), usym(r.y));
 }
 
-// One (i, j) pair of the neighbour sum: 4 ops for the squared distance, 1 saturating FMA for the 0/1
-// weight, 2 FMAs (packed by the compiler) for the heading sum.
-__device__ __forceinline__ void pair_accumulate(float xi, float yi, f4 t, float r2b, float& sx, float& sy) {
-    const float ddx = xi - t.x, ddy = yi - t.y;
-    const float d2 = fmaf(ddy, ddy, ddx * ddx);
-    const float w = neighbour_weight(d2, r2b);
+// One (i, j) pair of the neighbour sum: 2 subtractions, 2 FMAs for the 0/1 weight, 2 FMAs (packed by the
+// compiler) for the heading sum.  (XI, YI) and t.x, t.y are the 2^40-scaled coordinates.
+__device__ __forceinline__ void pair_accumulate(float XI, float YI, f4 t, float r2b, float& sx, float& sy) {
+    const float w = neighbour_weight(XI - t.x, YI - t.y, r2b);
     sx = fmaf(w, t.z, sx);
     sy = fmaf(w, t.w, sy);
 }
@@ -545,7 +547,7 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
     env_sync<WPE>();   // tile readers of the previous step are done
     // The tile holds the moving pedestrians first, compacted in ascending pedestrian order -- the columns
     // pos[efv] of the reference's distance matrix (area.py:99-106) -- then the others as padding with
-    // weight 0 (x = 3e38 -> d2 = inf) and heading 0.  Every lane writes exactly one entry.  Under a
+    // weight 0 (X = +inf) and heading 0.  Every lane writes exactly one entry.  Under a
     // RandomAgent most pedestrians have escaped by mid-episode, so the all-pairs loop shrinks from N to
     // n_efv iterations.
     int n_cols;
@@ -568,7 +570,7 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
         }
         const int tid = wave_in_env * kWave + lane;
         const int idx = efv ? before : n_cols + (tid - before);             // a bijection onto [0, WPE*64)
-        sm.tile[slot][idx] = f4{efv ? q.x : 3.0e38f, q.y, efv ? ux : 0.0f, efv ? uy : 0.0f};
+        sm.tile[slot][idx] = f4{efv ? q.x * kTileScale : __builtin_inff(), q.y * kTileScale, efv ? ux : 0.0f, efv ? uy : 0.0f};
     }
     env_sync<WPE>();   // tile complete
 
@@ -586,18 +588,19 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
         const f4* __restrict__ tile = sm.tile[slot];
         const int n8 = __builtin_amdgcn_readfirstlane(any_fv ? ((n_cols + 3) & ~3) : 0);   // batches of 8 (+ a half batch); no rows -> no loop
         const float r2b = kRPed2Big;
+        const float XI = q.x * kTileScale, YI = q.y * kTileScale;
         for (int j = 0; j < ((EVAC_ABLATE & 1) ? 0 : n8); j += 8) {
             f4 t[8];
             if (j + 8 <= n8) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) t[k] = tile[j + k];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) pair_accumulate(q.x, q.y, t[k], r2b, sx, sy);
+                for (int k = 0; k < 8; ++k) pair_accumulate(XI, YI, t[k], r2b, sx, sy);
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) pair_accumulate(q.x, q.y, t[k], r2b, sx, sy);
+                for (int k = 0; k < 4; ++k) pair_accumulate(XI, YI, t[k], r2b, sx, sy);
             }
         }
     }
