@@ -589,14 +589,20 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
         const int n8 = __builtin_amdgcn_readfirstlane(any_fv ? ((n_cols + 3) & ~3) : 0);   // batches of 8 (+ a half batch); no rows -> no loop
         const float r2b = kRPed2Big;
         const float XI = q.x * kTileScale, YI = q.y * kTileScale;
-        for (int j = 0; j < ((EVAC_ABLATE & 1) ? 0 : n8); j += 8) {
-            f4 t[8];
-            if (j + 8 <= n8) {
+        // peers per LDS round trip: 16 where registers allow (1-wave kernels: 3.31 vs 3.34 us at 8, 3.49 at 4),
+        // 8 in the multi-wave kernels, 4 in the 1024-thread one whose workgroup size caps it at 128 VGPRs
+        constexpr int B = WPE == 1 ? 16 : (WPE == 16 ? 4 : 8);
+        int j = 0;
+        if constexpr (!(EVAC_ABLATE & 1)) {
+            for (; j + B <= n8; j += B) {      // full batches
+                f4 t[B];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) t[k] = tile[j + k];
+                for (int k = 0; k < B; ++k) t[k] = tile[j + k];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) pair_accumulate(XI, YI, t[k], r2b, sx, sy);
-            } else {
+                for (int k = 0; k < B; ++k) pair_accumulate(XI, YI, t[k], r2b, sx, sy);
+            }
+            for (; j < n8; j += 4) {           // remainder in groups of 4 (n8 is a multiple of 4)
+                f4 t[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
 #pragma unroll
