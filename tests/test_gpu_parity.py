@@ -582,3 +582,52 @@ def test_c_abi_error_codes(ea):
     torch.cuda.synchronize()
     lib.evac_destroy(h)
     env.close()
+
+
+@pytest.mark.parametrize("n,E,T,wrap_kw", [
+    (256, 1024, 120, dict(positions="grav", alpha=3)),                          # BASELINE config 3
+    (1024, 32, 60, dict(positions="rel", statuses="ohe", type="Box")),          # one GPU's shard of config 5
+], ids=["c3_n256x1024_grav", "c5_n1024x32_box_ohe"])
+def test_full_size_invariants_large_envs(ea, n, E, T, wrap_kw):
+    """Size-independent properties at the BASELINE shapes that use the multi-wave kernels."""
+    import torch
+    cfg = ea.EnvConfig(number_of_pedestrians=n, is_new_exiting_reward=True, max_timesteps=50)
+    wrap = ea.EnvWrappersConfig(**wrap_kw)
+    env = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=0x5EED0003)
+    env.reset()
+    ro = env.rollout(T)
+    torch.cuda.synchronize()
+    st = env.get_state()
+    pos, dr, status = st["pos"], st["dir"], st["status"]
+    assert torch.isfinite(ro["slab"]).all() and torch.isfinite(pos).all()
+    assert (pos.abs() <= 1.0).all() and set(torch.unique(status).tolist()) <= {1, 2, 3, 4}
+    exit_xy = torch.tensor([0.0, -1.0], device=pos.device)
+    d_lead = (pos - st["agent_pos"][:, None, :]).norm(dim=-1)
+    d_exit = (pos - exit_xy).norm(dim=-1)
+    want = torch.ones_like(status)
+    want[d_lead < 0.2] = 2
+    want[d_exit < 0.4] = 3
+    want[d_exit < 0.01] = 4
+    near_tie = ((d_lead - 0.2).abs() < 1e-6) | ((d_exit - 0.4).abs() < 1e-6) | ((d_exit - 0.01).abs() < 1e-6)
+    assert ((want == status) | near_tie).all()
+    v = status == 1
+    np.testing.assert_allclose(dr[v].norm(dim=-1).cpu().numpy(), cfg.step_size, rtol=1e-5)
+    tr = ro["truncated"] != 0
+    n_trunc = T // 50                                                             # truncation every 50 steps, autoreset in between
+    assert all(tr[50 * k - 1].all() for k in range(1, n_trunc + 1)) and int(tr.sum()) == n_trunc * E
+    stats = ro["episode_stats"][49]
+    assert (stats[:, 1] == 50).all() and (stats[:, 4:8].sum(dim=1) == n).all()
+    np.testing.assert_allclose(stats[:, 0].cpu().numpy(), ro["reward"][:50].sum(dim=0).cpu().numpy(), rtol=1e-4)
+    obs = env.split_observation(ro["obs"][-1])                                   # last step's observation
+    if wrap.type == "Box":
+        assert obs.shape == (E, n + 2, 6)
+        np.testing.assert_array_equal(obs[:, 0, 2:].cpu().numpy(), 0)            # agent row: status 0000
+        np.testing.assert_array_equal(obs[:, 1, 2:].cpu().numpy(), np.tile([1, 0, 0, 0], (E, 1)))   # exit row
+        assert (obs[:, 2:, 2:].sum(dim=-1) == 1).all()                           # one-hot rows
+        code = obs[:, 2:, 2:].argmax(dim=-1)                                     # wrappers.py:49: 4 - Status.value
+        assert ((4 - code) == status.long()).all()
+        rel = (pos - st["agent_pos"][:, None, :]) * 0.70710678
+        np.testing.assert_allclose(obs[:, 2:, 0:2].cpu().numpy(), rel.cpu().numpy(), atol=1e-6)
+    else:
+        np.testing.assert_array_equal(obs["agent_position"].cpu().numpy(), st["agent_pos"].cpu().numpy())
+    env.close()
