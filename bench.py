@@ -58,48 +58,49 @@ def parse_args():
     ap.add_argument("--gather", default="obs", choices=["obs", "slab"],
                     help="what the ranks all-gather per chunk: the observation batch (north_star) or the whole packed record")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-procs", type=int, default=-1,
+                    help="worker processes for the many-core CPU figure (-1: min(32, cores); 0/1: skip)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
     return ap.parse_args()
 
 
-def cpu_baseline(n_ped: int, seconds: float):
+def cpu_baseline(n_ped: int, seconds: float, procs: int):
     """The NumPy oracle (a port of the reference's EvacuationEnv.step + GravityEncoding) stepped in a
-    single-env RandomAgent loop on one host core, as the reference's README loop does."""
-    import numpy as np
-    from oracle import evac_oracle as O
+    single-env RandomAgent loop on one host core, as the reference's README loop does; plus, as
+    `many_core`, the same loop in `procs` independent worker processes."""
+    from oracle import cpu_bench
 
-    p = O.OracleParams(number_of_pedestrians=n_ped, is_new_exiting_reward=True)
-    rng = np.random.default_rng(0)
-    st = O.env_reset(p, rng.uniform(-1, 1, (n_ped, 2)), rng.uniform(-1, 1, (n_ped, 2)))
-    for _ in range(50):
-        O.env_step(p, st, rng.uniform(-1, 1, 2).astype(np.float32), rng.uniform(-0.1, 0.1, n_ped))
-    n = 0
-    t0 = time.perf_counter()
-    while True:
-        for _ in range(200):
-            a = rng.uniform(-1, 1, 2).astype(np.float32)
-            out = O.env_step(p, st, a, O.draw_step_noise(p, st, rng))
-            O.observe(st, "grav", alpha=3, eps=p.eps)
-            if out["terminated"] or out["truncated"]:
-                st = O.env_reset(p, rng.uniform(-1, 1, (n_ped, 2)), rng.uniform(-1, 1, (n_ped, 2)))
-        n += 200
-        dt = time.perf_counter() - t0
-        if dt >= seconds:
-            break
-    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n} single-env steps (n={n_ped}, gravity obs, RandomAgent loop) of the NumPy oracle in {dt:.1f} s "
-                      f"on 1 of {os.cpu_count()} host cores",
-            "agent_updates_per_s": n * n_ped / dt}
+    n, dt = cpu_bench.readme_loop(n_ped, seconds)
+    out = {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+           "sample": f"{n} single-env steps (n={n_ped}, gravity obs, RandomAgent loop) of the NumPy oracle in {dt:.1f} s "
+                     f"on 1 of {os.cpu_count()} host cores",
+           "agent_updates_per_s": n * n_ped / dt}
+    if procs > 1:
+        try:
+            steps, busy, wall = cpu_bench.many_core(n_ped, min(seconds, 6.0), procs)
+            out["many_core"] = {"value": steps / busy, "unit": "env-steps/s", "cores": procs,
+                                "sample": f"{steps} steps by {procs} independent single-env worker processes, {busy:.1f} s each "
+                                          f"(wall {wall:.1f} s incl. process start-up) of {os.cpu_count()} host cores"}
+        except Exception as exc:  # noqa: BLE001
+            out["many_core"] = {"error": f"{type(exc).__name__}: {exc}"[:160]}
+    return out
 
 
 def main():
     args = parse_args()
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # CPU baseline first (rank 0, N=1 only): its worker processes are spawned before this process has
+    # touched the GPU, and the GPU measurement below runs on an otherwise idle host.
+    cpu_base = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        procs = min(32, os.cpu_count() or 1) if args.cpu_procs < 0 else args.cpu_procs
+        cpu_base = cpu_baseline(WORKLOADS[args.workload][0], args.cpu_seconds, procs)
+
+    import torch
+    import torch.distributed as dist
+
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -315,10 +316,7 @@ def main():
                          "note": "all-pairs O(N^2) work makes this kernel VALU-bound; valu_frac uses the 10*N^2+40*N lane-op model"},
             "step_api": step_api,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n_ped, args.cpu_seconds)
-        else:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)
     env.close()
     if world > 1:
