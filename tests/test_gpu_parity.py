@@ -631,3 +631,72 @@ def test_full_size_invariants_large_envs(ea, n, E, T, wrap_kw):
     else:
         np.testing.assert_array_equal(obs["agent_position"].cpu().numpy(), st["agent_pos"].cpu().numpy())
     env.close()
+
+
+def test_masked_reset_touches_only_selected_envs(ea):
+    import torch
+    n, E, seed = 60, 8, 5
+    env = ea.BatchedEvacuationEnv(ea.EnvConfig(number_of_pedestrians=n), ea.EnvWrappersConfig(positions="grav"), num_envs=E,
+                                  seed=seed, autoreset=False)
+    env.reset()
+    act = torch.rand((E, 2), device=env.device) * 2 - 1
+    for _ in range(5):
+        env.step(act)
+    before = {k: v.clone() for k, v in env.get_state().items()}
+    obs_before = env.obs.clone()
+    mask = torch.tensor([0, 1, 0, 0, 1, 0, 0, 1], dtype=torch.uint8, device=env.device)
+    obs, _ = env.reset(mask=mask)
+    after = env.get_state()
+    m = mask.bool()
+    for k in before:
+        assert (after[k][~m] == before[k][~m]).all(), k                          # untouched envs
+    assert (after["now"][m] == 0).all() and (after["agent_pos"][m] == 0).all()
+    np.testing.assert_array_equal(after["pos"][m].cpu().numpy(), P.reset_draws(seed, np.nonzero(m.cpu().numpy())[0], n, 1)[..., 0:2])
+    assert (obs[~m] == obs_before[~m]).all()                                      # only rows of reset envs are rewritten
+    assert (env.clock[:, 1].cpu() == torch.tensor([1, 2, 1, 1, 2, 1, 1, 2])).all()
+    env.close()
+
+
+def test_wrap_env_selects_the_observation_epilogue(ea):
+    """EnvWrappersConfig.wrap_env(env) (wrappers/config.py:46-93) on the single-env facade."""
+    cfg = ea.EnvConfig(number_of_pedestrians=12)
+    env = ea.EvacuationEnv(cfg)
+    o, _ = env.reset()
+    assert set(o) == {"agent_position", "exit_position", "pedestrians_positions"}
+    assert ea.EnvWrappersConfig().wrap_env(env) is env                            # abs / no / Dict: no wrapper
+    g = ea.EnvWrappersConfig(positions="grav", alpha=2).wrap_env(env)
+    o, _ = g.reset()
+    assert set(o) == {"agent_position", "grad_potential_exit", "grad_potential_pedestrians"}
+    assert list(g.observation_space.keys()) == sorted(g.observation_space.keys())
+    b = ea.EnvWrappersConfig(positions="rel", statuses="cat", type="Box").wrap_env(g)
+    o, _ = b.reset()
+    assert o.shape == (14, 3) and b.observation_space.shape == (14, 3) and b.unwrapped is b
+    with pytest.raises(NotImplementedError):
+        ea.EnvWrappersConfig(positions="grav", type="Box").wrap_env(b)
+    b.close()
+
+
+def test_long_rollouts_cross_the_64_step_action_blocks(ea):
+    """Actions are staged 64 steps at a time, one per lane: check T > 64 for given and for Philox actions."""
+    import torch
+    n, E, T, seed = 33, 5, 150, 0xABCDEF
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=70)
+    wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
+    a = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed)
+    b = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed)
+    c = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed)
+    for e in (a, b, c):
+        e.reset()
+    ro = a.rollout(T, record_actions=True)                                        # Philox actions
+    acts = ro["actions"]
+    for t in (0, 63, 64, 65, 127, 128, 149):
+        np.testing.assert_array_equal(acts[t].cpu().numpy(), P.random_action(seed, np.arange(E), t))
+    rb = b.rollout(T, actions=acts)                                               # the same actions, provided
+    assert (rb["slab"] == ro["slab"]).all()
+    for t in range(T):                                                            # and one step at a time
+        o, r, te, tr, _ = c.step(acts[t].contiguous())
+        assert (o == ro["obs"][t]).all() and (r == ro["reward"][t]).all(), t
+        assert (te == ro["terminated"][t]).all() and (tr == ro["truncated"][t]).all(), t
+    assert int((ro["truncated"] != 0).sum()) == 2 * E
+    for e in (a, b, c):
+        e.close()
