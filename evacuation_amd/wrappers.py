@@ -40,11 +40,12 @@ class NormalizedVectorEnv:
         cfg = dataclasses.replace(env_config, clip_action=True)
         return cls(BatchedEvacuationEnv(cfg, wrap_config, num_envs=num_envs, autoreset=True, **kw), gamma=gamma)
 
-    def reset(self, seed=None, options=None, **kw):
-        obs, info = self.env.reset(seed=seed, options=options, **kw)
-        _lib.check(self.lib.evac_norm_reset(self.env._h, _ptr(kw.get("mask")) if isinstance(kw.get("mask"), torch.Tensor) else None,
-                                            _ptr(obs), _ptr(self.norm_state), self.obs_clip, self.epsilon,
-                                            self.env._stream()), self.env._h)
+    def reset(self, seed=None, options=None, *, mask=None, draws=None):
+        """Wrapped reset: NormalizeObservation also normalises (and counts) the reset observation."""
+        mask_t = self.env._as_device(mask, (self.num_envs,), torch.uint8, "mask")
+        obs, info = self.env.reset(seed=seed, options=options, mask=mask_t, draws=draws)
+        _lib.check(self.lib.evac_norm_reset(self.env._h, _ptr(mask_t), _ptr(obs), _ptr(self.norm_state), self.obs_clip,
+                                            self.epsilon, self.env._stream()), self.env._h)
         return obs, info
 
     def step(self, actions, noise=None):

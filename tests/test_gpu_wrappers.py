@@ -69,3 +69,16 @@ def test_clip_action_changes_only_out_of_range_actions():
     want = np.array([1.0, 0.5]) / np.linalg.norm([1.0, 0.5]) * 0.01          # (3, .5) clipped to (1, .5)
     np.testing.assert_allclose(sb["agent_dir"][1].cpu().numpy(), want, rtol=1e-6)
     assert not torch.allclose(sa["agent_dir"][1], sb["agent_dir"][1])
+
+
+def test_normalized_masked_reset_counts_only_reset_envs():
+    import torch
+    import evacuation_amd as ea
+    env = ea.NormalizedVectorEnv.make(ea.EnvConfig(number_of_pedestrians=10), ea.EnvWrappersConfig(positions="grav"), num_envs=4)
+    env.reset()
+    D = env.obs_dim
+    c0 = env.norm_state[:, 2 * D].clone()
+    env.reset(mask=np.array([1, 0, 0, 1], dtype=np.uint8))
+    c1 = env.norm_state[:, 2 * D]
+    assert torch.allclose(c1 - c0, torch.tensor([1.0, 0.0, 0.0, 1.0], dtype=torch.float64, device=c1.device))
+    env.close()
