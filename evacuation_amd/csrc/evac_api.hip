@@ -5,11 +5,13 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
 
 #include "evac_device.h"
+#include "evac_subwave.h"
 
 namespace {
 
@@ -59,6 +61,7 @@ struct evac_handle {
     evac::Params p;
     int device;
     bool bound;
+    int sub_lanes;      // 0: one wave (or more) per env; 16 / 32: sub-wave kernels (evac_subwave.h)
     std::string err;
 };
 
@@ -85,14 +88,24 @@ dim3 grid_for(int n_envs) {
 
 #define EVAC_LAUNCH(h, KERNEL, WPE_, GRAV_, s_, ...) \
     hipLaunchKernelGGL((evac::KERNEL<WPE_, GRAV_>), grid_for<WPE_>((h)->p.n_envs), dim3(evac::Geometry<WPE_>::kBlock), 0, s_, __VA_ARGS__)
+#define EVAC_LAUNCH_SUB(h, KERNEL, G_, GRAV_, s_, ...)                                                              \
+    hipLaunchKernelGGL((evac::KERNEL##_sub<G_, GRAV_>),                                                             \
+                       dim3((unsigned)(((h)->p.n_envs + evac::SubGeo<G_>::kEnvsPerBlock - 1) / evac::SubGeo<G_>::kEnvsPerBlock)), \
+                       dim3(evac::SubGeo<G_>::kBlock), 0, s_, __VA_ARGS__)
 
-// kernel variant = (waves per env) x (gravity observation | generic positions/statuses observation)
+// kernel variant = (lanes or waves per env) x (gravity observation | generic positions/statuses observation)
 #define EVAC_DISPATCH(h, KERNEL, stream, ...)                                         \
     do {                                                                              \
         const int wpe_ = waves_per_env((h)->p.n_ped);                                 \
         const bool grav_ = (h)->p.obs_pos == EVAC_POS_GRAV;                           \
         hipStream_t s_ = (hipStream_t)(stream);                                       \
-        if (grav_) {                                                                  \
+        if ((h)->sub_lanes == 16) {                                                   \
+            if (grav_) EVAC_LAUNCH_SUB(h, KERNEL, 16, true, s_, __VA_ARGS__);         \
+            else EVAC_LAUNCH_SUB(h, KERNEL, 16, false, s_, __VA_ARGS__);              \
+        } else if ((h)->sub_lanes == 32) {                                            \
+            if (grav_) EVAC_LAUNCH_SUB(h, KERNEL, 32, true, s_, __VA_ARGS__);         \
+            else EVAC_LAUNCH_SUB(h, KERNEL, 32, false, s_, __VA_ARGS__);              \
+        } else if (grav_) {                                                           \
             if (wpe_ == 1) EVAC_LAUNCH(h, KERNEL, 1, true, s_, __VA_ARGS__);          \
             else if (wpe_ == 4) EVAC_LAUNCH(h, KERNEL, 4, true, s_, __VA_ARGS__);     \
             else if (wpe_ == 8) EVAC_LAUNCH(h, KERNEL, 8, true, s_, __VA_ARGS__);     \
@@ -159,6 +172,12 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
     h->cfg = *cfg;
     h->device = device;
     h->bound = false;
+    {   // small rooms share a wave: 4 envs per wave for N <= 16, 2 for N <= 32 (EVAC_SUBWAVE=0 disables, for A/B tests)
+        const char* sw = std::getenv("EVAC_SUBWAVE");
+        const bool allow = !(sw && sw[0] == '0');
+        const int n = cfg->number_of_pedestrians;
+        h->sub_lanes = !allow ? 0 : (n <= 16 ? 16 : (n <= 32 ? 32 : 0));
+    }
     evac::Params& p = h->p;
     std::memset(&p, 0, sizeof(p));
     p.n_envs = num_envs;

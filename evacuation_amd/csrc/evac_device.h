@@ -335,40 +335,10 @@ __device__ __forceinline__ void grav_term(const Params& p, float rx, float ry, f
     grav_term2(p, rx, ry, rx * rx + ry * ry, gx, gy);
 }
 
-// Gravity observation of the CURRENT state by a full reduction: used by reset / observe and after an
-// in-kernel autoreset (the per-step path gets the same numbers fused into step_env's reduction).
-// o6 = [agent(2), grad_potential_exit(2), grad_potential_pedestrians(2)], wave-uniform.
-template <int WPE>
-__device__ __forceinline__ void grav_observation(const Params& p, Smem<WPE>& sm, int slot, int wave_in_env, int lane,
-                                                 bool active, const Ped& q, const Env& e, float (&o6)[6]) {
-    Sums s{};
-    float gx = 0.0f, gy = 0.0f;
-    const bool visc = active && q.st == kViscek;
-    grav_term(p, e.ax - q.x, e.ay - q.y, gx, gy);                   // gravity_encoding.py:8-25
-    s.f0 = visc ? gx : 0.0f;
-    s.f1 = visc ? gy : 0.0f;
-    s.f2 = 0.0f;
-    const bool pred[8] = {active && q.st == kFollower, false, false, false, false, false, false, false};
-    env_reduce<WPE>(sm, slot, wave_in_env, lane, s, pred);
-    float ex, ey;
-    grav_term(p, e.ax - kExitX, e.ay - kExitY, ex, ey);              // gravity_encoding.py:28-38
-    const float nf = (float)s.i[0];
-    o6[0] = e.ax; o6[1] = e.ay; o6[2] = ex * nf; o6[3] = ey * nf; o6[4] = s.f0; o6[5] = s.f1;
-}
-
-template <int WPE, bool GRAV>
-__device__ __forceinline__ void write_obs(const Params& p, Smem<WPE>& sm, int slot, int wave_in_env, int lane,
-                                          int i, bool active, const Ped& q, const Env& e, float* __restrict__ obs) {
-    if constexpr (GRAV) {
-        float o6[6];
-        grav_observation<WPE>(p, sm, slot, wave_in_env, lane, active, q, e, o6);
-        if (i == 0) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) obs[k] = o6[k];
-        }
-        return;
-    }
-    if constexpr (GRAV) return;   // (unreachable; keeps the generic epilogue out of the gravity kernels)
+// Positions / statuses observations (abs | rel) x (no | ohe | cat) x (Dict | Box): env.py:98-104, wrappers.py:8-96.
+// Purely per-lane writes (lane i owns pedestrian row i; lane 0 also writes the agent and exit rows).
+__device__ __forceinline__ void write_obs_generic(const Params& p, int i, bool active, const Ped& q, const Env& e,
+                                                  float* __restrict__ obs) {
     const bool rel = p.obs_pos == EVAC_POS_REL;
     const float ihyp = 0.70710678118f;                                // wrappers.py:12-18: 1/sqrt(1+1)
     float px = q.x, py = q.y, ex = kExitX, ey = kExitY;
@@ -431,6 +401,42 @@ __device__ __forceinline__ void write_obs(const Params& p, Smem<WPE>& sm, int sl
             st[i] = (float)code * 0.25f;
         }
     }
+}
+
+// Gravity observation of the CURRENT state by a full reduction: used by reset / observe and after an
+// in-kernel autoreset (the per-step path gets the same numbers fused into step_env's reduction).
+// o6 = [agent(2), grad_potential_exit(2), grad_potential_pedestrians(2)], wave-uniform.
+template <int WPE>
+__device__ __forceinline__ void grav_observation(const Params& p, Smem<WPE>& sm, int slot, int wave_in_env, int lane,
+                                                 bool active, const Ped& q, const Env& e, float (&o6)[6]) {
+    Sums s{};
+    float gx = 0.0f, gy = 0.0f;
+    const bool visc = active && q.st == kViscek;
+    grav_term(p, e.ax - q.x, e.ay - q.y, gx, gy);                   // gravity_encoding.py:8-25
+    s.f0 = visc ? gx : 0.0f;
+    s.f1 = visc ? gy : 0.0f;
+    s.f2 = 0.0f;
+    const bool pred[8] = {active && q.st == kFollower, false, false, false, false, false, false, false};
+    env_reduce<WPE>(sm, slot, wave_in_env, lane, s, pred);
+    float ex, ey;
+    grav_term(p, e.ax - kExitX, e.ay - kExitY, ex, ey);              // gravity_encoding.py:28-38
+    const float nf = (float)s.i[0];
+    o6[0] = e.ax; o6[1] = e.ay; o6[2] = ex * nf; o6[3] = ey * nf; o6[4] = s.f0; o6[5] = s.f1;
+}
+
+template <int WPE, bool GRAV>
+__device__ __forceinline__ void write_obs(const Params& p, Smem<WPE>& sm, int slot, int wave_in_env, int lane,
+                                          int i, bool active, const Ped& q, const Env& e, float* __restrict__ obs) {
+    if constexpr (GRAV) {
+        float o6[6];
+        grav_observation<WPE>(p, sm, slot, wave_in_env, lane, active, q, e, o6);
+        if (i == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) obs[k] = o6[k];
+        }
+        return;
+    }
+    write_obs_generic(p, i, active, q, e, obs);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -700,3 +700,49 @@ def test_long_rollouts_cross_the_64_step_action_blocks(ea):
     assert int((ro["truncated"] != 0).sum()) == 2 * E
     for e in (a, b, c):
         e.close()
+
+
+@pytest.mark.parametrize("n", [3, 10, 16, 17, 31, 32])
+@pytest.mark.parametrize("wrap_kw", [dict(positions="grav", alpha=3), dict(positions="rel", statuses="ohe", type="Box")],
+                         ids=["grav", "box"])
+def test_subwave_kernels_match_one_wave_per_env(ea, n, wrap_kw):
+    """N <= 32 runs 2 (N <= 16: 4) envs per wave (csrc/evac_subwave.h).  Same arithmetic as the one-wave-per-env
+    kernels; only the reduction trees differ, so the dynamics (positions, directions, statuses, flags) must be
+    bit-identical and the summed quantities (reward with intrinsic term, gravity sums) equal to f32 rounding."""
+    import torch
+    E, T, seed = 11, 90, 2024                       # E not a multiple of the envs per wave / block
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=40, is_new_exiting_reward=True, intrinsic_reward_coef=0.5)
+    wrap = ea.EnvWrappersConfig(**wrap_kw)
+    old = os.environ.get("EVAC_SUBWAVE")
+    try:
+        os.environ["EVAC_SUBWAVE"] = "1"
+        a = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed)
+        os.environ["EVAC_SUBWAVE"] = "0"
+        b = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed)
+    finally:
+        if old is None:
+            os.environ.pop("EVAC_SUBWAVE", None)
+        else:
+            os.environ["EVAC_SUBWAVE"] = old
+    oa, _ = a.reset(); ob, _ = b.reset()
+    torch.testing.assert_close(oa, ob, rtol=2e-6, atol=1e-6)
+    ra = a.rollout(T, record_actions=True, capture_envs=E)
+    rb = b.rollout(T, record_actions=True, capture_envs=E)
+    assert (ra["actions"] == rb["actions"]).all()
+    assert (ra["trajectory"] == rb["trajectory"]).all()                      # positions + statuses, every step
+    assert (ra["terminated"] == rb["terminated"]).all() and (ra["truncated"] == rb["truncated"]).all()
+    torch.testing.assert_close(ra["reward"], rb["reward"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(ra["obs"], rb["obs"], rtol=2e-5, atol=1e-4 if wrap.positions == "grav" else 1e-6)
+    torch.testing.assert_close(ra["episode_stats"], rb["episode_stats"], rtol=1e-5, atol=1e-4)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert (sa[k] == sb[k]).all(), k
+    act = ra["actions"][0].contiguous()                                       # and the per-step kernel
+    o1, r1, t1, u1, i1 = a.step(act)
+    o2, r2, t2, u2, i2 = b.step(act)
+    assert (t1 == t2).all() and (u1 == u2).all()
+    torch.testing.assert_close(r1, r2, rtol=1e-5, atol=1e-5)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert (sa[k] == sb[k]).all(), k
+    a.close(); b.close()
