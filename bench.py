@@ -111,10 +111,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("EVAC_BENCH_BACKEND", "nccl")                 # "nccl" IS RCCL on ROCm; gloo = testing aid
+        import datetime
+        limit = datetime.timedelta(seconds=300)       # a stuck collective must surface as an error, not hang the run
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=limit)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
 
     import evacuation_amd as ea
     from evacuation_amd.distributed import ShardedEvacuationEnv
