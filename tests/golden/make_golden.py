@@ -315,6 +315,12 @@ def main():
     make_trajectory(ref, "traj_n256_s6_noise05", 6, 24, obs_every=4, number_of_pedestrians=256, noise_coef=0.5,
                     enslaving_degree=0.5)
     make_trajectory(ref, "traj_n1024_s7", 7, 3, obs_every=3, number_of_pedestrians=1024, is_new_exiting_reward=True)
+    make_trajectory(ref, "traj_n1024_s8_noise05_ens05", 8, 2, obs_every=2, number_of_pedestrians=1024, noise_coef=0.5,
+                    enslaving_degree=0.5, intrinsic_reward_coef=1.0)
+    make_trajectory(ref, "traj_n256_s9_ens01_step05", 9, 20, obs_every=10, number_of_pedestrians=256, enslaving_degree=0.1,
+                    step_size=0.05, is_new_exiting_reward=True, intrinsic_reward_coef=1.0)
+    make_trajectory(ref, "traj_n256_s10_noreward", 10, 20, obs_every=10, number_of_pedestrians=256,
+                    is_new_followers_reward=False, init_reward_each_step=0.0, noise_coef=0.05)
     make_crafted(ref)
 
 
