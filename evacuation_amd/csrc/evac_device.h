@@ -537,9 +537,10 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
         q.dx = exi ? vx * k : q.dx;
         q.dy = exi ? vy * k : q.dy;
     }
-    const bool efv = active && !esc && q.st != 0;                           // area.py:99  (E | F | V)
-    const bool fv = active && (q.st == kFollower || q.st == kViscek);       // area.py:104
-    const bool fol = active && q.st == kFollower;
+    // lanes beyond n_ped carry status 0, so status tests need no `active &&` (saves mask algebra on the SALU)
+    const bool efv = (unsigned)(q.st - kViscek) < 3u;                       // area.py:99  (V | F | E) = codes 1..3
+    const bool fv = (unsigned)(q.st - kViscek) < 2u;                        // area.py:104 (V | F) = codes 1..2
+    const bool fol = q.st == kFollower;
 
     // unit headings of the moving pedestrians: area.py:100-101.  0 * rsq(0) = 0 * inf = NaN, as 0/0.
     // A NaN heading is written to the tile as it is: w * NaN = NaN even for w = 0, so it poisons every

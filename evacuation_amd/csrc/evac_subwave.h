@@ -119,9 +119,9 @@ __device__ __forceinline__ void step_env_sub(const Params& p, SmemSub<G>& sm, co
         q.dx = exi ? vx * k : q.dx;
         q.dy = exi ? vy * k : q.dy;
     }
-    const bool efv = active && !esc && q.st != 0;
-    const bool fv = active && (q.st == kFollower || q.st == kViscek);
-    const bool fol = active && q.st == kFollower;
+    const bool efv = (unsigned)(q.st - kViscek) < 3u;       // V | F | E; lanes beyond n_ped carry status 0
+    const bool fv = (unsigned)(q.st - kViscek) < 2u;        // V | F
+    const bool fol = q.st == kFollower;
 
     const float inrm = frsq(q.dx * q.dx + q.dy * q.dy);
     float ux = q.dx * inrm, uy = q.dy * inrm;
