@@ -15,6 +15,11 @@
  *  - one handle per (device, set of state buffers); a handle is not thread-safe, distinct
  *    handles are independent.
  *
+ * Environment switches (diagnostics only): EVAC_SUBWAVE=0 read by evac_create() selects the one-wave-per-env
+ * kernels also for N <= 32 (default: 4 envs per wave for N <= 16, 2 for N <= 32; same results, see
+ * tests/test_gpu_parity.py::test_subwave_kernels_match_one_wave_per_env); the Python host honours
+ * EVAC_LIB=<path> to load a profiling build of this library instead of evacuation_amd/libevac.so.
+ *
  * Device layouts (row-major, E = num_envs, N = n_ped)
  *    ped    float [E][N][4]   (x, y, dir_x, dir_y)      pedestrians.py:17-19
  *    status uint8 [E][N]      1 VISCEK 2 FOLLOWER 3 EXITING 4 ESCAPED   statuses.py:16-27
