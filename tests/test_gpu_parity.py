@@ -746,3 +746,25 @@ def test_subwave_kernels_match_one_wave_per_env(ea, n, wrap_kw):
     for k in sa:
         assert (sa[k] == sb[k]).all(), k
     a.close(); b.close()
+
+
+def test_sharded_env_single_process_path(ea):
+    """ShardedEvacuationEnv without a process group = one shard holding every env; the gathered slab is the
+    packed [obs | reward | terminated | truncated] record in global env order."""
+    import torch
+    from evacuation_amd.distributed import ShardedEvacuationEnv, unpack_outputs
+    cfg = ea.EnvConfig(number_of_pedestrians=40, max_timesteps=6)
+    sh = ShardedEvacuationEnv(cfg, ea.EnvWrappersConfig(positions="grav"), total_envs=12, device="cuda:0", seed=3)
+    ref = ea.BatchedEvacuationEnv(cfg, ea.EnvWrappersConfig(positions="grav"), num_envs=12, seed=3)
+    assert (sh.rank, sh.world_size, sh.offset, sh.local_envs) == (0, 1, 0, 12)
+    sh.reset(); ref.reset()
+    act = torch.rand((12, 2), device="cuda") * 2 - 1
+    obs, rew, te, tr, info, slab = sh.step(act)
+    o2, r2, t2, u2, _ = ref.step(act)
+    o, r, t, u = unpack_outputs(slab)
+    assert (o == o2).all() and (r == r2).all() and (t == t2.bool()).all() and (u == u2.bool()).all()
+    ro, pending = sh.rollout_gathered(10)
+    full = sh.wait(pending)
+    rr = ref.rollout(10)
+    assert full.shape == (10, 12, 9) and (full == rr["slab"]).all() and (ro["slab"] == rr["slab"]).all()
+    sh.close(); ref.close()
