@@ -9,7 +9,6 @@ statistics per env, updated by a small epilogue kernel (``evac_norm_step``) on t
 observations never leave the GPU."""
 from __future__ import annotations
 
-import ctypes as C
 import dataclasses
 
 import torch

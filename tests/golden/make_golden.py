@@ -14,7 +14,6 @@ Fixture kinds
 """
 from __future__ import annotations
 
-import dataclasses
 import json
 import os
 import sys
