@@ -1,18 +1,19 @@
 // Device code of libevac: the fused evacuation-env step for gfx950 (CDNA4, wave64).
 //
-// One env is owned by WPE waves (WPE = 1 for N <= 64, else 4/8/16 = one workgroup); lane i owns
-// pedestrian i in registers.  The only O(N^2) part -- the Vicsek neighbour average, area.py:104-119
-// of the reference -- reads the peers' (x, y, unit heading) from an LDS tile with wave-uniform
-// (broadcast) ds_read_b128.  Everything else is O(N) per-lane work plus wave reductions
-// (__ballot/__popcll for the status-transition counts, shuffle trees for the float sums).
+// One env is owned by WPE waves (WPE = 1 for 33 <= N <= 64, else 4/8/16 = one workgroup; N <= 32 shares a wave
+// between envs, see evac_subwave.h); lane i owns pedestrian i in registers.  The only O(N^2) part -- the
+// Vicsek neighbour average, area.py:104-119 of the reference -- reads the moving peers' (x, y, unit heading)
+// from a compacted LDS tile with wave-uniform (broadcast) ds_read_b128.  Everything else is O(N) per-lane
+// work plus wave reductions (v_cmp ballots + s_bcnt1 for the counts, DPP trees for the float sums).
 // No MFMA: there is no dense contraction here (output width 2).
 //
-// Built with -ffp-contract=off: every fused multiply-add is written explicitly, so the f32
-// arithmetic is the same sequence of IEEE operations as the NumPy f32 oracle wherever the two
-// use the same formula.
+// Built with -ffp-contract=off: every fused multiply-add is written explicitly (fmaf), so what is fused is
+// a decision of this file, not of the compiler.  Divisions and square roots use the 1-ulp hardware
+// v_rcp / v_rsq / v_sqrt (see frcp / frsq / fsqrt); the parity bar is 1e-5 absolute.
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/evac.h"
@@ -48,7 +49,7 @@ namespace evac {
 constexpr int kViscek = 1, kFollower = 2, kExiting = 3, kEscaped = 4;   // statuses.py:16-27
 constexpr float kExitX = 0.0f, kExitY = -1.0f;                           // area.py:39
 // constants.py:35-38 (not configurable in the reference either).  Squared radii are rounded from the double
-// product; kRPed2Big = r_ped^2 * 2^100 exactly (see neighbour_weight).
+// product.
 constexpr float kRLeader2 = (float)(0.2 * 0.2), kRPed2 = (float)(0.1 * 0.1), kRExit = 0.4f, kREscape = 0.01f;
 constexpr float kTileScale = 0x1.0p40f;                 // tile coordinates are stored times 2^40 (exact)
 constexpr float kRPed2Big = kRPed2 * 0x1.0p80f;        // r_ped^2 * 2^80, exact: the pair test in scaled units
@@ -77,7 +78,7 @@ struct Params {
     int32_t obs_pos, obs_stat, obs_box, obs_dim;
     float alpha, neg_alpha, grav_pow;               // grav_pow = alpha + 2
     int32_t grav_pow_int;                           // alpha+2 if it is an integer in [1,32], else 0
-    int32_t small_noise;                 // small_noise: 2 = |eta| <= 0.2 (short Taylor), 1 = |eta| <= pi/4 (long Taylor), 0 = ocml sincosf
+    int32_t small_noise;                            // sin/cos regime: 2 short Taylor, 1 long Taylor, 0 ocml sincosf (noise_sincos)
     uint32_t seed_lo, seed_hi, env_id_offset;
     // bound state
     float4* ped;
@@ -122,18 +123,9 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_add(float v) {
     return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
 }
-// Sum over the 64 lanes, result wave-uniform (an SGPR).  row_shr 1/2/4/8 leave each row's total in
-// its lane 15; row_bcast:15 / row_bcast:31 fold the rows into lane 63 (the rocPRIM gfx9 scheme).
-// ~2.5x cheaper than six ds_bpermute butterflies (tools/microbench/valu_rates.hip).
-__device__ __forceinline__ float wave_sum(float v) {
-    v = dpp_add<0x111, 0xf>(v);
-    v = dpp_add<0x112, 0xf>(v);
-    v = dpp_add<0x114, 0xf>(v);
-    v = dpp_add<0x118, 0xf>(v);
-    v = dpp_add<0x142, 0xa>(v);
-    v = dpp_add<0x143, 0xc>(v);
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
+// Sums over the 64 lanes, results wave-uniform (SGPRs).  row_shr 1/2/4/8 leave each row's total in its lane 15;
+// row_bcast:15 / row_bcast:31 fold the rows into lane 63 (the rocPRIM gfx9 scheme), ~2.5x cheaper than six
+// ds_bpermute butterflies (tools/microbench/valu_rates.hip).
 // Three sums at once, the three DPP chains interleaved step by step: a DPP source written by the previous
 // VALU instruction costs wait states (the compiler pads a single chain with s_nop); with three independent
 // chains in lock-step the hazard is covered by real work.
@@ -253,7 +245,7 @@ struct Smem {
     int cols[Geometry<WPE>::kEnvsPerBlock][WPE];              // moving pedestrians per wave (tile compaction)
     float exitg[Geometry<WPE>::kEnvsPerBlock][2];            // gravity exit term from the lane that computed it (WPE > 1)
     // rollout outputs of up to kStageSteps steps, flushed with ONE 64-lane store (GRAV kernels)
-    float stage[Geometry<WPE>::kEnvsPerBlock][7][12];
+    alignas(16) float stage[Geometry<WPE>::kEnvsPerBlock][kStageSteps][12];   // rows written as two 16-byte vectors + 1 word
     int redi[Geometry<WPE>::kEnvsPerBlock][WPE][8];
 };
 
@@ -796,10 +788,11 @@ struct Who {
 };
 
 // ------------------------------------------------------------------------------------------------
-// Kernels
+// Kernels.  __launch_bounds__(block, 4): at least 4 waves per SIMD, i.e. at most 128 VGPRs -- the 4-wave kernel
+// once grew to 135 and silently lost a quarter of its occupancy (C3: 7.7 -> 8.5 us per step).
 // ------------------------------------------------------------------------------------------------
 template <int WPE, bool GRAV>
-__global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_step(
+__global__ __launch_bounds__(Geometry<WPE>::kBlock, 4) void k_step(
     Params p, const float2* __restrict__ actions, const float* __restrict__ noise_in, float* __restrict__ obs_out,
     float* __restrict__ reward_out, uint8_t* __restrict__ term_out, uint8_t* __restrict__ trunc_out, int autoreset,
     float* __restrict__ final_obs, evac_episode_stats_t* __restrict__ final_stats) {
@@ -992,14 +985,14 @@ __device__ __forceinline__ void rollout_body(
 // The default face carries no capture / action-recording code at all; the diagnostic face is used by
 // rollout(capture_envs=K) and rollout(record_actions=True).
 template <int WPE, bool GRAV>
-__global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_rollout(
+__global__ __launch_bounds__(Geometry<WPE>::kBlock, 4) void k_rollout(
     Params p, int n_steps, const float2* __restrict__ actions, float* __restrict__ slab_out,
     evac_episode_stats_t* __restrict__ final_stats) {
     __shared__ Smem<WPE> sm;
     rollout_body<WPE, GRAV, false>(sm, p, n_steps, actions, nullptr, slab_out, final_stats, 0, nullptr);
 }
 template <int WPE, bool GRAV>
-__global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_rollout_capture(
+__global__ __launch_bounds__(Geometry<WPE>::kBlock, 4) void k_rollout_capture(
     Params p, int n_steps, const float2* __restrict__ actions, float2* __restrict__ actions_out,
     float* __restrict__ slab_out, evac_episode_stats_t* __restrict__ final_stats, int capture_envs,
     float* __restrict__ capture) {
@@ -1008,7 +1001,7 @@ __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_rollout_capture(
 }
 
 template <int WPE, bool GRAV>
-__global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_reset(Params p, const uint8_t* __restrict__ mask,
+__global__ __launch_bounds__(Geometry<WPE>::kBlock, 4) void k_reset(Params p, const uint8_t* __restrict__ mask,
                                                                 const float4* __restrict__ draws,
                                                                 float* __restrict__ obs_out) {
     __shared__ Smem<WPE> sm;
@@ -1028,7 +1021,7 @@ __global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_reset(Params p, const
 }
 
 template <int WPE, bool GRAV>
-__global__ __launch_bounds__(Geometry<WPE>::kBlock) void k_observe(Params p, float* __restrict__ obs_out) {
+__global__ __launch_bounds__(Geometry<WPE>::kBlock, 4) void k_observe(Params p, float* __restrict__ obs_out) {
     __shared__ Smem<WPE> sm;
     const Who<WPE> w;
     if (w.env >= p.n_envs) return;
@@ -1150,4 +1143,11 @@ __global__ void k_norm_step(int n_envs, int D, float* __restrict__ obs, float* _
     }
 }
 
+}  // namespace evac
+
+namespace evac {
+// layout guards: the tile and the staging rows are accessed with 16-byte LDS instructions
+static_assert(offsetof(Smem<1>, stage) % 16 == 0 && offsetof(Smem<4>, stage) % 16 == 0 &&
+              offsetof(Smem<8>, stage) % 16 == 0 && offsetof(Smem<16>, stage) % 16 == 0, "stage rows must be 16-byte aligned");
+static_assert(offsetof(Smem<1>, tile) == 0 && alignof(Smem<1>) >= 16 && alignof(Smem<16>) >= 16, "tile must be 16-byte aligned");
 }  // namespace evac
