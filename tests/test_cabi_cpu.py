@@ -133,3 +133,29 @@ def test_product_never_imports_the_oracle():
     code = "import sys, evacuation_amd, evacuation_amd.vector_env, evacuation_amd.env; " \
            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'"
     subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+
+
+def test_kernel_resource_budgets():
+    """Compile the device code to gfx950 assembly and check the register budgets the design relies on:
+    every step / rollout kernel fits 4 waves per SIMD (<= 128 VGPRs; C3 lost a quarter of its occupancy when one
+    grew to 135), and the headline kernels (1 wave per env, sub-wave) neither spill VGPRs nor use scratch."""
+    import tempfile
+    src = os.path.join(ROOT, "evacuation_amd", "csrc", "evac_api.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "evac.s")
+        subprocess.run([build.hipcc_path(), "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-S",
+                        "--cuda-device-only", src, "-o", out], check=True, capture_output=True)
+        text = open(out).read()
+    meta = text[text.index("amdhsa.kernels:"):]
+    kernels = {}
+    for block in meta.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        kernels[name] = {k: int(re.search(rf"\.{k}:\s+(\d+)", block).group(1))
+                         for k in ("vgpr_count", "vgpr_spill_count", "sgpr_count", "private_segment_fixed_size")}
+    assert len(kernels) >= 40
+    for name, k in kernels.items():
+        if "k_step" in name or "k_rollout" in name or "k_reset" in name or "k_observe" in name:
+            assert k["vgpr_count"] <= 128, (name, k)
+        headline = ("k_rolloutILi1ELb1" in name or "k_stepILi1ELb1" in name or "_subILi" in name) and "capture" not in name
+        if headline:
+            assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (name, k)
