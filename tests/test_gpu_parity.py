@@ -768,3 +768,38 @@ def test_sharded_env_single_process_path(ea):
     rr = ref.rollout(10)
     assert full.shape == (10, 12, 9) and (full == rr["slab"]).all() and (ro["slab"] == rr["slab"]).all()
     sh.close(); ref.close()
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_randomized_configurations(ea, case):
+    """Random (N, room, step, noise, enslaving, eps, rewards, alpha, observation mode): oracle-generated states,
+    one teacher-forced step, reference-precision comparison.  Covers the sub-wave (N <= 32), one-wave and
+    multi-wave kernels with parameter combinations no hand-written case uses."""
+    rng = np.random.default_rng(9000 + case)
+    n = int(rng.choice([rng.integers(1, 17), rng.integers(17, 33), rng.integers(33, 65), rng.integers(65, 200)]))
+    kw = dict(number_of_pedestrians=n,
+              width=float(rng.uniform(0.8, 1.6)), height=float(rng.uniform(0.8, 1.6)),
+              step_size=float(rng.choice([0.005, 0.01, 0.03, 0.08])), noise_coef=float(rng.choice([0.0, 0.1, 0.2, 0.7, 1.9])),
+              enslaving_degree=float(rng.choice([1.0, 0.6, 0.05])), eps=float(rng.choice([1e-8, 1e-4])),
+              is_new_exiting_reward=bool(rng.integers(2)), is_new_followers_reward=bool(rng.integers(2)),
+              intrinsic_reward_coef=float(rng.choice([0.0, 1.0, 3.0])), init_reward_each_step=float(rng.choice([-1.0, 0.0, 0.5])),
+              is_termination_agent_wall_collision=bool(rng.integers(2)), max_timesteps=int(rng.choice([7, 2000])))
+    p = O.OracleParams(**kw)
+    wrap_kw = [dict(positions="grav", alpha=float(rng.choice([1, 2, 3, 4.5]))),
+               dict(positions=str(rng.choice(["abs", "rel"])), statuses=str(rng.choice(["no", "ohe", "cat"])),
+                    type=str(rng.choice(["Dict", "Box"])))][case % 2]
+    wrap = ea.EnvWrappersConfig(**wrap_kw)
+    E = 5
+    pre, acts, nzs = [], [], []
+    for e in range(E):
+        st = O.env_reset(p, rng.uniform(-1, 1, (n, 2)), rng.uniform(-1, 1, (n, 2)))
+        for _ in range(int(rng.integers(0, 7))):
+            with np.errstate(all="ignore"):
+                O.env_step(p, st, rng.uniform(-1, 1, 2).astype(np.float32), rng.uniform(-p.noise_coef / 2, p.noise_coef / 2, n))
+        if not np.isfinite(st.pos).all():
+            continue
+        pre.append(st)
+        acts.append(rng.uniform(-1, 1, 2).astype(np.float32))
+        nzs.append(rng.uniform(-p.noise_coef / 2, p.noise_coef / 2, n).astype(np.float32))
+    got = gpu_step_batch(ea, p, wrap, pre, acts, nzs)
+    compare_step(p, wrap, pre, acts, nzs, got, min_checked=max(1, len(pre) - 2))
