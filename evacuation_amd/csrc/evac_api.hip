@@ -78,7 +78,7 @@ int check_launch(evac_handle_t h, const char* what) {
     return EVAC_OK;
 }
 
-int waves_per_env(int n_ped) { return n_ped <= 64 ? 1 : (n_ped <= 256 ? 4 : (n_ped <= 512 ? 8 : 16)); }
+int waves_per_env(int n_ped) { return n_ped <= 64 ? 1 : (n_ped <= 128 ? 2 : (n_ped <= 256 ? 4 : (n_ped <= 512 ? 8 : 16))); }
 
 template <int WPE>
 dim3 grid_for(int n_envs) {
@@ -107,11 +107,13 @@ dim3 grid_for(int n_envs) {
             else EVAC_LAUNCH_SUB(h, KERNEL, 32, false, s_, __VA_ARGS__);              \
         } else if (grav_) {                                                           \
             if (wpe_ == 1) EVAC_LAUNCH(h, KERNEL, 1, true, s_, __VA_ARGS__);          \
+            else if (wpe_ == 2) EVAC_LAUNCH(h, KERNEL, 2, true, s_, __VA_ARGS__);     \
             else if (wpe_ == 4) EVAC_LAUNCH(h, KERNEL, 4, true, s_, __VA_ARGS__);     \
             else if (wpe_ == 8) EVAC_LAUNCH(h, KERNEL, 8, true, s_, __VA_ARGS__);     \
             else EVAC_LAUNCH(h, KERNEL, 16, true, s_, __VA_ARGS__);                   \
         } else {                                                                      \
             if (wpe_ == 1) EVAC_LAUNCH(h, KERNEL, 1, false, s_, __VA_ARGS__);         \
+            else if (wpe_ == 2) EVAC_LAUNCH(h, KERNEL, 2, false, s_, __VA_ARGS__);    \
             else if (wpe_ == 4) EVAC_LAUNCH(h, KERNEL, 4, false, s_, __VA_ARGS__);    \
             else if (wpe_ == 8) EVAC_LAUNCH(h, KERNEL, 8, false, s_, __VA_ARGS__);    \
             else EVAC_LAUNCH(h, KERNEL, 16, false, s_, __VA_ARGS__);                  \

@@ -1,6 +1,6 @@
 // Device code of libevac: the fused evacuation-env step for gfx950 (CDNA4, wave64).
 //
-// One env is owned by WPE waves (WPE = 1 for 33 <= N <= 64, else 4/8/16 = one workgroup; N <= 32 shares a wave
+// One env is owned by WPE waves (WPE = 1 for 33 <= N <= 64, else 2/4/8/16 = one workgroup; N <= 32 shares a wave
 // between envs, see evac_subwave.h); lane i owns pedestrian i in registers.  The only O(N^2) part -- the
 // Vicsek neighbour average, area.py:104-119 of the reference -- reads the moving peers' (x, y, unit heading)
 // from a compacted LDS tile with wave-uniform (broadcast) ds_read_b128.  Everything else is O(N) per-lane
@@ -234,7 +234,9 @@ struct Geometry {
 #ifndef EVAC_BLOCK1
 #define EVAC_BLOCK1 256
 #endif
-    static constexpr int kBlock = (kThreadsPerEnv < EVAC_BLOCK1) ? EVAC_BLOCK1 : kThreadsPerEnv;
+    // WPE == 1: several one-wave envs share a workgroup (no workgroup barrier is ever used there);
+    // WPE >= 2: exactly one env per workgroup, so that __syncthreads() is a per-env barrier
+    static constexpr int kBlock = WPE == 1 ? EVAC_BLOCK1 : kThreadsPerEnv;
     static constexpr int kEnvsPerBlock = kBlock / kThreadsPerEnv;
 };
 
@@ -592,7 +594,7 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
         const float XI = q.x * kTileScale, YI = q.y * kTileScale;
         // peers per LDS round trip: 16 where registers allow (1-wave kernels: 3.31 vs 3.34 us at 8, 3.49 at 4),
         // 8 in the multi-wave kernels, 4 in the 1024-thread one whose workgroup size caps it at 128 VGPRs
-        constexpr int B = WPE == 1 ? 16 : (WPE == 16 ? 4 : 8);
+        constexpr int B = WPE <= 2 ? 16 : (WPE == 16 ? 4 : 8);
         int j = 0;
         if constexpr (!(EVAC_ABLATE & 1)) {
             for (; j + B <= n8; j += B) {      // full batches
@@ -1147,7 +1149,7 @@ __global__ void k_norm_step(int n_envs, int D, float* __restrict__ obs, float* _
 
 namespace evac {
 // layout guards: the tile and the staging rows are accessed with 16-byte LDS instructions
-static_assert(offsetof(Smem<1>, stage) % 16 == 0 && offsetof(Smem<4>, stage) % 16 == 0 &&
+static_assert(offsetof(Smem<1>, stage) % 16 == 0 && offsetof(Smem<2>, stage) % 16 == 0 && offsetof(Smem<4>, stage) % 16 == 0 &&
               offsetof(Smem<8>, stage) % 16 == 0 && offsetof(Smem<16>, stage) % 16 == 0, "stage rows must be 16-byte aligned");
 static_assert(offsetof(Smem<1>, tile) == 0 && alignof(Smem<1>) >= 16 && alignof(Smem<16>) >= 16, "tile must be 16-byte aligned");
 }  // namespace evac
