@@ -475,31 +475,6 @@ __device__ __forceinline__ void pair_accumulate(float XI, float YI, f4 t, float 
     sy = fmaf(w, t.w, sy);
 }
 
-// Neighbour sums over tile entries [j0, j1) (both multiples of 4): full batches of B peers per LDS round trip,
-// then groups of 4.  Entries are read with one address per lane (wave-uniform in the one-wave kernels).
-template <int B>
-__device__ __forceinline__ void pair_sum_range(const f4* __restrict__ tile, int j0, int j1, float XI, float YI,
-                                               float& sx, float& sy) {
-    int j = j0;
-    for (; j + B <= j1; j += B) {
-        f4 t[B];
-#pragma unroll
-        for (int k = 0; k < B; ++k) t[k] = tile[j + k];
-#pragma unroll
-        for (int k = 0; k < B; ++k) pair_accumulate(XI, YI, t[k], kRPed2Big, sx, sy);
-    }
-    for (; j < j1; j += 4) {
-        f4 t[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pair_accumulate(XI, YI, t[k], kRPed2Big, sx, sy);
-    }
-}
-// Every kernel sums the columns in two halves, [0, h) and [h, n4), and adds the halves at the end: the duo
-// rollout kernel gives the second half to a helper wave, and all kernels must round identically.
-__device__ __forceinline__ int pair_split(int n4) { return ((n4 >> 1) + 3) & ~3; }
-
 // ------------------------------------------------------------------------------------------------
 // One env step: env.py:141-171.  All lanes of the env call this together.
 // ------------------------------------------------------------------------------------------------
@@ -620,13 +595,22 @@ __device__ __forceinline__ void step_env(const Params& p, Smem<WPE>& sm, int slo
         // peers per LDS round trip: 16 where registers allow (1-wave kernels: 3.31 vs 3.34 us at 8, 3.49 at 4),
         // 8 in the multi-wave kernels, 4 in the 1024-thread one whose workgroup size caps it at 128 VGPRs
         constexpr int B = WPE <= 2 ? 16 : (WPE == 16 ? 4 : 8);
+        int j = 0;
         if constexpr (!(EVAC_ABLATE & 1)) {
-            const int h = pair_split(n8);
-            float tx = 0.0f, ty = 0.0f;
-            pair_sum_range<B>(tile, 0, h, XI, YI, sx, sy);
-            pair_sum_range<B>(tile, h, n8, XI, YI, tx, ty);
-            sx += tx;
-            sy += ty;
+            for (; j + B <= n8; j += B) {      // full batches
+                f4 t[B];
+#pragma unroll
+                for (int k = 0; k < B; ++k) t[k] = tile[j + k];
+#pragma unroll
+                for (int k = 0; k < B; ++k) pair_accumulate(XI, YI, t[k], r2b, sx, sy);
+            }
+            for (; j < n8; j += 4) {           // remainder in groups of 4 (n8 is a multiple of 4)
+                f4 t[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pair_accumulate(XI, YI, t[k], r2b, sx, sy);
+            }
         }
     }
     EVAC_T(3);   // all-pairs loop

@@ -154,12 +154,21 @@ __device__ __forceinline__ void step_env_sub(const Params& p, SmemSub<G>& sm, co
         const int n4 = (__ballot(fv) != 0ull) ? ((nmax + 3) & ~3) : 0;
         const f4* __restrict__ tile = sm.tile[w.slot];           // per lane: its group's tile
         const float XI = q.x * kTileScale, YI = q.y * kTileScale;
-        const int h = pair_split(n4);                            // same two-halves summation as every other kernel
-        float tx = 0.0f, ty = 0.0f;
-        pair_sum_range<8>(tile, 0, h, XI, YI, sx, sy);
-        pair_sum_range<8>(tile, h, n4, XI, YI, tx, ty);
-        sx += tx;
-        sy += ty;
+        int j = 0;
+        for (; j + 8 <= n4; j += 8) {
+            f4 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = tile[j + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pair_accumulate(XI, YI, t[k], kRPed2Big, sx, sy);
+        }
+        for (; j < n4; j += 4) {
+            f4 t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pair_accumulate(XI, YI, t[k], kRPed2Big, sx, sy);
+        }
     }
     {
         const bool zero_mean = sx == 0.0f && sy == 0.0f;
