@@ -633,9 +633,10 @@ def test_full_size_invariants_large_envs(ea, n, E, T, wrap_kw):
     env.close()
 
 
-def test_masked_reset_touches_only_selected_envs(ea):
+@pytest.mark.parametrize("n", [10, 20, 60, 100])
+def test_masked_reset_touches_only_selected_envs(ea, n):
     import torch
-    n, E, seed = 60, 8, 5
+    E, seed = 8, 5
     env = ea.BatchedEvacuationEnv(ea.EnvConfig(number_of_pedestrians=n), ea.EnvWrappersConfig(positions="grav"), num_envs=E,
                                   seed=seed, autoreset=False)
     env.reset()
