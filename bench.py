@@ -310,7 +310,7 @@ def main():
                        "max_timesteps": 2000, "autoreset": True},
             "agent_updates_per_s": value * n_ped,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "frac_of_measured_copy_peak": achieved / 6290.0, "traffic": traffic,
                          "kernel": f"k_rollout<{1 if n_ped <= 64 else 4 if n_ped <= 256 else 8 if n_ped <= 512 else 16}>" if args.mode == "rollout" else "k_step",
                          "kernel_ms_per_launch": kernel_s * 1e3, "algorithmic_bytes_per_env_step": bytes_per_env_step,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
