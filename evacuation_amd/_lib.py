@@ -15,6 +15,8 @@ POS = {"abs": 0, "rel": 1, "grav": 2}
 STAT = {"no": 0, "ohe": 1, "cat": 2}
 TYPE = {"Dict": 0, "Box": 1}
 MAX_PEDESTRIANS = 1024
+VERSION = 110
+EPISODE_STATS_WORDS = 10       # evac_episode_stats_t: 8 floats + 2 int32
 
 
 class EvacConfig(C.Structure):
@@ -48,10 +50,11 @@ SIGNATURES = {
     "evac_destroy": (C.c_int, [_P]),
     "evac_obs_dim": (C.c_int64, [_P]),
     "evac_num_envs": (C.c_int32, [_P]),
+    "evac_kernel_variant": (C.c_char_p, [_P, C.c_int32]),
     "evac_bind_state": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "evac_reset": (C.c_int, [_P, _P, _P, _P, _P]),
     "evac_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
-    "evac_rollout": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P]),
+    "evac_rollout": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     "evac_get_state": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "evac_set_state": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "evac_observe": (C.c_int, [_P, _P, _P]),

@@ -62,7 +62,9 @@ struct evac_handle {
     int device;
     bool bound;
     int sub_lanes;      // 0: one wave (or more) per env; 16 / 32: sub-wave kernels (evac_subwave.h)
+    bool cells;         // workgroup-per-env kernels with the cell list (N > 64) instead of all pairs
     std::string err;
+    std::string variant[2];
 };
 
 namespace {
@@ -80,20 +82,29 @@ int check_launch(evac_handle_t h, const char* what) {
 
 int waves_per_env(int n_ped) { return n_ped <= 64 ? 1 : (n_ped <= 128 ? 2 : (n_ped <= 256 ? 4 : (n_ped <= 512 ? 8 : 16))); }
 
-template <int WPE>
-dim3 grid_for(int n_envs) {
-    const int per = evac::Geometry<WPE>::kEnvsPerBlock;
-    return dim3((unsigned)((n_envs + per - 1) / per));
-}
-
-#define EVAC_LAUNCH(h, KERNEL, WPE_, GRAV_, s_, ...) \
-    hipLaunchKernelGGL((evac::KERNEL<WPE_, GRAV_>), grid_for<WPE_>((h)->p.n_envs), dim3(evac::Geometry<WPE_>::kBlock), 0, s_, __VA_ARGS__)
+// launch KERNEL<F, GRAV> for a Wave / Cells family F
+#define EVAC_LAUNCH_F(h, KERNEL, F_, GRAV_, s_, ...)                                                                  \
+    hipLaunchKernelGGL((evac::KERNEL<F_, GRAV_>), dim3((unsigned)(((h)->p.n_envs + F_::kEnvsPerBlock - 1) / F_::kEnvsPerBlock)), \
+                       dim3(F_::kBlock), 0, s_, __VA_ARGS__)
 #define EVAC_LAUNCH_SUB(h, KERNEL, G_, GRAV_, s_, ...)                                                              \
     hipLaunchKernelGGL((evac::KERNEL##_sub<G_, GRAV_>),                                                             \
-                       dim3((unsigned)(((h)->p.n_envs + evac::SubGeo<G_>::kEnvsPerBlock - 1) / evac::SubGeo<G_>::kEnvsPerBlock)), \
-                       dim3(evac::SubGeo<G_>::kBlock), 0, s_, __VA_ARGS__)
+                       dim3((unsigned)(((h)->p.n_envs + evac::Sub<G_>::kEnvsPerBlock - 1) / evac::Sub<G_>::kEnvsPerBlock)), \
+                       dim3(evac::Sub<G_>::kBlock), 0, s_, __VA_ARGS__)
+#define EVAC_LAUNCH_WPE(h, KERNEL, WPE_, s_, ...)                                                                   \
+    do {                                                                                                            \
+        if (WPE_ > 1 && (h)->cells) {                                                                               \
+            using FC_ = evac::Cells<(WPE_ > 1 ? WPE_ : 2)>;                                                         \
+            if (grav_) EVAC_LAUNCH_F(h, KERNEL, FC_, true, s_, __VA_ARGS__);                                        \
+            else EVAC_LAUNCH_F(h, KERNEL, FC_, false, s_, __VA_ARGS__);                                             \
+        } else {                                                                                                    \
+            using FW_ = evac::Wave<WPE_>;                                                                           \
+            if (grav_) EVAC_LAUNCH_F(h, KERNEL, FW_, true, s_, __VA_ARGS__);                                        \
+            else EVAC_LAUNCH_F(h, KERNEL, FW_, false, s_, __VA_ARGS__);                                             \
+        }                                                                                                           \
+    } while (0)
 
-// kernel variant = (lanes or waves per env) x (gravity observation | generic positions/statuses observation)
+// kernel variant = family (lanes or waves per env, all pairs | cell list) x (gravity observation | generic
+// positions/statuses observation)
 #define EVAC_DISPATCH(h, KERNEL, stream, ...)                                         \
     do {                                                                              \
         const int wpe_ = waves_per_env((h)->p.n_ped);                                 \
@@ -105,19 +116,11 @@ dim3 grid_for(int n_envs) {
         } else if ((h)->sub_lanes == 32) {                                            \
             if (grav_) EVAC_LAUNCH_SUB(h, KERNEL, 32, true, s_, __VA_ARGS__);         \
             else EVAC_LAUNCH_SUB(h, KERNEL, 32, false, s_, __VA_ARGS__);              \
-        } else if (grav_) {                                                           \
-            if (wpe_ == 1) EVAC_LAUNCH(h, KERNEL, 1, true, s_, __VA_ARGS__);          \
-            else if (wpe_ == 2) EVAC_LAUNCH(h, KERNEL, 2, true, s_, __VA_ARGS__);     \
-            else if (wpe_ == 4) EVAC_LAUNCH(h, KERNEL, 4, true, s_, __VA_ARGS__);     \
-            else if (wpe_ == 8) EVAC_LAUNCH(h, KERNEL, 8, true, s_, __VA_ARGS__);     \
-            else EVAC_LAUNCH(h, KERNEL, 16, true, s_, __VA_ARGS__);                   \
-        } else {                                                                      \
-            if (wpe_ == 1) EVAC_LAUNCH(h, KERNEL, 1, false, s_, __VA_ARGS__);         \
-            else if (wpe_ == 2) EVAC_LAUNCH(h, KERNEL, 2, false, s_, __VA_ARGS__);    \
-            else if (wpe_ == 4) EVAC_LAUNCH(h, KERNEL, 4, false, s_, __VA_ARGS__);    \
-            else if (wpe_ == 8) EVAC_LAUNCH(h, KERNEL, 8, false, s_, __VA_ARGS__);    \
-            else EVAC_LAUNCH(h, KERNEL, 16, false, s_, __VA_ARGS__);                  \
-        }                                                                             \
+        } else if (wpe_ == 1) EVAC_LAUNCH_WPE(h, KERNEL, 1, s_, __VA_ARGS__);         \
+        else if (wpe_ == 2) EVAC_LAUNCH_WPE(h, KERNEL, 2, s_, __VA_ARGS__);           \
+        else if (wpe_ == 4) EVAC_LAUNCH_WPE(h, KERNEL, 4, s_, __VA_ARGS__);           \
+        else if (wpe_ == 8) EVAC_LAUNCH_WPE(h, KERNEL, 8, s_, __VA_ARGS__);           \
+        else EVAC_LAUNCH_WPE(h, KERNEL, 16, s_, __VA_ARGS__);                         \
     } while (0)
 
 }  // namespace
@@ -179,6 +182,10 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         const bool allow = !(sw && sw[0] == '0');
         const int n = cfg->number_of_pedestrians;
         h->sub_lanes = !allow ? 0 : (n <= 16 ? 16 : (n <= 32 ? 32 : 0));
+        // rooms of more than 512 pedestrians use the cell list; EVAC_CELLS=1 / 0 forces it on (for every room of more
+        // than one wave) / off, for A/B tests
+        const char* cl = std::getenv("EVAC_CELLS");
+        h->cells = n > evac::kWave && (cl && cl[0] == '1' ? true : (cl && cl[0] == '0' ? false : n > 512));
     }
     evac::Params& p = h->p;
     std::memset(&p, 0, sizeof(p));
@@ -208,17 +215,40 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
     p.neg_alpha = -cfg->alpha;
     p.grav_pow = cfg->alpha + 2.0f;
     const float gp = cfg->alpha + 2.0f;
-    p.grav_pow_int = (gp == std::floor(gp) && gp >= 1.0f && gp <= 32.0f) ? (int)gp : 0;
+    p.grav_pow_int = (gp == std::floor(gp) && gp >= 1.0f && gp <= 63.0f) ? (int)gp : 0;
     {
         const float half = std::fabs(cfg->noise_coef) * 0.5f;
         p.small_noise = half <= 0.2f ? 2 : (half <= 0.78539816f ? 1 : 0);
     }
+    {   // cell list: 16 x 16 cells over [-max(W,1), max(W,1)] x [-max(H,1), max(H,1)] (reset draws positions in +-1
+        // whatever the room, pedestrians.py:17): a cell is >= 0.125 wide, the pedestrian radius is 0.1
+        const float wb = std::fmax(cfg->width, 1.0f), hb = std::fmax(cfg->height, 1.0f);
+        p.cell_ox = wb;
+        p.cell_oy = hb;
+        p.cell_inv_hx = (float)evac::kCellsX / (2.0f * wb);
+        p.cell_inv_hy = (float)evac::kCellsY / (2.0f * hb);
+        int k = 22;                                        // |heading| * 2^k must fit v_mad_i32_i24, N * 2^k <= 2^30
+        while (((int64_t)cfg->number_of_pedestrians << k) > (1ll << 30)) --k;
+        p.head_scale = std::ldexp(1.0f, k);
+    }
     p.seed_lo = (uint32_t)(seed & 0xffffffffull);
     p.seed_hi = (uint32_t)(seed >> 32);
     p.env_id_offset = (uint32_t)env_id_offset;
+    {
+        const int wpe = waves_per_env(p.n_ped);
+        const bool grav = p.obs_pos == EVAC_POS_GRAV;
+        std::string fam = h->sub_lanes == 16 ? evac::Sub<16>::kName : h->sub_lanes == 32 ? evac::Sub<32>::kName :
+                          wpe == 1 ? evac::Wave<1>::kName :
+                          h->cells ? (wpe == 2 ? evac::Cells<2>::kName : wpe == 4 ? evac::Cells<4>::kName : wpe == 8 ? evac::Cells<8>::kName : evac::Cells<16>::kName)
+                                   : (wpe == 2 ? evac::Wave<2>::kName : wpe == 4 ? evac::Wave<4>::kName : wpe == 8 ? evac::Wave<8>::kName : evac::Wave<16>::kName);
+        h->variant[0] = "k_step<" + fam + (grav ? ", grav obs>" : ", generic obs>");
+        h->variant[1] = "k_rollout<" + fam + (grav ? ", grav obs>" : ", generic obs>");
+    }
     *out = h;
     return EVAC_OK;
 }
+
+const char* evac_kernel_variant(evac_handle_t h, int32_t rollout) { return h ? h->variant[rollout ? 1 : 0].c_str() : ""; }
 
 int evac_destroy(evac_handle_t h) {
     delete h;
@@ -275,7 +305,8 @@ int evac_step(evac_handle_t h, const float* actions, const float* noise, float* 
 }
 
 int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* actions_out, float* slab_out,
-                 evac_episode_stats_t* final_stats, int32_t capture_envs, float* capture, void* stream) {
+                 evac_episode_stats_t* final_stats, int32_t capture_envs, float* capture, const float* noise,
+                 void* stream) {
     EVAC_REQUIRE_BOUND(h, "evac_rollout");
     if (n_steps < 1) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_rollout: n_steps must be >= 1");
     if (!slab_out) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_rollout: slab_out must be non-NULL");
@@ -284,9 +315,9 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
     DeviceGuard g(h->device);
     if (capture && (capture_envs < 1 || capture_envs > h->p.n_envs))
         return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_rollout: capture_envs must be in [1, num_envs] when capture is given");
-    if (capture || actions_out)
-        EVAC_DISPATCH(h, k_rollout_capture, stream, h->p, (int)n_steps, (const float2*)actions, (float2*)actions_out, slab_out,
-                      final_stats, (int)capture_envs, capture);
+    if (capture || actions_out || noise)
+        EVAC_DISPATCH(h, k_rollout_diag, stream, h->p, (int)n_steps, (const float2*)actions, (float2*)actions_out, slab_out,
+                      final_stats, (int)capture_envs, capture, noise);
     else
         EVAC_DISPATCH(h, k_rollout, stream, h->p, (int)n_steps, (const float2*)actions, slab_out, final_stats);
     return check_launch(h, "evac_rollout");

@@ -1,0 +1,468 @@
+// Device code of libevac, part 1: constants, parameter block, Philox, wave helpers and the per-lane pieces of the
+// evacuation-env step that every kernel family shares (gfx950 / CDNA4, wave64).
+//
+// Lane i of an env owns pedestrian i in registers.  How the lanes of an env are grouped differs per family
+// (evac_families.h): 16 or 32 lanes of a wave (small rooms), one wave, or a workgroup of 2..16 waves; the
+// arithmetic in this file is identical for all of them, and the ONE step body (step_env, evac_device.h) is
+// written against the family interface.
+//
+// Built with -ffp-contract=off: every fused multiply-add is written explicitly (fmaf), so what is fused is
+// a decision of these files, not of the compiler.  Divisions and square roots use the 1-ulp hardware
+// v_rcp / v_rsq / v_sqrt (see frcp / frsq / fsqrt); the parity bar is 1e-5 absolute.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/evac.h"
+
+// Profiling-only phase ablation (tools/ablate.sh builds side libraries with -DEVAC_ABLATE=mask; the
+// shipped library is always built with 0).  1: no pair loop, 2: no observation epilogue,
+// 4: no Philox (constant action / noise), 8: no status/reward reductions, 16: no per-step stores.
+#ifndef EVAC_ABLATE
+#define EVAC_ABLATE 0
+#endif
+
+// Diagnostic build only (-DEVAC_STAMP, tools/stamps.sh): s_memtime stamps around the phases of a step,
+// summed per phase over all waves into g_stamps.  No stamp executes in the shipped library.
+#ifdef EVAC_STAMP
+__device__ unsigned long long g_stamps[16];
+struct StampState {
+    unsigned long long acc[16] = {};
+    unsigned long long last = 0;
+};
+#define EVAC_T(c, k)                                                                      \
+    do {                                                                                  \
+        unsigned long long now_;                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        (c).stamp.acc[k] += now_ - (c).stamp.last;                                        \
+        (c).stamp.last = now_;                                                            \
+    } while (0)
+#else
+#define EVAC_T(c, k) do { } while (0)
+#endif
+
+namespace evac {
+
+constexpr int kViscek = 1, kFollower = 2, kExiting = 3, kEscaped = 4;   // statuses.py:16-27
+constexpr float kExitX = 0.0f, kExitY = -1.0f;                           // area.py:39
+// constants.py:35-38 (not configurable in the reference either).  Squared radii are rounded from the double
+// product.
+constexpr float kRLeader2 = (float)(0.2 * 0.2), kRPed2 = (float)(0.1 * 0.1), kRExit = 0.4f, kREscape = 0.01f;
+constexpr float kTileScale = 0x1.0p40f;                 // tile coordinates are stored times 2^40 (exact)
+constexpr float kRPed2Big = kRPed2 * 0x1.0p80f;        // r_ped^2 * 2^80, exact: the pair test in scaled units
+// boolean options packed into Params::flags (one SGPR instead of seven)
+constexpr uint32_t kFlagNewExitingReward = 1u, kFlagNewFollowersReward = 2u, kFlagTermOnWall = 4u, kFlagNanGuard = 8u,
+                   kFlagClipAction = 16u;
+constexpr int kWave = 64;
+constexpr int kStageSteps = 7, kGravRow = 9;   // 7 steps x (6 obs + reward + terminated + truncated) = 63 words <= 64 lanes
+// Cell list of the workgroup-per-env kernels (evac_families.h, Cells): kCellsX x kCellsY cells over the room.
+// A cell is at least 0.125 wide (host: evac_create), i.e. wider than the pedestrian radius 0.1 by far more than any
+// rounding of the cell index, so two pedestrians within the radius are never more than one cell apart.
+constexpr int kCellsX = 16, kCellsY = 16, kCells = kCellsX * kCellsY;
+// native 16-byte vector: loads/stores of it are single ds_read_b128 / ds_write_b128 (HIP's float4 is
+// copied member-wise and re-merged only to 8-byte alignment, i.e. ds_read2_b64 at half the LDS rate)
+using f4 = float __attribute__((ext_vector_type(4)));
+using i4 = int __attribute__((ext_vector_type(4)));
+using i2 = int __attribute__((ext_vector_type(2)));
+
+// Philox stream ids (counter word 3)
+constexpr uint32_t kStreamNoise = 0x4e4f4953u;   // 'NOIS'
+constexpr uint32_t kStreamReset = 0x52455345u;   // 'RESE'
+constexpr uint32_t kStreamAction = 0x41435449u;  // 'ACTI'
+
+struct Params {
+    int32_t n_envs, n_ped;
+    float width, height, step_size, noise_coef, eps;
+    float ens, one_minus_ens;
+    float init_reward, intrinsic_coef;
+    int32_t max_timesteps;
+    uint32_t flags;                                 // kFlag*
+    float inv_n, inv_200n;                          // 1/N, 1/(200 N)
+    int32_t obs_pos, obs_stat, obs_box, obs_dim;
+    float alpha, neg_alpha, grav_pow;               // grav_pow = alpha + 2
+    int32_t grav_pow_int;                           // alpha+2 if it is an integer in [1,63], else 0
+    int32_t small_noise;                            // sin/cos regime: 2 short Taylor, 1 long Taylor, 0 ocml sincosf (noise_sincos)
+    uint32_t seed_lo, seed_hi, env_id_offset;
+    // cell list (Cells family): cell = (int)((x + cell_ox) * cell_inv_hx) clamped to [0, 15], same in y;
+    // head_scale = 2^k with N * 2^k <= 2^30: unit headings are summed as integers (exact, order-independent)
+    float cell_ox, cell_oy, cell_inv_hx, cell_inv_hy, head_scale;
+    // bound state
+    float4* ped;
+    uint8_t* status;
+    float4* agent;
+    int4* clock;
+    float4* acc;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11; Random123).  Restated in oracle/philox.py and checked there
+// against the Random123 known-answer vectors.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
+#ifndef EVAC_NO_KEY_BARRIER
+    // Keep the ten round keys from being hoisted out of the caller's loop as 20 live SGPRs (the step loop is
+    // already over the scalar-register budget); recomputing them is 20 s_add per call.
+    asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        // one 32x32->64 multiply (v_mad_u64_u32) per product instead of a v_mul_hi_u32 / v_mul_lo_u32 pair
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+// 24-bit uniform in [0,1): exact in f32
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * 0x1.0p-24f; }
+// U[-1,1): exact in f32 (pedestrians.py:17-18 draws U(-1,1); random_agent.py:8-9 samples Box(-1,1))
+__device__ __forceinline__ float usym(uint32_t x) { return 2.0f * u01(x) - 1.0f; }
+
+// ------------------------------------------------------------------------------------------------
+// wave-level helpers
+// ------------------------------------------------------------------------------------------------
+// DPP add step: v + (v moved by `ctrl`), lanes without a source (or in rows masked off) add 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_addi(int v) {
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+// Sums over the 64 lanes, results wave-uniform (SGPRs).  row_shr 1/2/4/8 leave each row's total in its lane 15;
+// row_bcast:15 / row_bcast:31 fold the rows into lane 63 (the rocPRIM gfx9 scheme), ~2.5x cheaper than six
+// ds_bpermute butterflies (tools/microbench/valu_rates.hip).
+// Three sums at once, the three DPP chains interleaved step by step: a DPP source written by the previous
+// VALU instruction costs wait states (the compiler pads a single chain with s_nop); with three independent
+// chains in lock-step the hazard is covered by real work.
+#define EVAC_DPP3(CTRL, MASK) a = dpp_add<CTRL, MASK>(a); b = dpp_add<CTRL, MASK>(b); c = dpp_add<CTRL, MASK>(c);
+__device__ __forceinline__ void wave_sum3(float& a, float& b, float& c) {
+    EVAC_DPP3(0x111, 0xf)
+    EVAC_DPP3(0x112, 0xf)
+    EVAC_DPP3(0x114, 0xf)
+    EVAC_DPP3(0x118, 0xf)
+    EVAC_DPP3(0x142, 0xa)
+    EVAC_DPP3(0x143, 0xc)
+    a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
+    b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 63));
+    c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), 63));
+}
+// Inclusive prefix sum over the 64 lanes (Hillis-Steele inside each 16-lane row with row_shr 1/2/4/8, then the
+// row totals carried across with row_bcast:15 / row_bcast:31).
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    v = dpp_addi<0x111, 0xf>(v);
+    v = dpp_addi<0x112, 0xf>(v);
+    v = dpp_addi<0x114, 0xf>(v);
+    v = dpp_addi<0x118, 0xf>(v);
+    v = dpp_addi<0x142, 0xa>(v);
+    v = dpp_addi<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ int wave_count(bool p) { return __popcll(__ballot(p)); }
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// 1-ulp hardware reciprocal / rsqrt / sqrt (v_rcp_f32, v_rsq_f32, v_sqrt_f32) instead of the ~10
+// instruction IEEE division / sqrt sequences: the parity bar is 1e-5, these are ~1e-7 relative.
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+// Neighbour weight 1.0 if |p_i - p_j|^2 < r^2 else 0.0 without a compare: with coordinates pre-scaled by
+// S = 2^40 (exact), r^2 S^2 - DX^2 - DY^2 = (r^2 - d^2) * 2^80 is evaluated by two FMAs, the second saturating
+// to [0,1] through the VOP3 clamp modifier.  Any non-zero difference of two f32 numbers near 0.01 is at least
+// ~1e-9, times 2^80 it is far above 1, so the result is exactly 1 or 0; an exact tie gives 0 (strict <, as
+// distances.py / area.py:107); NaN gives 0 (DX10 clamp); padding entries carry X = +inf -> -inf -> 0.
+// Two roundings sit between the true r^2 - d^2 and its sign -- the same tie sensitivity (~1e-9 in d) as
+// computing d^2 in f32 at all.  v_cmp + v_cndmask would cost ~3 slots (tools/microbench/valu_rates.hip).
+__device__ __forceinline__ float neighbour_weight(float DX, float DY, float r2_big) {
+    const float a = fmaf(-DY, DY, r2_big);
+    float w;
+    asm("v_fma_f32 %0, -%1, %1, %2 clamp" : "=v"(w) : "v"(DX), "v"(a));
+    return w;
+}
+
+// One (i, j) pair of the neighbour sum: 2 subtractions, 2 FMAs for the 0/1 weight, 2 FMAs (packed by the
+// compiler) for the heading sum.  (XI, YI) and t.x, t.y are the 2^40-scaled coordinates.
+__device__ __forceinline__ void pair_accumulate(float XI, float YI, f4 t, float r2b, float& sx, float& sy) {
+    const float w = neighbour_weight(XI - t.x, YI - t.y, r2b);
+    sx = fmaf(w, t.z, sx);
+    sy = fmaf(w, t.w, sy);
+}
+// The same pair with the unit heading stored as integers (heading * Params::head_scale, rounded): the weight's
+// bit pattern (0x3f800000 or 0) shifted down is the integer 1 or 0, and the sums are integer multiply-adds
+// (v_mad_i32_i24: |heading| <= 2^22).  Integer addition is exact, so the sum does not depend on the order in
+// which the peers are visited -- which is what lets the cell-list kernels place peers with LDS atomics.
+__device__ __forceinline__ void pair_accumulate_int(float XI, float YI, f4 t, float r2b, int& sx, int& sy) {
+    const float w = neighbour_weight(XI - t.x, YI - t.y, r2b);
+    const int wi = (int)(__builtin_bit_cast(unsigned, w) >> 29);
+    const float hz = t.z, hw = t.w;   // (bit_cast straight from a vector element picks element 0 with this compiler)
+    sx = __mul24(wi, __float_as_int(hz)) + sx;
+    sy = __mul24(wi, __float_as_int(hw)) + sy;
+}
+
+// x^k for a wave-uniform integer k in [1,63]: straight-line binary powering (no loop, no branches;
+// the selects take a wave-uniform condition).  A few ulp.
+__device__ __forceinline__ float powi(float x, int k) {
+    const float x2 = x * x, x4 = x2 * x2;
+    float r = (k & 1) ? x : 1.0f;
+    r *= (k & 2) ? x2 : 1.0f;
+    r *= (k & 4) ? x4 : 1.0f;
+    if (k & 56) {   // rare: alpha >= 6
+        const float x8 = x4 * x4, x16 = x8 * x8;
+        r *= (k & 8) ? x8 : 1.0f;
+        r *= (k & 16) ? x16 : 1.0f;
+        r *= (k & 32) ? x16 * x16 : 1.0f;
+    }
+    return r;
+}
+
+// sin/cos of the angular noise eta in [-noise_coef/2, noise_coef/2] (wave-uniform regime choice):
+//   |eta| <= 0.2   (noise_coef <= 0.4, the reference's default is 0.2): Taylor to x^5 / x^4, remainder < 3e-9
+//   |eta| <= pi/4  : Taylor to x^9 / x^10, remainder < 2e-9 relative
+//   otherwise      : ocml sincosf with full range reduction
+__device__ __forceinline__ void noise_sincos(float a, int regime, float& s, float& c) {
+    if (regime == 2) {
+        const float z = a * a;
+        float ps = fmaf(z, 8.3333333e-3f, -1.6666667e-1f);
+        ps = ps * z;
+        s = fmaf(ps, a, a);
+        float pc = fmaf(z, 4.1666667e-2f, -0.5f);
+        c = fmaf(pc, z, 1.0f);
+    } else if (regime == 1) {
+        const float z = a * a;
+        float ps = fmaf(z, 2.7557319e-6f, -1.9841270e-4f);
+        ps = fmaf(ps, z, 8.3333333e-3f);
+        ps = fmaf(ps, z, -1.6666667e-1f);
+        ps = ps * z;
+        s = fmaf(ps, a, a);
+        float pc = fmaf(z, -2.7557319e-7f, 2.4801587e-5f);
+        pc = fmaf(pc, z, -1.3888889e-3f);
+        pc = fmaf(pc, z, 4.1666667e-2f);
+        pc = fmaf(pc, z, -0.5f);
+        c = fmaf(pc, z, 1.0f);
+    } else {
+        sincosf(a, &s, &c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-lane / per-env register state
+// ------------------------------------------------------------------------------------------------
+struct Ped {
+    float x, y, dx, dy;
+    int st;   // status code; 0 on lanes beyond n_ped
+};
+struct Env {
+    float ax, ay, adx, ady;           // leader position / direction        area.py:12-30
+    int now, n_resets;                // Time.now, reset count               area.py:42-59
+    uint32_t total;                   // steps since creation (Philox counter; Time.overall_timesteps)
+    float acc_ret, acc_intr, acc_stat;   // env.py:65-67
+};
+struct StepOut {
+    float reward;
+    bool terminated, truncated;
+    int n_escaped, n_exiting, n_follower, n_viscek;
+    float gx, gy, ex, ey;   // gravity observation of the post-step state (GRAV kernels): ped sums, exit term * n_followers
+};
+struct Sums {
+    float f0, f1, f2;
+    int i[8];
+};
+
+// statuses.py:29-48 -- pure function of the position, the leader position and the exit.
+// `de` returns the distance to the exit (reused by the intrinsic reward, distances.py:51-56).
+__device__ __forceinline__ int classify(const Params& p, float x, float y, float ax, float ay, float& de,
+                                        float& lx, float& ly, float& dl2) {
+    lx = x - ax;
+    ly = y - ay;
+    dl2 = lx * lx + ly * ly;
+    const float ex = x - kExitX, ey = y - kExitY;
+    de = fsqrt(ex * ex + ey * ey);
+    int st = kViscek;
+    if (dl2 < kRLeader2) st = kFollower;
+    if (de < kRExit) st = kExiting;
+    if (de < kREscape) st = kEscaped;
+    return st;
+}
+
+// gravity_encoding.py:15-16,35-37:  -alpha / (|R| + eps)^(alpha+2) * R, with |R|^2 given
+__device__ __forceinline__ void grav_term2(const Params& p, float rx, float ry, float r2, float& gx, float& gy) {
+    const float nrm = fsqrt(r2) + p.eps;
+    const float pw = p.grav_pow_int ? powi(nrm, p.grav_pow_int) : powf(nrm, p.grav_pow);
+    const float c = p.neg_alpha * frcp(pw);
+    gx = c * rx;
+    gy = c * ry;
+}
+__device__ __forceinline__ void grav_term(const Params& p, float rx, float ry, float& gx, float& gy) {
+    grav_term2(p, rx, ry, rx * rx + ry * ry, gx, gy);
+}
+
+// Positions / statuses observations (abs | rel) x (no | ohe | cat) x (Dict | Box): env.py:98-104, wrappers.py:8-96.
+// Purely per-lane writes (lane i owns pedestrian row i; lane 0 also writes the agent and exit rows).
+__device__ __forceinline__ void write_obs_generic(const Params& p, int i, bool active, const Ped& q, const Env& e,
+                                                  float* __restrict__ obs) {
+    const bool rel = p.obs_pos == EVAC_POS_REL;
+    const float ihyp = 0.70710678118f;                                // wrappers.py:12-18: 1/sqrt(1+1)
+    float px = q.x, py = q.y, ex = kExitX, ey = kExitY;
+    if (rel) {                                                        // wrappers.py:20-27
+        px = (q.x - e.ax) * ihyp;
+        py = (q.y - e.ay) * ihyp;
+        ex = (kExitX - e.ax) * ihyp;
+        ey = (kExitY - e.ay) * ihyp;
+    }
+    const int code = 4 - q.st;                                        // wrappers.py:49
+    if (p.obs_box) {                                                  // wrappers.py:77-96
+        const int C = p.obs_stat == EVAC_STAT_OHE ? 6 : (p.obs_stat == EVAC_STAT_CAT ? 3 : 2);
+        if (i == 0) {
+            obs[0] = e.ax;
+            obs[1] = e.ay;
+            obs[C + 0] = ex;
+            obs[C + 1] = ey;
+            if (p.obs_stat == EVAC_STAT_OHE) {
+                obs[2] = obs[3] = obs[4] = obs[5] = 0.0f;
+                obs[C + 2] = 1.0f;
+                obs[C + 3] = obs[C + 4] = obs[C + 5] = 0.0f;
+            } else if (p.obs_stat == EVAC_STAT_CAT) {
+                obs[2] = 0.0f;
+                obs[C + 2] = 1.0f;
+            }
+        }
+        if (active) {
+            float* row = obs + (size_t)(i + 2) * C;
+            row[0] = px;
+            row[1] = py;
+            if (p.obs_stat == EVAC_STAT_OHE) {
+                row[2] = code == 0 ? 1.0f : 0.0f;
+                row[3] = code == 1 ? 1.0f : 0.0f;
+                row[4] = code == 2 ? 1.0f : 0.0f;
+                row[5] = code == 3 ? 1.0f : 0.0f;
+            } else if (p.obs_stat == EVAC_STAT_CAT) {
+                row[2] = (float)code * 0.25f;
+            }
+        }
+        return;
+    }
+    // Dict, flattened in gymnasium key order: agent, exit, pedestrians_positions, pedestrians_statuses
+    const int N = p.n_ped;
+    if (i == 0) {
+        obs[0] = e.ax;
+        obs[1] = e.ay;
+        obs[2] = ex;
+        obs[3] = ey;
+    }
+    if (active) {
+        obs[4 + 2 * i] = px;
+        obs[5 + 2 * i] = py;
+        float* st = obs + 4 + 2 * N;
+        if (p.obs_stat == EVAC_STAT_OHE) {                            // wrappers.py:50-54
+            st[4 * i + 0] = code == 0 ? 1.0f : 0.0f;
+            st[4 * i + 1] = code == 1 ? 1.0f : 0.0f;
+            st[4 * i + 2] = code == 2 ? 1.0f : 0.0f;
+            st[4 * i + 3] = code == 3 ? 1.0f : 0.0f;
+        } else if (p.obs_stat == EVAC_STAT_CAT) {                     // wrappers.py:55-56
+            st[i] = (float)code * 0.25f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// EvacuationEnv.reset: env.py:129-137, pedestrians.py:16-27, area.py:27-30, 49-51.
+// `draw` = the four U(-1,1) numbers of this pedestrian (pos.x, pos.y, dir.x, dir.y).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void reset_env(const Params& p, bool active, float4 draw, Ped& q, Env& e) {
+    e.ax = e.ay = e.adx = e.ady = 0.0f;
+    e.now = 0;
+    e.n_resets += 1;
+    e.acc_ret = e.acc_intr = e.acc_stat = 0.0f;
+    q.x = draw.x;
+    q.y = draw.y;
+    const float inrm = frsq(draw.z * draw.z + draw.w * draw.w);        // pedestrians.py:29-31
+    q.dx = draw.z * inrm;
+    q.dy = draw.w * inrm;
+    float de;
+    float lx, ly, dl2;
+    q.st = active ? classify(p, q.x, q.y, 0.0f, 0.0f, de, lx, ly, dl2) : 0;
+}
+
+__device__ __forceinline__ float4 philox_reset_draw(const Params& p, uint32_t env_gid, int i, int n_resets) {
+    const uint4 r = philox4x32_10(make_uint4(env_gid, (uint32_t)i, (uint32_t)n_resets, kStreamReset), p.seed_lo, p.seed_hi);
+    return make_float4(usym(r.x), usym(r.y), usym(r.z), usym(r.w));
+}
+__device__ __forceinline__ float philox_noise(const Params& p, uint32_t env_gid, int i, uint32_t total) {
+    const uint4 r = philox4x32_10(make_uint4(env_gid, (uint32_t)i, total >> 2, kStreamNoise), p.seed_lo, p.seed_hi);
+    const uint32_t sel = total & 3u;
+    const uint32_t w = sel == 0 ? r.x : (sel == 1 ? r.y : (sel == 2 ? r.z : r.w));
+    return (u01(w) - 0.5f) * p.noise_coef;                             // area.py:124: U(-c/2, c/2)
+}
+__device__ __forceinline__ float2 philox_action(const Params& p, uint32_t env_gid, uint32_t total) {
+    const uint4 r = philox4x32_10(make_uint4(env_gid, 0u, total, kStreamAction), p.seed_lo, p.seed_hi);
+    return make_float2(usym(r.x), usym(r.y));
+}
+
+// area.py:189-192: a /= |a| + eps ; agent.direction = step_size * a
+__device__ __forceinline__ float2 agent_direction(const Params& p, float act_x, float act_y) {
+    if (p.flags & kFlagClipAction) {                                  // gym.wrappers.ClipAction (rpo_agent.py:27), wave-uniform
+        act_x = __builtin_amdgcn_fmed3f(act_x, -1.0f, 1.0f);
+        act_y = __builtin_amdgcn_fmed3f(act_y, -1.0f, 1.0f);
+    }
+    const float inrm = frcp(fsqrt(act_x * act_x + act_y * act_y) + p.eps);   // area.py:190
+    return make_float2(p.step_size * (act_x * inrm), p.step_size * (act_y * inrm));
+}
+
+// ------------------------------------------------------------------------------------------------
+// state <-> HBM
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_env(const Params& p, int env, int i, bool active, Ped& q, Env& e) {
+    const float4 a = p.agent[env];
+    const int4 c = p.clock[env];
+    const float4 k = p.acc[env];
+    e.ax = a.x; e.ay = a.y; e.adx = a.z; e.ady = a.w;
+    e.now = c.x; e.n_resets = c.y; e.total = (uint32_t)c.z;
+    e.acc_ret = k.x; e.acc_intr = k.y; e.acc_stat = k.z;
+    if (active) {
+        const float4 v = p.ped[(size_t)env * p.n_ped + i];
+        q.x = v.x; q.y = v.y; q.dx = v.z; q.dy = v.w;
+        q.st = p.status[(size_t)env * p.n_ped + i];
+    } else {
+        q.x = q.y = q.dx = q.dy = 0.0f;
+        q.st = 0;
+    }
+}
+// `owner`: the lane that writes the per-env words
+__device__ __forceinline__ void store_env(const Params& p, int env, int i, bool active, bool owner, const Ped& q, const Env& e) {
+    if (active) {
+        p.ped[(size_t)env * p.n_ped + i] = make_float4(q.x, q.y, q.dx, q.dy);
+        p.status[(size_t)env * p.n_ped + i] = (uint8_t)q.st;
+    }
+    if (owner) {
+        p.agent[env] = make_float4(e.ax, e.ay, e.adx, e.ady);
+        p.clock[env] = make_int4(e.now, e.n_resets, (int)e.total, 0);
+        p.acc[env] = make_float4(e.acc_ret, e.acc_intr, e.acc_stat, 0.0f);
+    }
+}
+
+// the episode record: env.py:115-125 (nine keys) + Time.n_episodes
+__device__ __forceinline__ void write_stats(evac_episode_stats_t* dst, const Env& e, const StepOut& o) {
+    dst->episode_reward = e.acc_ret;
+    dst->episode_length = (float)e.now;
+    dst->episode_intrinsic_reward = e.acc_intr;
+    dst->episode_status_reward = e.acc_stat;
+    dst->escaped_pedestrians = (float)o.n_escaped;
+    dst->exiting_pedestrians = (float)o.n_exiting;
+    dst->following_pedestrians = (float)o.n_follower;
+    dst->viscek_pedestrians = (float)o.n_viscek;
+    dst->overall_timesteps = (int32_t)e.total;
+    dst->n_episodes = e.n_resets;
+}
+
+}  // namespace evac

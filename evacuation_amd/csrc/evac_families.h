@@ -1,0 +1,520 @@
+// Device code of libevac, part 2: the kernel FAMILIES -- how the lanes that own one env's pedestrians are grouped,
+// how they exchange what the step needs from each other, and how the only O(N^2) part, the Vicsek neighbour sum
+// (area.py:104-119 of the reference), is evaluated.  step_env (evac_device.h) is written once against this interface:
+//
+//   F::Smem, F::Ctx                 LDS block of a workgroup; "who am I" (env, slot, lane, pedestrian i, owner lane)
+//   F::kEnvUniform                  per-env values (counts, flags) are wave-uniform (false only for Sub)
+//   F::neighbour_sum(...)           heading sum over the moving pedestrians within the radius, per FOLLOWER/VISCEK lane
+//   F::reduce<GUARD>(...)           three float sums and up to eight predicate counts over the env's lanes
+//   F::exit_publish / exit_fetch    the gravity exit term evaluated by the env's first idle lane
+//
+//   Sub<G>     G = 16 / 32 lanes of a wave per env (N <= 16 / 32): 4 / 2 envs per wave, no barrier at all
+//   Wave<WPE>  WPE waves per env, all pairs: WPE = 1 for N <= 64 (4 envs per 256-thread workgroup, no workgroup
+//              barrier), one workgroup per env for WPE = 2..16
+//   Cells<WPE> one workgroup per env (N > 64) with a 16 x 16 cell list: peers are binned with LDS atomics, rows are
+//              re-dealt to lanes in cell order, each row scans only the 3 x 3 cells around it
+#pragma once
+
+#include "evac_common.h"
+
+namespace evac {
+
+// ------------------------------------------------------------------------------------------------
+// Wave<WPE>: all pairs, wave-uniform broadcast reads of a compacted LDS tile
+// ------------------------------------------------------------------------------------------------
+#ifndef EVAC_BLOCK1
+#define EVAC_BLOCK1 256
+#endif
+
+template <int WPE_>
+struct Wave {
+    static constexpr int WPE = WPE_;
+    static constexpr bool kEnvUniform = true;
+    static constexpr int kThreadsPerEnv = WPE * kWave;
+    // WPE == 1: several one-wave envs share a workgroup (no workgroup barrier is ever used there);
+    // WPE >= 2: exactly one env per workgroup, so that __syncthreads() is a per-env barrier
+    static constexpr int kBlock = WPE == 1 ? EVAC_BLOCK1 : kThreadsPerEnv;
+    static constexpr int kEnvsPerBlock = kBlock / kThreadsPerEnv;
+    static constexpr const char* kName = WPE == 1 ? "1 wave/env, all pairs" : (WPE == 2 ? "2 waves/env, all pairs" : (WPE == 4 ? "4 waves/env, all pairs" : (WPE == 8 ? "8 waves/env, all pairs" : "16 waves/env, all pairs")));
+
+    struct Smem {
+        f4 tile[kEnvsPerBlock][WPE * kWave];   // (x, y, ux, uy) of every pedestrian
+        f4 redf[kEnvsPerBlock][WPE];               // per-wave partial sums (reduce)
+        i4 redi[kEnvsPerBlock][WPE];               // per-wave partial counts, packed in pairs
+        int cols[kEnvsPerBlock][WPE];              // moving pedestrians per wave (tile compaction)
+        float exitg[kEnvsPerBlock][2];            // gravity exit term from the lane that computed it (WPE > 1)
+        // rollout outputs of up to kStageSteps steps, flushed with ONE 64-lane store (GRAV kernels)
+        alignas(16) float stage[kEnvsPerBlock][kStageSteps][12];   // rows written as two 16-byte vectors + 1 word
+    };
+
+    struct Ctx {
+        Smem& sm;
+        int env, slot, wave_in_env, lane, i;
+        bool owner;
+#ifdef EVAC_STAMP
+        StampState stamp;
+#endif
+        __device__ __forceinline__ explicit Ctx(Smem& s) : sm(s) {
+            const int t = threadIdx.x;
+            slot = t / kThreadsPerEnv;
+            const int tin = t - slot * kThreadsPerEnv;
+            wave_in_env = tin / kWave;
+            lane = tin & (kWave - 1);
+            i = tin;
+            env = blockIdx.x * kEnvsPerBlock + slot;
+            if constexpr (WPE == 1) {   // wave-uniform by construction: let the compiler keep it in SGPRs
+                env = __builtin_amdgcn_readfirstlane(env);
+                slot = __builtin_amdgcn_readfirstlane(slot);
+            }
+            owner = i == 0;
+        }
+    };
+
+    // Sync the WPE waves of one env.  WPE == 1: a wave is in lock-step; only keep the compiler from
+    // moving LDS accesses across the point.  WPE > 1: one env per workgroup, so a workgroup barrier.
+    static __device__ __forceinline__ void sync() {
+        if constexpr (WPE == 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __syncthreads();
+        }
+    }
+
+    static __device__ __forceinline__ void init(Ctx&) {}
+
+    // Reduce 3 floats and up to 8 predicates over all lanes of the env.  Result in every lane.
+    // GUARD: a barrier in front, for callers whose previous reduction may still be read by another wave.
+    // WPE > 1: every wave leaves one 32-byte record (three sums, eight counts packed in pairs -- a count is at most
+    // 1024); after the barrier lane w of every wave reads record w and the records are folded with DPP row_shr steps
+    // (a fixed tree: deterministic), 2 LDS reads per wave instead of 11 * WPE.
+    template <bool GUARD, class C>
+    static __device__ __forceinline__ void reduce(C& c, Sums& s, const bool (&pred)[8]) {
+        wave_sum3(s.f0, s.f1, s.f2);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s.i[k] = wave_count(pred[k]);
+        if constexpr (WPE > 1) {
+            auto& sm = c.sm;
+            if constexpr (GUARD) __syncthreads();   // previous users of the records are done
+            if (c.lane == 0) {
+                sm.redf[c.slot][c.wave_in_env] = f4{s.f0, s.f1, s.f2, 0.0f};
+                sm.redi[c.slot][c.wave_in_env] = i4{s.i[0] | (s.i[1] << 16), s.i[2] | (s.i[3] << 16), s.i[4] | (s.i[5] << 16), s.i[6] | (s.i[7] << 16)};
+            }
+            __syncthreads();
+            const int w = c.lane < WPE ? c.lane : WPE - 1;
+            f4 rf = sm.redf[c.slot][w];
+            i4 ri = sm.redi[c.slot][w];
+#define EVAC_RED_STEP(CTRL)                                                                                      \
+    rf.x = dpp_add<CTRL, 0xf>(rf.x); rf.y = dpp_add<CTRL, 0xf>(rf.y); rf.z = dpp_add<CTRL, 0xf>(rf.z);           \
+    ri.x = dpp_addi<CTRL, 0xf>(ri.x); ri.y = dpp_addi<CTRL, 0xf>(ri.y); ri.z = dpp_addi<CTRL, 0xf>(ri.z);        \
+    ri.w = dpp_addi<CTRL, 0xf>(ri.w);
+            EVAC_RED_STEP(0x111)
+            if constexpr (WPE > 2) { EVAC_RED_STEP(0x112) }
+            if constexpr (WPE > 4) { EVAC_RED_STEP(0x114) }
+            if constexpr (WPE > 8) { EVAC_RED_STEP(0x118) }
+#undef EVAC_RED_STEP
+            s.f0 = readlane_f(rf.x, WPE - 1);
+            s.f1 = readlane_f(rf.y, WPE - 1);
+            s.f2 = readlane_f(rf.z, WPE - 1);
+            const int a = __builtin_amdgcn_readlane(ri.x, WPE - 1), b = __builtin_amdgcn_readlane(ri.y, WPE - 1);
+            const int d = __builtin_amdgcn_readlane(ri.z, WPE - 1), g = __builtin_amdgcn_readlane(ri.w, WPE - 1);
+            s.i[0] = a & 0xffff; s.i[1] = a >> 16;
+            s.i[2] = b & 0xffff; s.i[3] = b >> 16;
+            s.i[4] = d & 0xffff; s.i[5] = d >> 16;
+            s.i[6] = g & 0xffff; s.i[7] = g >> 16;
+        }
+    }
+
+    // The gravity exit term is evaluated by the env's first idle lane (i == N) with the pedestrians' instructions.
+    template <class C>
+    static __device__ __forceinline__ void exit_publish(C& c, bool exit_lane, float gx, float gy) {
+        if constexpr (WPE > 1) {
+            if (exit_lane) {
+                c.sm.exitg[c.slot][0] = gx;
+                c.sm.exitg[c.slot][1] = gy;
+            }
+        }
+    }
+    template <class C>
+    static __device__ __forceinline__ void exit_fetch(C& c, float gx, float gy, int src_i, float& ex, float& ey) {
+        if constexpr (WPE == 1) {
+            ex = readlane_f(gx, src_i);
+            ey = readlane_f(gy, src_i);
+        } else {
+            ex = c.sm.exitg[c.slot][0];       // written before reduce's barrier
+            ey = c.sm.exitg[c.slot][1];
+        }
+    }
+
+    // Vicsek neighbour sum, all pairs: area.py:99-119.  `sx, sy` = sum of the unit headings of the moving
+    // pedestrians within the radius (the count n_intersections only rescales the mean heading, which arctan2
+    // ignores; it is not needed).
+    static __device__ __forceinline__ void neighbour_sum(const Params& p, Ctx& c, const Ped& q, bool efv, bool fv,
+                                                         float ux, float uy, float& sx, float& sy) {
+        auto& sm = c.sm;
+        sync();   // tile readers of the previous step are done
+        // The tile holds the moving pedestrians first, compacted in ascending pedestrian order -- the columns
+        // pos[efv] of the reference's distance matrix (area.py:99-106) -- then the others as padding with
+        // weight 0 (X = +inf) and heading 0.  Every lane writes exactly one entry.  Under a
+        // RandomAgent most pedestrians have escaped by mid-episode, so the all-pairs loop shrinks from N to
+        // n_efv iterations.
+        int n_cols;
+        {
+            const unsigned long long m = __ballot(efv);
+            int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            n_cols = __popcll(m);
+            if constexpr (WPE > 1) {
+                if (c.lane == 0) sm.cols[c.slot][c.wave_in_env] = n_cols;
+                __syncthreads();
+                int tot = 0, base = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < WPE; ++w2) {
+                    const int k = sm.cols[c.slot][w2];
+                    base += (w2 < c.wave_in_env) ? k : 0;
+                    tot += k;
+                }
+                n_cols = tot;
+                before += base;                                                 // moving pedestrians before this one
+            }
+            const int tid = c.wave_in_env * kWave + c.lane;
+            const int idx = efv ? before : n_cols + (tid - before);             // a bijection onto [0, WPE*64)
+            sm.tile[c.slot][idx] = f4{efv ? q.x * kTileScale : __builtin_inff(), q.y * kTileScale, efv ? ux : 0.0f, efv ? uy : 0.0f};
+        }
+        sync();   // tile complete
+        EVAC_T(c, 2);   // tile write
+        // rows of the distance matrix exist only for FOLLOWER/VISCEK pedestrians (area.py:104)
+        bool any_fv;
+        if constexpr (WPE == 1) any_fv = __ballot(fv) != 0ull;
+        else any_fv = true;   // (a workgroup-wide OR would cost a barrier; the loop is short when n_cols is)
+        sx = 0.0f;
+        sy = 0.0f;
+        // Branch-free batches: the B wave-uniform ds_read_b128 broadcasts are issued back to
+        // back (LDS latency paid once per batch, no VALU slot), then 6 full-rate VALU ops per pair.
+        const f4* __restrict__ tile = sm.tile[c.slot];
+        const int n8 = __builtin_amdgcn_readfirstlane(any_fv ? ((n_cols + 3) & ~3) : 0);   // no rows -> no loop
+        const float r2b = kRPed2Big;
+        const float XI = q.x * kTileScale, YI = q.y * kTileScale;
+        // peers per LDS round trip: 16 where registers allow (1-wave kernels: 3.31 vs 3.34 us at 8, 3.49 at 4),
+        // 8 in the multi-wave kernels, 4 in the 1024-thread one whose workgroup size caps it at 128 VGPRs
+        constexpr int B = WPE <= 2 ? 16 : (WPE == 16 ? 4 : 8);
+        int j = 0;
+        if constexpr (!(EVAC_ABLATE & 1)) {
+            for (; j + B <= n8; j += B) {      // full batches
+                f4 t[B];
+#pragma unroll
+                for (int k = 0; k < B; ++k) t[k] = tile[j + k];
+#pragma unroll
+                for (int k = 0; k < B; ++k) pair_accumulate(XI, YI, t[k], r2b, sx, sy);
+            }
+            for (; j < n8; j += 4) {           // remainder in groups of 4 (n8 is a multiple of 4)
+                f4 t[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pair_accumulate(XI, YI, t[k], r2b, sx, sy);
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Cells<WPE>: one workgroup per env, 16 x 16 cell list.
+//
+// Every step:
+//   1. each moving pedestrian (E | F | V) takes a ticket in its cell's counter (ds_add_rtn; the order of arrival is
+//      arbitrary);                                                                         -- barrier
+//   2. wave 0 turns the 256 counters into an exclusive prefix (start[]) and clears them;    -- barrier
+//   3. each moving pedestrian writes (X, Y, heading) to tile[start[cell] + ticket] and who[slot] = (i, cell):
+//      the tile now lists the moving pedestrians cell by cell (x-major);                    -- barrier
+//   4. ROWS ARE RE-DEALT IN TILE ORDER: the thread with workgroup index s evaluates the row of the pedestrian in tile
+//      slot s.  Its peers within the radius lie in the 3 x 3 cells around its own, i.e. in three runs of three
+//      consecutive cells (c-17..c-15, c-1..c+1, c+15..c+17 in x-major cell numbers; where a run wraps around the end
+//      of a cell column it only picks up a few extra, harmless candidates).  The lane sweeps the three slot ranges
+//      in ascending order, 4 entries per LDS round trip; reading past the end of a run is harmless (the extra
+//      entries are real pedestrians that are tested like any other, or +inf padding behind the last one) as long as
+//      no slot is visited twice -- the next run starts where the previous batch ended if that is later.
+//      Lanes of a wave own neighbouring cells, so their trip counts are similar and waves behind the last moving
+//      pedestrian do nothing.  The heading sums are INTEGERS (pair_accumulate_int): exact, hence independent of
+//      the arbitrary ticket order, so results are reproducible bit for bit.
+//      The row result goes to res[i] of the pedestrian it belongs to;                        -- barrier
+//   5. every pedestrian reads its own res[i].
+// A NaN heading (0/0, area.py:101) poisons every row in the reference (NaN * 0, area.py:118-119); here such a
+// pedestrian bumps counter 256 and every row adds NaN when that count is non-zero.
+// ------------------------------------------------------------------------------------------------
+template <int WPE_>
+struct Cells {
+    static constexpr int WPE = WPE_;
+    static_assert(WPE >= 2, "Cells is a workgroup-per-env family");
+    static constexpr bool kEnvUniform = true;
+    static constexpr int kThreadsPerEnv = WPE * kWave;
+    static constexpr int kBlock = kThreadsPerEnv;
+    static constexpr int kEnvsPerBlock = 1;
+    static constexpr int kPad = 8;   // +inf entries behind the last moving pedestrian (>= entries per batch)
+    static constexpr const char* kName = WPE == 2 ? "2 waves/env, cell list" : (WPE == 4 ? "4 waves/env, cell list" : (WPE == 8 ? "8 waves/env, cell list" : "16 waves/env, cell list"));
+
+    struct Smem {
+        f4 tile[1][kThreadsPerEnv + kPad];
+        alignas(16) int cnt[kCells + 4];      // tickets per cell; [256] = pedestrians with a NaN heading
+        alignas(16) int start[kCells + 4];    // exclusive prefix of cnt; [256] = moving pedestrians, [257] = NaN headings
+        int who[kThreadsPerEnv];              // tile slot -> pedestrian | cell << 16
+        i2 res[kThreadsPerEnv];               // pedestrian -> integer heading sums of its row
+        f4 redf[1][WPE];
+        i4 redi[1][WPE];
+        float exitg[1][2];
+        alignas(16) float stage[1][kStageSteps][12];
+    };
+
+    struct Ctx {
+        Smem& sm;
+        int env, slot, wave_in_env, lane, i;
+        bool owner;
+#ifdef EVAC_STAMP
+        StampState stamp;
+#endif
+        __device__ __forceinline__ explicit Ctx(Smem& s) : sm(s) {
+            const int t = threadIdx.x;
+            slot = 0;
+            wave_in_env = t / kWave;
+            lane = t & (kWave - 1);
+            i = t;
+            env = blockIdx.x;
+            owner = i == 0;
+        }
+    };
+
+    static __device__ __forceinline__ void sync() { __syncthreads(); }
+
+    // Once per kernel, before the first step: the counters start at zero (afterwards the prefix wave clears them).
+    static __device__ __forceinline__ void init(Ctx& c) {
+        for (int k = c.i; k < kCells + 4; k += kThreadsPerEnv) c.sm.cnt[k] = 0;
+        __syncthreads();
+    }
+
+    template <bool GUARD, class C>
+    static __device__ __forceinline__ void reduce(C& c, Sums& s, const bool (&pred)[8]) {
+        Wave<WPE>::template reduce<GUARD>(c, s, pred);
+    }
+    template <class C>
+    static __device__ __forceinline__ void exit_publish(C& c, bool exit_lane, float gx, float gy) {
+        Wave<WPE>::exit_publish(c, exit_lane, gx, gy);
+    }
+    template <class C>
+    static __device__ __forceinline__ void exit_fetch(C& c, float gx, float gy, int src_i, float& ex, float& ey) {
+        Wave<WPE>::exit_fetch(c, gx, gy, src_i, ex, ey);
+    }
+
+    static __device__ __forceinline__ int cell_of(const Params& p, float x, float y) {
+        // monotone in x and in y; the float -> int conversion saturates and maps NaN to 0
+        int cx = (int)((x + p.cell_ox) * p.cell_inv_hx), cy = (int)((y + p.cell_oy) * p.cell_inv_hy);
+        cx = min(max(cx, 0), kCellsX - 1);
+        cy = min(max(cy, 0), kCellsY - 1);
+        return cx * kCellsY + cy;
+    }
+
+    static __device__ __forceinline__ void neighbour_sum(const Params& p, Ctx& c, const Ped& q, bool efv, bool fv,
+                                                         float ux, float uy, float& sx, float& sy) {
+        auto& sm = c.sm;
+        // ---- 1. tickets ----
+        const int cell = cell_of(p, q.x, q.y);
+        int ticket = 0;
+        if (efv) {
+            ticket = atomicAdd(&sm.cnt[cell], 1);                                 // ds_add_rtn_u32
+            if (ux != ux || uy != uy) atomicAdd(&sm.cnt[kCells], 1);              // rare: the reference's NaN poisoning
+        }
+        __syncthreads();
+        // ---- 2. exclusive prefix over the 256 cells by wave 0 (4 cells per lane), counters cleared ----
+        if (c.wave_in_env == 0) {
+            const i4 v = *(const i4*)&sm.cnt[4 * c.lane];
+            const int p1 = v.x, p2 = p1 + v.y, p3 = p2 + v.z, tot = p3 + v.w;
+            const int incl = wave_inclusive_scan(tot);
+            const int ex = incl - tot;
+            *(i4*)&sm.start[4 * c.lane] = i4{ex, ex + p1, ex + p2, ex + p3};
+            *(i4*)&sm.cnt[4 * c.lane] = i4{0, 0, 0, 0};
+            if (c.lane == kWave - 1) {
+                sm.start[kCells] = incl;                                           // moving pedestrians
+                sm.start[kCells + 1] = sm.cnt[kCells];
+                sm.cnt[kCells] = 0;
+            }
+        }
+        __syncthreads();
+        // ---- 3. the tile in cell order ----
+        const int n_cols = sm.start[kCells];
+        const int n_nan = sm.start[kCells + 1];
+        if (efv) {
+            const int s = sm.start[cell] + ticket;
+            const float hs = p.head_scale;
+            const int hx = (int)__builtin_rintf(ux * hs), hy = (int)__builtin_rintf(uy * hs);
+            sm.tile[0][s] = f4{q.x * kTileScale, q.y * kTileScale, __builtin_bit_cast(float, hx), __builtin_bit_cast(float, hy)};
+            sm.who[s] = c.i | (cell << 16);
+        }
+        if (c.i < kPad) sm.tile[0][n_cols + c.i] = f4{__builtin_inff(), 0.0f, 0.0f, 0.0f};
+        __syncthreads();
+        EVAC_T(c, 2);   // binning
+        // ---- 4. rows in tile order ----
+        if constexpr (!(EVAC_ABLATE & 1)) {
+            const int s = c.i;
+            if (s < n_cols) {
+                const f4 me = sm.tile[0][s];
+                const int wc = sm.who[s];
+                const int rc = wc >> 16;
+                int lo[3], hi[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int c0 = rc + (r - 1) * kCellsY - 1;
+                    lo[r] = sm.start[min(max(c0, 0), kCells)];
+                    hi[r] = sm.start[min(max(c0 + 3, 0), kCells)];
+                }
+                int ax = 0, ay = 0;
+                int j = lo[0];
+                const f4* __restrict__ tile = sm.tile[0];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    j = max(j, lo[r]);
+                    while (j < hi[r]) {
+                        f4 t[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) pair_accumulate_int(me.x, me.y, t[k], kRPed2Big, ax, ay);
+                        j += 4;
+                    }
+                }
+                sm.res[wc & 0xffff] = i2{ax, ay};
+            }
+        }
+        __syncthreads();
+        // ---- 5. back to the owner of the pedestrian ----
+        const i2 r = sm.res[c.i];
+        sx = fv ? (float)r.x : 0.0f;       // lanes without a row (not moving) hold stale words: unused
+        sy = fv ? (float)r.y : 0.0f;
+        if (n_nan != 0) sx = sy = __builtin_nanf("");
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Sub<G>: G lanes of a wave per env (G = 32 for N <= 32, G = 16 for N <= 16), i.e. 2 or 4 independent envs
+// per 64-lane wave.  The reference's default is number_of_pedestrians = 10 (src/env/env/config.py:11); with one
+// wave per env 54 of 64 lanes would idle.  What is "wave-uniform" in Wave<1> is "group-uniform" here:
+//   * votes / counts: the 64-bit ballot is masked to the group's lanes (popcount / mbcnt on the masked word);
+//   * float sums: DPP row_shr 1/2/4/8 reduce each 16-lane row (= a whole G=16 group), one row_bcast:15 joins
+//     the two rows of a G=32 group; the total lands in the group's LAST lane, which therefore owns the
+//     per-env outputs (reward, observation, state write-back);
+//   * values that Wave<1> fetches with v_readlane come through ds_bpermute from a per-group source lane.
+// There is no workgroup barrier anywhere (a wave is in lock-step).
+// ------------------------------------------------------------------------------------------------
+template <int G_>
+struct Sub {
+    static constexpr int G = G_;
+    static_assert(G == 16 || G == 32, "sub-wave groups are 16 or 32 lanes");
+    static constexpr bool kEnvUniform = false;
+    static constexpr int kThreadsPerEnv = G;
+    static constexpr int kEnvsPerWave = kWave / G;
+    static constexpr int kBlock = 256;
+    static constexpr int kEnvsPerBlock = (kBlock / kWave) * kEnvsPerWave;
+    static constexpr unsigned long long kGroupBits = G == 32 ? 0xffffffffull : 0xffffull;
+    static constexpr const char* kName = G == 16 ? "4 envs/wave, all pairs" : "2 envs/wave, all pairs";
+
+    struct Smem {
+        f4 tile[kEnvsPerBlock][G];   // per env: moving pedestrians first, then zero-weight padding
+    };
+
+    struct Ctx {
+        Smem& sm;
+        int env, slot, lane, sub, i;
+        unsigned long long gmask;   // this group's lanes in a 64-bit ballot
+        bool owner;                 // the group's last lane: the DPP sums are valid there
+#ifdef EVAC_STAMP
+        StampState stamp;
+#endif
+        __device__ __forceinline__ explicit Ctx(Smem& s) : sm(s) {
+            const int t = threadIdx.x;
+            lane = t & (kWave - 1);
+            sub = lane / G;
+            i = lane - sub * G;
+            slot = (t / kWave) * kEnvsPerWave + sub;
+            env = blockIdx.x * kEnvsPerBlock + slot;
+            gmask = kGroupBits << (sub * G);
+            owner = i == G - 1;
+        }
+    };
+
+    static __device__ __forceinline__ void sync() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    static __device__ __forceinline__ int count(unsigned long long m, unsigned long long gmask) { return __popcll(m & gmask); }
+    // number of set lanes of the group below this lane
+    static __device__ __forceinline__ int rank(unsigned long long m, unsigned long long gmask) {
+        const unsigned long long g = m & gmask;
+        return __builtin_amdgcn_mbcnt_hi((unsigned)(g >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)g, 0u));
+    }
+    // value held by lane `src_i` of this lane's group
+    static __device__ __forceinline__ float fetch(float v, int sub_base, int src_i) { return __shfl(v, sub_base + src_i, kWave); }
+
+    // Sums valid in the group's last lane (three chains interleaved, see wave_sum3); counts in every lane of the group.
+    template <bool GUARD, class C>
+    static __device__ __forceinline__ void reduce(C& c, Sums& s, const bool (&pred)[8]) {
+        float &a = s.f0, &b = s.f1, &cc = s.f2;
+        {
+            float& c = cc;
+            EVAC_DPP3(0x111, 0xf)
+            EVAC_DPP3(0x112, 0xf)
+            EVAC_DPP3(0x114, 0xf)
+            EVAC_DPP3(0x118, 0xf)
+            if constexpr (G == 32) { EVAC_DPP3(0x142, 0xa) }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s.i[k] = count(__ballot(pred[k]), c.gmask);
+    }
+    template <class C>
+    static __device__ __forceinline__ void exit_publish(C&, bool, float, float) {}
+    template <class C>
+    static __device__ __forceinline__ void exit_fetch(C& c, float gx, float gy, int src_i, float& ex, float& ey) {
+        ex = fetch(gx, c.sub * G, src_i);
+        ey = fetch(gy, c.sub * G, src_i);
+    }
+
+    static __device__ __forceinline__ void neighbour_sum(const Params& p, Ctx& c, const Ped& q, bool efv, bool fv,
+                                                         float ux, float uy, float& sx, float& sy) {
+        auto& sm = c.sm;
+        sync();   // tile readers of the previous step are done
+        const unsigned long long m_efv = __ballot(efv);
+        const int n_cols = count(m_efv, c.gmask);
+        {
+            const int before = rank(m_efv, c.gmask);
+            const int idx = efv ? before : n_cols + (c.i - before);     // a bijection onto the group's G slots
+            sm.tile[c.slot][idx] = f4{efv ? q.x * kTileScale : __builtin_inff(), q.y * kTileScale, efv ? ux : 0.0f, efv ? uy : 0.0f};
+        }
+        sync();
+        sx = 0.0f;
+        sy = 0.0f;
+        // the loop runs to the largest column count of the wave's groups (wave-uniform); the padding entries
+        // of smaller groups weigh 0
+        int nmax = 0;
+#pragma unroll
+        for (int g = 0; g < kEnvsPerWave; ++g) {
+            const int k = __popcll((m_efv >> (g * G)) & kGroupBits);
+            nmax = k > nmax ? k : nmax;
+        }
+        const int n4 = (__ballot(fv) != 0ull) ? ((nmax + 3) & ~3) : 0;
+        const f4* __restrict__ tile = sm.tile[c.slot];           // per lane: its group's tile
+        const float XI = q.x * kTileScale, YI = q.y * kTileScale;
+        int j = 0;
+        for (; j + 8 <= n4; j += 8) {
+            f4 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = tile[j + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pair_accumulate(XI, YI, t[k], kRPed2Big, sx, sy);
+        }
+        for (; j < n4; j += 4) {
+            f4 t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pair_accumulate(XI, YI, t[k], kRPed2Big, sx, sy);
+        }
+    }
+};
+
+}  // namespace evac

@@ -21,8 +21,56 @@ from . import _lib
 from .config import EnvConfig, EnvWrappersConfig, obs_dim, to_c_config
 from .spaces import Box, Dict
 
+# evac_episode_stats_t (include/evac.h): the nine keys of the reference's per-episode logging dict (env.py:115-125)
+# + Time.n_episodes.  Words 0-7 are floats, words 8-9 int32 (read them through ``stats_int_view``).
 STATS_FIELDS = ("episode_reward", "episode_length", "episode_intrinsic_reward", "episode_status_reward",
                 "escaped_pedestrians", "exiting_pedestrians", "following_pedestrians", "viscek_pedestrians")
+STATS_INT_FIELDS = ("overall_timesteps", "n_episodes")
+STATS_WORDS = _lib.EPISODE_STATS_WORDS
+
+
+def stats_int_view(stats: torch.Tensor) -> torch.Tensor:
+    """The integer words (overall_timesteps, n_episodes) of an episode-stats tensor [..., 10] as int32 [..., 2]."""
+    return stats.view(torch.int32)[..., len(STATS_FIELDS):]
+
+
+class StepInfos(dict):
+    """``infos`` of a vector step.  Holds the device tensors (``final_observation``, ``episode_stats``; rows are
+    meaningful where terminated | truncated) and, like gymnasium 0.29's SyncVectorEnv, answers ``"final_info" in
+    infos`` / ``infos["final_info"]`` / ``infos["_final_info"]`` -- what the reference trainer iterates
+    (rpo_agent.py:198-203) -- WITHOUT an extra call: the list is built on first access (one small device-to-host
+    read of the flags; nothing is read if the trainer never asks)."""
+
+    _LAZY = ("final_info", "_final_info")
+
+    def __init__(self, env, terminated, truncated, **kw):
+        super().__init__(**kw)
+        self._env, self._term, self._trunc = env, terminated, truncated
+        self._done = None
+
+    def _done_mask(self):
+        if self._done is None:
+            self._done = ((self._term != 0) | (self._trunc != 0)).cpu().numpy()
+        return self._done
+
+    def __contains__(self, key):
+        if key in self._LAZY and not dict.__contains__(self, key):
+            return bool(self._done_mask().any())
+        return dict.__contains__(self, key)
+
+    def __missing__(self, key):
+        if key not in self._LAZY or not self._done_mask().any():
+            raise KeyError(key)
+        done = self._done_mask()
+        self["final_info"] = np.array(self._env.final_info_list(self, done=done), dtype=object)
+        self["_final_info"] = done.copy()
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -118,7 +166,8 @@ class BatchedEvacuationEnv:
         self.terminated = torch.zeros((E,), dtype=torch.uint8, device=dev)
         self.truncated = torch.zeros((E,), dtype=torch.uint8, device=dev)
         self.final_obs = torch.zeros((E, self.obs_dim), dtype=torch.float32, device=dev)
-        self.final_stats = torch.zeros((E, len(STATS_FIELDS)), dtype=torch.float32, device=dev)
+        self.final_stats = torch.zeros((E, STATS_WORDS), dtype=torch.float32, device=dev)
+        self.stats_words = STATS_WORDS
         self.single_action_space = Box(-1.0, 1.0, (2,), np.float32)            # env.py:69
         self.single_observation_space = observation_space_for(env_config, self.wrap_config)
         self.action_space = Box(-1.0, 1.0, (E, 2), np.float32)
@@ -168,9 +217,14 @@ class BatchedEvacuationEnv:
         self._was_reset = True
         return self.obs, {}
 
-    def step(self, actions, noise=None):
+    def step(self, actions, noise=None, *, out_obs=None, out_reward=None, out_terminated=None, out_truncated=None):
         """EvacuationEnv.step + wrappers for the batch (env.py:141-171).  ``actions`` [E,2] f32 on
-        the device; ``noise`` [E,N] injects the per-pedestrian angular noise (parity tests)."""
+        the device; ``noise`` [E,N] injects the per-pedestrian angular noise (parity tests).
+
+        Destination form (the trainer's rollout storage, rpo_agent.py:158-163,182-196): ``out_obs`` [E,D] f32,
+        ``out_reward`` [E] f32, ``out_terminated`` / ``out_truncated`` [E] uint8 are written by the kernel itself
+        -- e.g. ``out_obs=obs_buf[t + 1]``, ``out_reward=rewards[t]`` -- so the step needs no copy into the
+        buffers afterwards.  Contiguous rows of the caller's tensors; the returned tensors are those."""
         E, N = self.num_envs, self.n_ped
         if isinstance(actions, torch.Tensor) and actions.device == self.device and actions.dtype == torch.float32 \
                 and actions.is_contiguous() and tuple(actions.shape) == (E, 2):
@@ -178,18 +232,44 @@ class BatchedEvacuationEnv:
         else:
             act = self._as_device(actions, (E, 2), torch.float32, "actions")
         nz = self._as_device(noise, (E, N), torch.float32, "noise")
-        _lib.check(self.lib.evac_step(self._h, _ptr(act), _ptr(nz), _ptr(self.obs), _ptr(self.reward),
-                                      _ptr(self.terminated), _ptr(self.truncated), int(self.autoreset),
+        obs = self.obs if out_obs is None else self._check_tensor(out_obs, (E, self.obs_dim), torch.float32, "out_obs")
+        rew = self.reward if out_reward is None else self._check_tensor(out_reward, (E,), torch.float32, "out_reward")
+        term = self.terminated if out_terminated is None else self._check_tensor(out_terminated, (E,), torch.uint8, "out_terminated")
+        trunc = self.truncated if out_truncated is None else self._check_tensor(out_truncated, (E,), torch.uint8, "out_truncated")
+        _lib.check(self.lib.evac_step(self._h, _ptr(act), _ptr(nz), _ptr(obs), _ptr(rew), _ptr(term), _ptr(trunc),
+                                      int(self.autoreset),
                                       _ptr(self.final_obs) if self.autoreset else None,
                                       _ptr(self.final_stats) if self.autoreset else None, self._stream()), self._h)
         infos = {}
         if self.autoreset:
-            # device tensors; rows are meaningful where terminated | truncated (no host sync here)
-            infos = {"final_observation": self.final_obs, "episode_stats": self.final_stats}
-        return self.obs, self.reward, self.terminated, self.truncated, infos
+            # device tensors; rows are meaningful where terminated | truncated (no host sync unless "final_info" is asked for)
+            infos = StepInfos(self, term, trunc, final_observation=self.final_obs, episode_stats=self.final_stats)
+        return obs, rew, term, trunc, infos
+
+    def kernel_variant(self, mode: str = "rollout") -> str:
+        """Name of the kernel instantiation behind ``step`` ("step") or ``rollout`` ("rollout")."""
+        return self.lib.evac_kernel_variant(self._h, 1 if mode == "rollout" else 0).decode()
+
+    def rollout_launcher(self, n_steps: int, out: TDict):
+        """A zero-argument callable that enqueues ``rollout(n_steps, out=out)`` (RandomAgent actions) on the
+        current stream with all ctypes arguments prepared once: for loops that launch the same shape many times."""
+        T, E, D = int(n_steps), self.num_envs, self.obs_dim
+        slab = self._check_tensor(out["slab"], (T, E, D + 3), torch.float32, "slab")
+        stats = out.get("episode_stats")
+        if stats is not None:
+            self._check_tensor(stats, (T, E, STATS_WORDS), torch.float32, "episode_stats")
+        fn, h = self.lib.evac_rollout, self._h
+        a_slab, a_stats, dev = _ptr(slab), _ptr(stats), self.device
+        cur = torch.cuda.current_stream
+
+        def launch():
+            rc = fn(h, T, None, None, a_slab, a_stats, 0, None, None, C.c_void_p(cur(dev).cuda_stream))
+            if rc != 0:
+                _lib.check(rc, h)
+        return launch
 
     def rollout(self, n_steps: int, actions=None, record_actions: bool = False, out: Optional[TDict] = None,
-                capture_envs: int = 0):
+                capture_envs: int = 0, noise=None):
         """``n_steps`` env steps in ONE kernel launch with the state held in registers (the
         rollout loop rpo_agent.py:180-203 with given or RandomAgent actions).  The kernel writes one
         packed time-major slab ``[T,E,D+3] = [obs | reward | terminated | truncated]`` (f32); the
@@ -198,12 +278,13 @@ class BatchedEvacuationEnv:
         episode ended), ``actions [T,E,2]`` if recorded.  Pass a previous result as ``out`` to reuse it.
         ``capture_envs=K`` additionally records the trajectories of the first K envs for rendering
         (what ``Pedestrians.save`` / ``Agent.save`` keep in the reference): ``trajectory [T,K,N+1,3]`` with
-        views ``positions [T,K,N,2]``, ``statuses [T,K,N]`` and ``agent_positions [T,K,2]``."""
+        views ``positions [T,K,N,2]``, ``statuses [T,K,N]`` and ``agent_positions [T,K,2]``.
+        ``noise`` [T,E,N] injects the per-pedestrian angular noise (parity tests; diagnostic kernel face)."""
         T, E, D = int(n_steps), self.num_envs, self.obs_dim
         dev = self.device
         if out is None:
             out = {"slab": torch.empty((T, E, D + 3), dtype=torch.float32, device=dev),
-                   "episode_stats": torch.zeros((T, E, len(STATS_FIELDS)), dtype=torch.float32, device=dev)}
+                   "episode_stats": torch.zeros((T, E, STATS_WORDS), dtype=torch.float32, device=dev)}
             if record_actions:
                 out["actions"] = torch.empty((T, E, 2), dtype=torch.float32, device=dev)
             if capture_envs:
@@ -220,8 +301,9 @@ class BatchedEvacuationEnv:
             self._check_tensor(traj, (T, k_cap, self.n_ped + 1, 3), torch.float32, "trajectory")
             out["positions"], out["statuses"] = traj[:, :, :self.n_ped, 0:2], traj[:, :, :self.n_ped, 2]
             out["agent_positions"] = traj[:, :, self.n_ped, 0:2]
+        nz = self._as_device(noise, (T, E, self.n_ped), torch.float32, "noise")
         _lib.check(self.lib.evac_rollout(self._h, T, _ptr(act), _ptr(out.get("actions")), _ptr(slab),
-                                         _ptr(out.get("episode_stats")), k_cap, _ptr(traj), self._stream()), self._h)
+                                         _ptr(out.get("episode_stats")), k_cap, _ptr(traj), _ptr(nz), self._stream()), self._h)
         return out
 
     def observe(self, out: Optional[torch.Tensor] = None):
@@ -260,16 +342,23 @@ class BatchedEvacuationEnv:
         self._keepalive = a   # the copy kernel runs asynchronously on the stream
 
     # ------------------------------------------------------------------------------------------
-    def final_info_list(self, infos, terminated=None, truncated=None):
+    def final_info_list(self, infos, terminated=None, truncated=None, done=None):
         """gymnasium-0.29 style ``infos['final_info']`` (list with one dict or None per env), as
-        consumed by rpo_agent.py:198-203.  Synchronises with the device."""
-        term = (self.terminated if terminated is None else terminated).bool()
-        trunc = (self.truncated if truncated is None else truncated).bool()
-        done = (term | trunc).cpu().numpy()
-        stats = infos["episode_stats"].cpu().numpy()
+        consumed by rpo_agent.py:198-203: per finished env the reference's nine-key episode record (env.py:115-125)
+        plus ``episode = {"r", "l"}`` (RecordEpisodeStatistics).  Synchronises with the device; ``infos["final_info"]``
+        calls this on first access."""
+        if done is None:
+            term = (self.terminated if terminated is None else terminated).bool()
+            trunc = (self.truncated if truncated is None else truncated).bool()
+            done = (term | trunc).cpu().numpy()
+        stats_t = dict.__getitem__(infos, "episode_stats")
+        stats = stats_t.cpu().numpy()
+        ints = stats_int_view(stats_t).cpu().numpy()
         out = [None] * self.num_envs
         for k in np.nonzero(done)[0]:
             rec = {f: float(stats[k, j]) for j, f in enumerate(STATS_FIELDS)}
+            for j, f in enumerate(STATS_INT_FIELDS):
+                rec[f] = int(ints[k, j])
             rec["episode"] = {"r": rec["episode_reward"], "l": int(rec["episode_length"])}
             out[k] = rec
         return out

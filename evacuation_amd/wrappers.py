@@ -47,8 +47,11 @@ class NormalizedVectorEnv:
                                             self.epsilon, self.env._stream()), self.env._h)
         return obs, info
 
-    def step(self, actions, noise=None):
-        obs, reward, term, trunc, infos = self.env.step(actions, noise=noise)
+    def step(self, actions, noise=None, **out):
+        """Wrapped step.  ``out_obs= / out_reward= / out_terminated= / out_truncated=`` (see
+        ``BatchedEvacuationEnv.step``) make the kernels write -- and normalise in place -- the caller's rollout
+        storage directly."""
+        obs, reward, term, trunc, infos = self.env.step(actions, noise=noise, **out)
         _lib.check(self.lib.evac_norm_step(self.env._h, _ptr(obs), _ptr(infos["final_observation"]), _ptr(reward),
                                            _ptr(term), _ptr(trunc), _ptr(self.norm_state), self.gamma, self.obs_clip,
                                            self.reward_clip, self.epsilon, self.env._stream()), self.env._h)

@@ -63,7 +63,7 @@ int main(int argc, char** argv) {
     HIP_OK(hipStreamCreate(&stream));
     EVAC_OK_(evac_bind_state(h, ped, status, agent, clock, acc), h);
     EVAC_OK_(evac_reset(h, nullptr, nullptr, obs, stream), h);
-    EVAC_OK_(evac_rollout(h, T, nullptr, nullptr, slab, nullptr, 0, nullptr, stream), h);      // the checked launch
+    EVAC_OK_(evac_rollout(h, T, nullptr, nullptr, slab, nullptr, 0, nullptr, nullptr, stream), h);      // the checked launch
     HIP_OK(hipStreamSynchronize(stream));
     std::vector<float> host(slab_floats);
     HIP_OK(hipMemcpy(host.data(), slab, sizeof(float) * slab_floats, hipMemcpyDeviceToHost));
@@ -73,7 +73,7 @@ int main(int argc, char** argv) {
 
     const int reps = 10;                                                                         // timing
     const auto t0 = std::chrono::steady_clock::now();
-    for (int r = 0; r < reps; ++r) EVAC_OK_(evac_rollout(h, T, nullptr, nullptr, slab, nullptr, 0, nullptr, stream), h);
+    for (int r = 0; r < reps; ++r) EVAC_OK_(evac_rollout(h, T, nullptr, nullptr, slab, nullptr, 0, nullptr, nullptr, stream), h);
     HIP_OK(hipStreamSynchronize(stream));
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("{\"client\": \"c_api_demo\", \"num_envs\": %d, \"n_ped\": %d, \"steps\": %d, \"obs_dim\": %lld, "

@@ -3,10 +3,13 @@
 
 A small MLP actor (the shape of RPOLinearNetwork, rpo_linear_agent_network.py:19-61: obs -> 64 -> 64 -> 2)
 drives 4096 evacuation envs through ``NormalizedVectorEnv`` (= the trainer's wrapper chain on device).
-Observations, actions, rewards and done flags never leave HBM; the whole `policy -> step -> store` body
-is captured once into a hipGraph and replayed.  Prints steps per second ("SPS" of rpo_agent.py:298-299).
+The trainer's storage (rpo_agent.py:158-163: ``obs[step]``, ``actions[step]``, ``rewards[step]``, ``dones[step]``) is
+written by the step kernel itself: every ``envs.step`` gets row ``t`` of the buffers as its destination
+(``out_obs=obs[t + 1]``, ``out_reward=rewards[t]``, ...), so there is no per-step copy into the buffers and nothing
+leaves HBM.  The whole T-step `policy -> step` rollout is captured once into a hipGraph and replayed.
+Prints steps per second ("SPS" of rpo_agent.py:298-299).
 
-    python examples/rollout_with_policy.py [--envs 4096] [--steps 256]
+    python examples/rollout_with_policy.py [--envs 4096] [--steps 128]
 """
 import argparse
 import os
@@ -22,7 +25,7 @@ import evacuation_amd as ea  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=4096)
-    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -33,48 +36,46 @@ def main():
     actor = torch.nn.Sequential(torch.nn.Linear(D, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(),
                                 torch.nn.Linear(64, 2)).to(dev)
     T, E = args.steps, args.envs
-    obs_buf = torch.zeros((T, E, D), device=dev)
-    act_buf = torch.zeros((T, E, 2), device=dev)
-    rew_buf = torch.zeros((T, E), device=dev)
-    done_buf = torch.zeros((T, E), device=dev)
-    next_obs, _ = envs.reset()
-    action = torch.zeros((E, 2), device=dev)
-    slot = torch.zeros((), dtype=torch.long, device=dev)
+    obs = torch.zeros((T + 1, E, D), device=dev)            # obs[t] is what the policy sees at step t
+    actions = torch.zeros((T, E, 2), device=dev)
+    rewards = torch.zeros((T, E), device=dev)
+    terminated = torch.zeros((T, E), dtype=torch.uint8, device=dev)
+    truncated = torch.zeros((T, E), dtype=torch.uint8, device=dev)
+    first, _ = envs.reset()
+    obs[0].copy_(first)
 
-    def body():
+    def rollout():
         with torch.no_grad():
-            mean = actor(next_obs)
-            action.copy_(mean + 0.5 * torch.randn_like(mean))
-            obs_buf.index_copy_(0, slot.view(1), next_obs.unsqueeze(0))
-            act_buf.index_copy_(0, slot.view(1), action.unsqueeze(0))
-            obs, rew, term, trunc, _ = envs.step(action)          # same tensors every call: graph-safe
-            rew_buf.index_copy_(0, slot.view(1), rew.unsqueeze(0))
-            done_buf.index_copy_(0, slot.view(1), (term | trunc).float().unsqueeze(0))
-            slot.add_(1).remainder_(T)
+            for t in range(T):
+                mean = actor(obs[t])
+                torch.add(mean, torch.randn_like(mean), alpha=0.5, out=actions[t])
+                envs.step(actions[t], out_obs=obs[t + 1], out_reward=rewards[t], out_terminated=terminated[t],
+                          out_truncated=truncated[t])
+            obs[0].copy_(obs[T])                             # the next rollout continues from here
 
-    for _ in range(3):
-        body()
+    rollout()
     torch.cuda.synchronize()
     if args.no_graph:
-        run = body
+        run = rollout
     else:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(side):
             with torch.cuda.graph(g, stream=side):
-                body()
+                rollout()
         torch.cuda.current_stream().wait_stream(side)
         run = g.replay
-    slot.zero_()
     torch.cuda.synchronize()
+    reps = 4
     t0 = time.perf_counter()
-    for _ in range(T):
+    for _ in range(reps):
         run()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = (time.perf_counter() - t0) / reps
+    done = (terminated | truncated).float()
     print(f"envs={E} steps={T} graph={not args.no_graph}: {E * T / dt:.3e} env-steps/s  ({dt / T * 1e6:.1f} us per vector step), "
-          f"mean normalised reward {rew_buf.mean().item():.3f}, done fraction {done_buf.mean().item():.4f}")
+          f"mean normalised reward {rewards.mean().item():.3f}, done fraction {done.mean().item():.4f}")
     envs.close()
 
 

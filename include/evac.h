@@ -17,7 +17,8 @@
  *
  * Environment switches (diagnostics only): EVAC_SUBWAVE=0 read by evac_create() selects the one-wave-per-env
  * kernels also for N <= 32 (default: 4 envs per wave for N <= 16, 2 for N <= 32; same results, see
- * tests/test_gpu_parity.py::test_subwave_kernels_match_one_wave_per_env); the Python host honours
+ * tests/test_gpu_parity.py::test_subwave_kernels_match_one_wave_per_env); EVAC_CELLS=1 / 0 forces the cell-list
+ * kernels on (for every N > 64) / off (default: N > 512; the all-pairs kernels give the same neighbour sets); the Python host honours
  * EVAC_LIB=<path> to load a profiling build of this library instead of evacuation_amd/libevac.so.
  *
  * Device layouts (row-major, E = num_envs, N = n_ped)
@@ -45,7 +46,7 @@
 extern "C" {
 #endif
 
-#define EVAC_VERSION 100          /* 0.1.0 */
+#define EVAC_VERSION 110          /* 0.1.1 */
 #define EVAC_MAX_PEDESTRIANS 1024 /* one workgroup (<=16 waves) per env */
 
 typedef enum evac_status {
@@ -89,7 +90,9 @@ typedef struct evac_config {
     int32_t clip_action;
 } evac_config_t;
 
-/* Written for envs whose episode ended this step (env.py:115-125 logging dict). */
+/* Written for envs whose episode ended this step: the nine keys of the reference's per-episode logging dict
+ * (env.py:115-125) plus the episode counter Time.n_episodes (area.py:49-51).  Ten 4-byte words; the two
+ * counters are integers (a float would lose steps beyond 2^24). */
 typedef struct evac_episode_stats {
     float episode_reward;
     float episode_length;
@@ -99,7 +102,10 @@ typedef struct evac_episode_stats {
     float exiting_pedestrians;
     float following_pedestrians;
     float viscek_pedestrians;
+    int32_t overall_timesteps; /* Time.overall_timesteps (area.py:47,55): steps of this env since creation */
+    int32_t n_episodes;        /* Time.n_episodes when the episode ended (resets so far) */
 } evac_episode_stats_t;
+#define EVAC_EPISODE_STATS_WORDS 10
 
 typedef struct evac_handle* evac_handle_t;
 
@@ -123,6 +129,9 @@ int evac_destroy(evac_handle_t h);
 /* Floats per env in the observation buffer for this handle's observation mode. */
 int64_t evac_obs_dim(evac_handle_t h);
 int32_t evac_num_envs(evac_handle_t h);
+/* Name of the kernel instantiation this handle's evac_step (rollout == 0) / evac_rollout (rollout != 0) launches,
+ * e.g. "k_rollout<1 wave/env, grav>": the label bench.py puts next to its roofline numbers (no reference analogue). */
+const char* evac_kernel_variant(evac_handle_t h, int32_t rollout);
 
 /* Bind the caller-owned state buffers (device pointers, layouts above). */
 int evac_bind_state(evac_handle_t h, float* ped, uint8_t* status, float* agent, int32_t* clock, float* acc);
@@ -156,13 +165,15 @@ int evac_step(evac_handle_t h, const float* actions, const float* noise_or_null,
  *   slab_out            float [T][E][D+3] = [obs(D) | reward | terminated (0/1) | truncated (0/1)] per env-step:
  *                       one packed record (what the trainer's rollout buffers and the all-gather consume)
  *   final_stats_or_null [T][E] (rows of envs that finished at step t)
+ *   noise_or_null       float [T][E][N]   per-pedestrian angular noise replacing the Philox draw (injection mode, as
+ *                       evac_step's; served by the diagnostic kernel face, like capture / actions_out)
  *   capture_or_null     float [T][capture_envs][N+1][3]: trajectory capture for rendering (the memory that
  *                       Pedestrians.save / Agent.save keep, pedestrians.py:33-35, area.py:32-33, consumed by
  *                       save_animation env.py:241-324): rows 0..N-1 = (x, y, status) of every pedestrian of the
  *                       first `capture_envs` envs after the step (before an autoreset), row N = (leader x, y, 0) */
 int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions_or_null, float* actions_out_or_null,
                  float* slab_out, evac_episode_stats_t* final_stats_or_null, int32_t capture_envs,
-                 float* capture_or_null, void* stream);
+                 float* capture_or_null, const float* noise_or_null, void* stream);
 
 /* State exchange in the reference's own shapes (needed for parity tests, checkpoints):
  * pos/dir float [E][N][2], status uint8 [E][N], agent_pos/agent_dir float [E][2], now int32 [E]. */

@@ -1,0 +1,77 @@
+"""bench.py's own multi-rank launcher, driven on CPU (gloo, world 2) through `--dry-run`:
+`python bench.py --gpus N` without torchrun must start N ranks itself, report n_gpus == N only when N ranks
+joined, and exit non-zero when a rank is missing (the reference's fan-out being replaced is
+gym.vector.SyncVectorEnv, /root/reference/src/agents/rpo_agent.py:123-126)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run_bench(args, env_extra=None, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+
+
+def json_lines(text):
+    return [json.loads(l) for l in text.splitlines() if l.startswith("{")]
+
+
+def test_plain_invocation_spawns_its_own_ranks():
+    r = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout                   # rank 0 prints ONE line
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["ranks_joined"] == 2 and d["self_launched"] is True
+    assert d["steps"] == 20 and d["warmup"] == 5
+    assert d["total_envs"] == 2 * d["envs_per_gpu"]    # weak scaling: the per-rank shard is fixed
+    assert d["gather_in_global_env_order"] is True
+
+
+def test_a_missing_rank_is_a_hard_error():
+    r = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run"], {"EVAC_BENCH_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert not json_lines(r.stdout)                    # no result line for a run that lost a rank
+    assert "rank failed" in r.stderr
+
+
+def test_world_size_mismatch_is_a_hard_error():
+    # under a launcher (WORLD_SIZE set) the rank count must equal --gpus: never report a 1-rank number as N GPUs
+    r = run_bench(["--gpus", "4", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+    r = run_bench(["--gpus", "1", "--dry-run"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_PORT": "29999"})
+    assert r.returncode != 0
+
+
+def test_torchrun_style_environment_is_honoured():
+    # what `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` provides, without the launcher
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(2):
+        env = {k: v for k, v in os.environ.items()}
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--steps", "40", "--warmup", "8", "--dry-run"],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT))
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1000:] for o in outs]
+    lines = json_lines(outs[0][0])
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["self_launched"] is False
+    assert not json_lines(outs[1][0])                  # only rank 0 reports
+
+
+def test_block_plan_tiles_the_episode():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.block_plan(20, 0, 0) == (100, 3)      # the driver's --steps 20: 100 blocks per episode sweep, 3 sweeps
+    assert bench.block_plan(2000, 0, 0) == (1, 20)     # default: a block is a whole episode, 20 of them
+    assert bench.block_plan(500, 0, 0)[0] == 4 and bench.block_plan(500, 0, 0)[0] * bench.block_plan(500, 0, 0)[1] >= 20
+    per, sw = bench.block_plan(20, 0, 7)
+    assert per * sw == 7
+    avg, info = bench.summarize_blocks([1.0, 3.0, 1.2, 2.8], [5, 1005, 5, 1005], 2, 10)
+    assert abs(avg - (1.1 + 2.9) / 2) < 1e-12 and info["dense"]["episode_phase"] == 5 and info["mid_episode"]["episode_phase"] == 1005

@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert s in _lib.SIGNATURES, f"{s} declared in evac.h but not bound in _lib.py"
         getattr(lib, s)
     assert set(_lib.SIGNATURES) == set(syms)
-    assert lib.evac_version() == 100
+    assert lib.evac_version() == 110
 
 
 def test_code_object_targets_gfx950(lib):
@@ -153,9 +153,14 @@ def test_kernel_resource_budgets():
         kernels[name] = {k: int(re.search(rf"\.{k}:\s+(\d+)", block).group(1))
                          for k in ("vgpr_count", "vgpr_spill_count", "sgpr_count", "private_segment_fixed_size")}
     assert len(kernels) >= 40
-    for name, k in kernels.items():
-        if "k_step" in name or "k_rollout" in name or "k_reset" in name or "k_observe" in name:
+    names = subprocess.run(["c++filt"], input="\n".join(kernels), capture_output=True, text=True).stdout.splitlines()
+    for mangled, name in zip(kernels, names):
+        k = kernels[mangled]
+        if any(t in name for t in ("k_step", "k_rollout", "k_reset", "k_observe")):
             assert k["vgpr_count"] <= 128, (name, k)
-        headline = ("k_rolloutILi1ELb1" in name or "k_stepILi1ELb1" in name or "_subILi" in name) and "capture" not in name
+        # the default faces of the production families: one wave per env, sub-wave, cell list
+        headline = ("k_step" in name or "k_rollout" in name) and "diag" not in name and \
+                   ("Wave<1>" in name or "_sub<" in name or "Cells<" in name)
         if headline:
             assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (name, k)
+    assert sum("Cells<" in n and "k_rollout<" in n for n in names) == 8      # 4 sizes x 2 observation faces

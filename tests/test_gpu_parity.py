@@ -564,16 +564,16 @@ def test_c_abi_error_codes(ea):
     assert lib.evac_step(h, p, None, p, p, q, q, 0, None, None, s) == _lib.ERR_NOT_BOUND
     assert b"evac_bind_state" in lib.evac_last_error(h)
     assert lib.evac_reset(h, None, None, None, s) == _lib.ERR_NOT_BOUND
-    assert lib.evac_rollout(h, 1, None, None, p, None, 0, None, s) == _lib.ERR_NOT_BOUND
+    assert lib.evac_rollout(h, 1, None, None, p, None, 0, None, None, s) == _lib.ERR_NOT_BOUND
     assert lib.evac_bind_state(h, p, q, None, p, p) == _lib.ERR_INVALID_ARGUMENT                      # NULL buffer
     assert lib.evac_bind_state(h, C.c_void_p(buf.data_ptr() + 4), q, p, p, p) == _lib.ERR_INVALID_ARGUMENT   # alignment
     env = ea.BatchedEvacuationEnv(ea.EnvConfig(number_of_pedestrians=60), ea.EnvWrappersConfig(positions="grav"), num_envs=4)
     env.reset()
     hh = env._h
     assert lib.evac_step(hh, None, None, p, p, q, q, 0, None, None, s) == _lib.ERR_INVALID_ARGUMENT  # actions NULL
-    assert lib.evac_rollout(hh, 0, None, None, p, None, 0, None, s) == _lib.ERR_INVALID_ARGUMENT      # n_steps < 1
-    assert lib.evac_rollout(hh, 1, None, None, None, None, 0, None, s) == _lib.ERR_INVALID_ARGUMENT   # slab NULL
-    assert lib.evac_rollout(hh, 1, None, None, p, None, 9, p, s) == _lib.ERR_INVALID_ARGUMENT         # capture_envs > E
+    assert lib.evac_rollout(hh, 0, None, None, p, None, 0, None, None, s) == _lib.ERR_INVALID_ARGUMENT      # n_steps < 1
+    assert lib.evac_rollout(hh, 1, None, None, None, None, 0, None, None, s) == _lib.ERR_INVALID_ARGUMENT   # slab NULL
+    assert lib.evac_rollout(hh, 1, None, None, p, None, 9, p, None, s) == _lib.ERR_INVALID_ARGUMENT         # capture_envs > E
     with pytest.raises(ValueError):
         env.step(torch.zeros((3, 2), device="cuda"))                                                  # wrong batch size
     with pytest.raises(_lib.EvacError):

@@ -15,16 +15,17 @@ from evacuation_amd import _lib
 lib = _lib.load()
 n, E, T = int("${2:-60}"), int("${3:-4096}"), 100
 env = ea.BatchedEvacuationEnv(ea.EnvConfig(number_of_pedestrians=n, is_new_exiting_reward=True), ea.EnvWrappersConfig(positions="grav"), num_envs=E, seed=1)
+print(env.kernel_variant())
 env.reset()
 buf = (C.c_ulonglong * 16)()
-names = ["0 action fetch + noise Philox", "1 leader + pre-pair per-lane", "2 tile write + vote", "3 all-pairs loop",
+names = ["0 action fetch + noise Philox", "1 leader + pre-pair per-lane", "2 tile write / binning", "3 neighbour loop (+ result exchange)",
          "4 heading/blend/move/reflect", "5 classify + reductions", "6 rewards/flags", "7 reset check + obs + stores"]
 for phase in range(4):
     env.rollout(T * 5); torch.cuda.synchronize()
     lib.evac_debug_stamps(buf)
     env.rollout(T); torch.cuda.synchronize()
     lib.evac_debug_stamps(buf)
-    waves = E * max(1, (n + 63) // 64 if n <= 64 else (4 if n <= 256 else 8 if n <= 512 else 16))
+    waves = E * (1 if n <= 64 else 2 if n <= 128 else 4 if n <= 256 else 8 if n <= 512 else 16)
     tot = sum(buf[:8])
     print(f"-- steps {phase*600+500}..{phase*600+600}: {tot / waves / T:.0f} cycles per wave-step")
     for k in range(8):
