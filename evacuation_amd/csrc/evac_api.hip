@@ -227,9 +227,10 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         p.cell_oy = hb;
         p.cell_inv_hx = (float)evac::kCellsX / (2.0f * wb);
         p.cell_inv_hy = (float)evac::kCellsY / (2.0f * hb);
-        int k = 22;                                        // |heading| * 2^k must fit v_mad_i32_i24, N * 2^k <= 2^30
-        while (((int64_t)cfg->number_of_pedestrians << k) > (1ll << 30)) --k;
-        p.head_scale = std::ldexp(1.0f, k);
+        // integer heading = rint(heading * head_scale): it must fit v_mad_i32_i24 (< 2^23) and N of them an int32
+        // (a unit-heading component can exceed 1 by a few ulp of v_rsq: 16 units of slack cover it)
+        const int64_t cap = (int64_t)0x7fffffff / cfg->number_of_pedestrians - 16;
+        p.head_scale = (float)(cap < 0x7ffff0 ? cap : (int64_t)0x7ffff0);     // exact in f32 (< 2^24)
     }
     p.seed_lo = (uint32_t)(seed & 0xffffffffull);
     p.seed_hi = (uint32_t)(seed >> 32);

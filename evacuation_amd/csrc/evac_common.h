@@ -88,7 +88,7 @@ struct Params {
     int32_t small_noise;                            // sin/cos regime: 2 short Taylor, 1 long Taylor, 0 ocml sincosf (noise_sincos)
     uint32_t seed_lo, seed_hi, env_id_offset;
     // cell list (Cells family): cell = (int)((x + cell_ox) * cell_inv_hx) clamped to [0, 15], same in y;
-    // head_scale = 2^k with N * 2^k <= 2^30: unit headings are summed as integers (exact, order-independent)
+    // head_scale = min(2^23 - 1, (2^31 - 1) / N): unit headings are summed as integers (exact, order-independent)
     float cell_ox, cell_oy, cell_inv_hx, cell_inv_hy, head_scale;
     // bound state
     float4* ped;
@@ -200,7 +200,7 @@ __device__ __forceinline__ void pair_accumulate(float XI, float YI, f4 t, float 
 }
 // The same pair with the unit heading stored as integers (heading * Params::head_scale, rounded): the weight's
 // bit pattern (0x3f800000 or 0) shifted down is the integer 1 or 0, and the sums are integer multiply-adds
-// (v_mad_i32_i24: |heading| <= 2^22).  Integer addition is exact, so the sum does not depend on the order in
+// (v_mad_i32_i24: |heading| < 2^23; N of them fit an int32).  Integer addition is exact, so the sum does not depend on the order in
 // which the peers are visited -- which is what lets the cell-list kernels place peers with LDS atomics.
 __device__ __forceinline__ void pair_accumulate_int(float XI, float YI, f4 t, float r2b, int& sx, int& sy) {
     const float w = neighbour_weight(XI - t.x, YI - t.y, r2b);

@@ -119,14 +119,19 @@ class ShardedEvacuationEnv:
         slab = ro["slab"]            # the kernel already wrote the packed [obs | reward | flags] record
         if self.world_size == 1:
             return ro, (slab.unsqueeze(0), None)
+        compute = torch.cuda.current_stream(self.local.device)
+        # the gathered buffer is allocated on the COMPUTE stream (where wait() / gathered_view consume it) and lent to
+        # the comm stream for the collective: both directions are recorded with the caching allocator
+        g = torch.empty((self.world_size,) + tuple(slab.shape), dtype=slab.dtype, device=slab.device)
         ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(self.local.device))
+        ready.record(compute)
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(ready)
-            g, _ = all_gather_envs(slab, group=self.group)
+            all_gather_envs(slab, group=self.group, out=g)
             done = torch.cuda.Event()
             done.record(self.comm_stream)
         slab.record_stream(self.comm_stream)
+        g.record_stream(self.comm_stream)
         return ro, (g, done)
 
     def wait(self, pending):
