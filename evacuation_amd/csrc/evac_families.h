@@ -230,7 +230,7 @@ struct Wave {
 //      slot s.  Its peers within the radius lie in the 3 x 3 cells around its own, i.e. in three runs of three
 //      consecutive cells (c-17..c-15, c-1..c+1, c+15..c+17 in x-major cell numbers; where a run wraps around the end
 //      of a cell column it only picks up a few extra, harmless candidates).  The lane sweeps the three slot ranges
-//      in ascending order, 4 entries per LDS round trip; reading past the end of a run is harmless (the extra
+//      in ascending order, kRowBatch entries per LDS round trip; reading past the end of a run is harmless (the extra
 //      entries are real pedestrians that are tested like any other, or +inf padding behind the last one) as long as
 //      no slot is visited twice -- the next run starts where the previous batch ended if that is later.
 //      Lanes of a wave own neighbouring cells, so their trip counts are similar and waves behind the last moving
@@ -250,6 +250,10 @@ struct Cells {
     static constexpr int kBlock = kThreadsPerEnv;
     static constexpr int kEnvsPerBlock = 1;
     static constexpr int kPad = 8;   // +inf entries behind the last moving pedestrian (>= entries per batch)
+#ifndef EVAC_ROW_BATCH
+#define EVAC_ROW_BATCH 8
+#endif
+    static constexpr int kRowBatch = EVAC_ROW_BATCH;   // tile entries per LDS round trip of a row
     static constexpr const char* kName = WPE == 2 ? "2 waves/env, cell list" : (WPE == 4 ? "4 waves/env, cell list" : (WPE == 8 ? "8 waves/env, cell list" : "16 waves/env, cell list"));
 
     struct Smem {
@@ -258,6 +262,10 @@ struct Cells {
         alignas(16) int start[kCells + 4];    // exclusive prefix of cnt; [256] = moving pedestrians, [257] = NaN headings
         int who[kThreadsPerEnv];              // tile slot -> pedestrian | cell << 16
         i2 res[kThreadsPerEnv];               // pedestrian -> integer heading sums of its row
+        // 16-wave workgroups: claim more than half of the CU's 160 KiB so that the dispatcher places ONE env per CU
+        // (two 1024-thread workgroups on one CU halve each other's speed while other CUs idle: 29.8 vs 16.3 us per step
+        // at 256 envs)
+        char one_workgroup_per_cu[WPE == 16 ? 52 * 1024 : 16];
         f4 redf[1][WPE];
         i4 redi[1][WPE];
         float exitg[1][2];
@@ -371,12 +379,12 @@ struct Cells {
                 for (int r = 0; r < 3; ++r) {
                     j = max(j, lo[r]);
                     while (j < hi[r]) {
-                        f4 t[4];
+                        f4 t[kRowBatch];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+                        for (int k = 0; k < kRowBatch; ++k) t[k] = tile[j + k];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) pair_accumulate_int(me.x, me.y, t[k], kRPed2Big, ax, ay);
-                        j += 4;
+                        for (int k = 0; k < kRowBatch; ++k) pair_accumulate_int(me.x, me.y, t[k], kRPed2Big, ax, ay);
+                        j += kRowBatch;
                     }
                 }
                 sm.res[wc & 0xffff] = i2{ax, ay};

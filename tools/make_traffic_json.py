@@ -2,15 +2,18 @@
 """profiles/traffic.json from a tools/profile_pmc.sh output directory.
 HBM bytes per launch = FETCH_SIZE[KiB] * 1024 * 2  (gfx950 reports half of a coalesced read stream,
 MI355X_MICROARCH.md 'HBM') + WRITE_SIZE[KiB] * 1024; separate --pmc passes, mean over the dispatches
-of the timed kernel.  usage: make_traffic_json.py <pmc_dir> <key> [<pmc_dir> <key> ...]"""
+of the timed kernel, divided by the env-steps of one launch: bench.py scales it back to whatever launch shape it
+runs (`roofline.traffic`).
+usage: make_traffic_json.py <pmc_dir> <workload:mode> <envs> <steps_per_launch> [...]"""
 import csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_path = os.path.join(ROOT, "profiles", "traffic.json")
 data = json.load(open(out_path)) if os.path.exists(out_path) else {}
+data = {k: v for k, v in data.items() if "hbm_bytes_per_env_step" in v}     # drop entries of the round-1 format
 args = sys.argv[1:]
-for d, key in zip(args[0::2], args[1::2]):
-    kern = "k_rollout" if ":rollout:" in key else "k_step"
+for d, key, envs, inner in zip(args[0::4], args[1::4], args[2::4], args[3::4]):
+    kern = "k_rollout" if key.endswith(":rollout") else "k_step"
     vals = {"FETCH_SIZE": [], "WRITE_SIZE": []}
     for f in glob.glob(os.path.join(d, "pmc*", "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
@@ -18,8 +21,10 @@ for d, key in zip(args[0::2], args[1::2]):
                 vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
     fetch = sum(vals["FETCH_SIZE"]) / max(1, len(vals["FETCH_SIZE"]))
     write = sum(vals["WRITE_SIZE"]) / max(1, len(vals["WRITE_SIZE"]))
-    data[key] = {"kernel": kern, "fetch_size_kib": fetch, "write_size_kib": write,
-                 "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
+    per_launch = fetch * 1024 * 2 + write * 1024
+    data[key] = {"kernel": kern, "fetch_size_kib_per_launch": fetch, "write_size_kib_per_launch": write,
+                 "envs": int(envs), "steps_per_launch": int(inner),
+                 "hbm_bytes_per_launch": per_launch, "hbm_bytes_per_env_step": per_launch / (int(envs) * int(inner)),
                  "note": "FETCH_SIZE doubled per the gfx950 correction; dispatches averaged: %d" % len(vals["FETCH_SIZE"]),
                  "source": os.path.relpath(d, ROOT)}
     print(key, data[key])

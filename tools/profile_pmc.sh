@@ -1,14 +1,18 @@
 #!/bin/bash
 # rocprofv3 passes for the bench workload (run ON the GPU box via gpurun).  Separate --pmc passes
 # (never combined with trace domains other than --kernel-trace), outputs under gpurun_out/<tag>/.
-# usage: tools/profile_pmc.sh <tag> [bench args...]
+# usage: tools/profile_pmc.sh <tag> [bench args...]      (default bench args: the driver's `--gpus 1 --steps 20 --warmup 5`)
+# The profiled command is bench.py itself with the same arguments (+ --no-cpu-baseline --no-step-api: the CPU leg and
+# the one-launch-per-step side measurement launch other kernels and are not what the roofline block describes).
 set -u
 TAG=${1:-prof}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --steps 400 --warmup 100 $*"
+if [ $# -eq 0 ]; then set -- --gpus 1 --steps 20 --warmup 5; fi
+ARGS="--no-cpu-baseline --no-step-api $*"
+echo "bench.py $ARGS" > "$OUT/command.txt"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/stats.log" 2>&1
 i=0
 for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \

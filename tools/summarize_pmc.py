@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Summarise the rocprofv3 CSVs written by tools/profile_pmc.sh: per-kernel mean duration and mean
-counter values per dispatch for the evac kernels."""
+counter values per dispatch for the evac kernels (dispatches of one launch shape: the most frequent grid/steps)."""
 import csv
 import glob
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -11,19 +12,24 @@ out = sys.argv[1]
 
 
 def short(name):
-    for k in ("k_rollout", "k_step", "k_reset", "k_observe"):
-        if k in name:
-            i = name.index(k)
-            return name[i:name.index(">", i) + 1]
-    return None
+    m = re.search(r"k_(?:rollout|step|reset|observe)\w*<", name)
+    if not m:
+        return None
+    depth, k = 1, m.end()
+    while k < len(name) and depth:
+        depth += {"<": 1, ">": -1}.get(name[k], 0)
+        k += 1
+    return name[m.start():k].replace("evac::", "")
 
 
+if os.path.exists(os.path.join(out, "command.txt")):
+    print("== command:", open(os.path.join(out, "command.txt")).read().strip())
 for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
     print("== kernel stats (", os.path.relpath(f, out), ")")
     for row in csv.DictReader(open(f)):
         s = short(row["Name"])
         if s:
-            print(f"  {s:16s} calls={row['Calls']:>6s} avg_ns={float(row['AverageNs']):12.1f} min_ns={row['MinNs']:>10s} max_ns={row['MaxNs']:>10s} pct={row['Percentage']}")
+            print(f"  {s:44s} calls={row['Calls']:>6s} avg_ns={float(row['AverageNs']):12.1f} min_ns={row['MinNs']:>10s} max_ns={row['MaxNs']:>10s} pct={row['Percentage']}")
 
 agg = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
