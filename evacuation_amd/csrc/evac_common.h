@@ -144,13 +144,29 @@ __device__ __forceinline__ int dpp_addi(int v) {
 // VALU instruction costs wait states (the compiler pads a single chain with s_nop); with three independent
 // chains in lock-step the hazard is covered by real work.
 #define EVAC_DPP3(CTRL, MASK) a = dpp_add<CTRL, MASK>(a); b = dpp_add<CTRL, MASK>(b); c = dpp_add<CTRL, MASK>(c);
+// The two row_bcast steps with a partial row mask: written through update_dpp the compiler emits
+// v_mov 0 / v_mov_dpp / v_add for each (the masked-off rows must add 0); as v_add_f32_dpp on the accumulator itself the
+// masked-off rows simply keep their value -- one instruction per step.  The three chains are interleaved so that every
+// DPP source was written at least two instructions earlier (the DPP read-after-VALU-write wait states); the leading
+// s_nop covers the compiler's last row_shr step, the trailing one the readers that follow.
+__device__ __forceinline__ void dpp_bcast_fold3(float& a, float& b, float& c) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(a), "+v"(b), "+v"(c));
+}
 __device__ __forceinline__ void wave_sum3(float& a, float& b, float& c) {
     EVAC_DPP3(0x111, 0xf)
     EVAC_DPP3(0x112, 0xf)
     EVAC_DPP3(0x114, 0xf)
     EVAC_DPP3(0x118, 0xf)
-    EVAC_DPP3(0x142, 0xa)
-    EVAC_DPP3(0x143, 0xc)
+    dpp_bcast_fold3(a, b, c);
     a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
     b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 63));
     c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), 63));
@@ -166,7 +182,14 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
     v = dpp_addi<0x143, 0xc>(v);
     return v;
 }
-__device__ __forceinline__ int wave_count(bool p) { return __popcll(__ballot(p)); }
+// Set bits of a ballot as a 32-bit value the compiler knows nothing else about: otherwise (float)count is expanded as a
+// 64-bit integer conversion (s_lshl_b64 / s_min / s_or / v_cvt / v_ldexp) because ctpop's operand is 64 bits wide.
+__device__ __forceinline__ int mask_count(unsigned long long m) {
+    int n = __popcll(m);
+    asm volatile("" : "+s"(n));
+    return n;
+}
+__device__ __forceinline__ int wave_count(bool p) { return mask_count(__ballot(p)); }
 __device__ __forceinline__ float readlane_f(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
@@ -210,18 +233,22 @@ __device__ __forceinline__ void pair_accumulate_int(float XI, float YI, f4 t, fl
     sy = __mul24(wi, __float_as_int(hw)) + sy;
 }
 
-// x^k for a wave-uniform integer k in [1,63]: straight-line binary powering (no loop, no branches;
-// the selects take a wave-uniform condition).  A few ulp.
+// x^k for a wave-uniform integer k in [1,63] (k = alpha + 2).  The powers the reference's experiments use
+// (alpha = 2, 3, 5: run_scripts/) take a uniform branch to a straight product; anything else binary powering with
+// uniform branches -- no per-bit select masks held in scalar registers through the step loop.  A few ulp.
 __device__ __forceinline__ float powi(float x, int k) {
     const float x2 = x * x, x4 = x2 * x2;
+    if (k == 5) return x4 * x;
+    if (k == 4) return x4;
+    if (k == 7) return x4 * x2 * x;
     float r = (k & 1) ? x : 1.0f;
-    r *= (k & 2) ? x2 : 1.0f;
-    r *= (k & 4) ? x4 : 1.0f;
+    if (k & 2) r *= x2;
+    if (k & 4) r *= x4;
     if (k & 56) {   // rare: alpha >= 6
         const float x8 = x4 * x4, x16 = x8 * x8;
-        r *= (k & 8) ? x8 : 1.0f;
-        r *= (k & 16) ? x16 : 1.0f;
-        r *= (k & 32) ? x16 * x16 : 1.0f;
+        if (k & 8) r *= x8;
+        if (k & 16) r *= x16;
+        if (k & 32) r *= x16 * x16;
     }
     return r;
 }

@@ -28,7 +28,7 @@ __device__ __forceinline__ void grav_observation(const Params& p, typename F::Ct
     s.f0 = visc ? gx : 0.0f;
     s.f1 = visc ? gy : 0.0f;
     s.f2 = 0.0f;
-    const bool pred[8] = {active && q.st == kFollower, false, false, false, false, false, false, false};
+    const unsigned long long pred[8] = {__ballot(active && q.st == kFollower), 0, 0, 0, 0, 0, 0, 0};
     F::template reduce<true>(c, s, pred);
     float ex, ey;
     grav_term(p, e.ax - kExitX, e.ay - kExitY, ex, ey);              // gravity_encoding.py:28-38
@@ -56,7 +56,7 @@ __device__ __forceinline__ void write_obs(const Params& p, typename F::Ctx& c, b
 template <class F>
 __device__ __forceinline__ void finish_counts(typename F::Ctx& c, const Ped& q, StepOut& o) {
     Sums s{};
-    const bool pred[8] = {q.st == kExiting, q.st == kViscek, false, false, false, false, false, false};
+    const unsigned long long pred[8] = {__ballot(q.st == kExiting), __ballot(q.st == kViscek), 0, 0, 0, 0, 0, 0};
     F::template reduce<true>(c, s, pred);
     o.n_exiting = s.i[0];
     o.n_viscek = s.i[1];
@@ -183,10 +183,10 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     }
     // per-step counts: the two reward transitions, escaped (termination) and followers (gravity exit term);
     // exiting / viscek counts are only part of the episode record and are taken at episode end.
-    const bool pred[8] = {
-        (old_st == kViscek || old_st == kFollower) && new_st == kExiting,    // reward.py:35-39
-        old_st == kViscek && new_st == kFollower,                             // reward.py:43-46
-        new_st == kEscaped, false, new_st == kFollower, false, false, false};
+    const unsigned long long pred[8] = {
+        __ballot((old_st == kViscek || old_st == kFollower) && new_st == kExiting),    // reward.py:35-39
+        __ballot(old_st == kViscek && new_st == kFollower),                             // reward.py:43-46
+        __ballot(new_st == kEscaped), 0, __ballot(new_st == kFollower), 0, 0, 0};
     if constexpr (GRAV) F::exit_publish(c, exit_lane, gx, gy);
     if constexpr (!(EVAC_ABLATE & 8)) F::template reduce<false>(c, s, pred);
     if constexpr (GRAV) {
@@ -316,7 +316,6 @@ __device__ __forceinline__ void rollout_body(
     float2 lane_act = make_float2(0.f, 0.f), lane_adir = make_float2(0.f, 0.f);
     // flush mapping of the staged outputs: lane l carries word l % 9 of staged step l / 9
     const int fl_s = w.lane / kGravRow, fl_k = w.lane - fl_s * kGravRow;
-    int staged = 0, stage_t0 = 0;
     // Retire the state loads HERE, or their first use inside the loop puts `s_waitcnt vmcnt(0)` -- which
     // also waits for the previous step's stores -- into every iteration.
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
@@ -385,23 +384,21 @@ __device__ __forceinline__ void rollout_body(
         const float f_term = o.terminated ? 1.0f : 0.0f, f_trunc = o.truncated ? 1.0f : 0.0f;
         if constexpr (GRAV) {
             if constexpr (!(EVAC_ABLATE & 16)) {
-                if (staged == 0) stage_t0 = t;
+                const int staged = t % kStageSteps;                 // slot of this step in the staging block (scalar)
                 if (w.owner) {
                     float* st = sm.stage[w.slot][staged];
                     *(f4*)(st + 0) = f4{o6[0], o6[1], o6[2], o6[3]};
                     *(f4*)(st + 4) = f4{o6[4], o6[5], o.reward, f_term};
                     st[8] = f_trunc;
                 }
-                ++staged;
-                if (staged == kStageSteps || t == n_steps - 1) {
+                if (staged == kStageSteps - 1 || t == n_steps - 1) {
                     if (w.wave_in_env == 0) {   // the wave that staged them: in-order LDS, no barrier needed
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        if (fl_s < staged) {
+                        if (fl_s <= staged) {
                             const float v = sm.stage[w.slot][fl_s][fl_k];
-                            slab_out[((size_t)(stage_t0 + fl_s) * E + w.env) * kGravRow + fl_k] = v;
+                            slab_out[((size_t)(t - staged + fl_s) * E + w.env) * kGravRow + fl_k] = v;
                         }
                     }
-                    staged = 0;
                 }
             }
         } else {

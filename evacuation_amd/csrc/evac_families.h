@@ -5,7 +5,7 @@
 //   F::Smem, F::Ctx                 LDS block of a workgroup; "who am I" (env, slot, lane, pedestrian i, owner lane)
 //   F::kEnvUniform                  per-env values (counts, flags) are wave-uniform (false only for Sub)
 //   F::neighbour_sum(...)           heading sum over the moving pedestrians within the radius, per FOLLOWER/VISCEK lane
-//   F::reduce<GUARD>(...)           three float sums and up to eight predicate counts over the env's lanes
+//   F::reduce<GUARD>(...)           three float sums and the set bits of up to eight ballots over the env's lanes
 //   F::exit_publish / exit_fetch    the gravity exit term evaluated by the env's first idle lane
 //
 //   Sub<G>     G = 16 / 32 lanes of a wave per env (N <= 16 / 32): 4 / 2 envs per wave, no barrier at all
@@ -89,10 +89,10 @@ struct Wave {
     // 1024); after the barrier lane w of every wave reads record w and the records are folded with DPP row_shr steps
     // (a fixed tree: deterministic), 2 LDS reads per wave instead of 11 * WPE.
     template <bool GUARD, class C>
-    static __device__ __forceinline__ void reduce(C& c, Sums& s, const bool (&pred)[8]) {
+    static __device__ __forceinline__ void reduce(C& c, Sums& s, const unsigned long long (&pred)[8]) {
         wave_sum3(s.f0, s.f1, s.f2);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s.i[k] = wave_count(pred[k]);
+        for (int k = 0; k < 8; ++k) s.i[k] = mask_count(pred[k]);
         if constexpr (WPE > 1) {
             auto& sm = c.sm;
             if constexpr (GUARD) __syncthreads();   // previous users of the records are done
@@ -299,7 +299,7 @@ struct Cells {
     }
 
     template <bool GUARD, class C>
-    static __device__ __forceinline__ void reduce(C& c, Sums& s, const bool (&pred)[8]) {
+    static __device__ __forceinline__ void reduce(C& c, Sums& s, const unsigned long long (&pred)[8]) {
         Wave<WPE>::template reduce<GUARD>(c, s, pred);
     }
     template <class C>
@@ -461,7 +461,7 @@ struct Sub {
 
     // Sums valid in the group's last lane (three chains interleaved, see wave_sum3); counts in every lane of the group.
     template <bool GUARD, class C>
-    static __device__ __forceinline__ void reduce(C& c, Sums& s, const bool (&pred)[8]) {
+    static __device__ __forceinline__ void reduce(C& c, Sums& s, const unsigned long long (&pred)[8]) {
         float &a = s.f0, &b = s.f1, &cc = s.f2;
         {
             float& c = cc;
@@ -472,7 +472,7 @@ struct Sub {
             if constexpr (G == 32) { EVAC_DPP3(0x142, 0xa) }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s.i[k] = count(__ballot(pred[k]), c.gmask);
+        for (int k = 0; k < 8; ++k) s.i[k] = count(pred[k], c.gmask);
     }
     template <class C>
     static __device__ __forceinline__ void exit_publish(C&, bool, float, float) {}
