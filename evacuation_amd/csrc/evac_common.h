@@ -186,7 +186,7 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
 // 64-bit integer conversion (s_lshl_b64 / s_min / s_or / v_cvt / v_ldexp) because ctpop's operand is 64 bits wide.
 __device__ __forceinline__ int mask_count(unsigned long long m) {
     int n = __popcll(m);
-    asm volatile("" : "+s"(n));
+    asm("" : "+s"(n));        // (not volatile: an unused count still disappears)
     return n;
 }
 __device__ __forceinline__ int wave_count(bool p) { return mask_count(__ballot(p)); }

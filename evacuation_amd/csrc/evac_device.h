@@ -186,7 +186,9 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     const unsigned long long pred[8] = {
         __ballot((old_st == kViscek || old_st == kFollower) && new_st == kExiting),    // reward.py:35-39
         __ballot(old_st == kViscek && new_st == kFollower),                             // reward.py:43-46
-        __ballot(new_st == kEscaped), 0, __ballot(new_st == kFollower), 0, 0, 0};
+        __ballot(new_st == kEscaped),
+        __ballot((unsigned)(new_st - kViscek) < 3u),      // moves at the next step (only the multi-wave all-pairs family uses it)
+        __ballot(new_st == kFollower), 0, 0, 0};
     if constexpr (GRAV) F::exit_publish(c, exit_lane, gx, gy);
     if constexpr (!(EVAC_ABLATE & 8)) F::template reduce<false>(c, s, pred);
     if constexpr (GRAV) {
@@ -378,6 +380,7 @@ __device__ __forceinline__ void rollout_body(
                 if (w.owner) write_stats(final_stats + (size_t)t * E + w.env, e, o);
             }
             reset_env(p, active, philox_reset_draw(p, gid, w.i, e.n_resets), q, e);
+            F::invalidate(w);
             if constexpr (GRAV) grav_observation<F>(p, w, active, q, e, o6);
         }
         float* rowp = slab_out + ((size_t)t * E + w.env) * row;
@@ -584,6 +587,7 @@ static_assert(offsetof(Cells<2>::Smem, stage) % 16 == 0 && offsetof(Cells<4>::Sm
               offsetof(Cells<8>::Smem, stage) % 16 == 0 && offsetof(Cells<16>::Smem, stage) % 16 == 0 &&
               offsetof(Cells<4>::Smem, cnt) % 16 == 0 && offsetof(Cells<4>::Smem, start) % 16 == 0,
               "stage rows and the cell tables must be 16-byte aligned");
+static_assert(sizeof(Wave<4>::Smem::tile) == 2 * 256 * 16, "two tiles for the multi-wave all-pairs kernels");
 static_assert(offsetof(Wave<1>::Smem, tile) == 0 && alignof(Wave<1>::Smem) >= 16 && alignof(Cells<16>::Smem) >= 16,
               "tile must be 16-byte aligned");
 

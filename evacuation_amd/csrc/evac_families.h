@@ -15,6 +15,8 @@
 //              re-dealt to lanes in cell order, each row scans only the 3 x 3 cells around it
 #pragma once
 
+#include <type_traits>
+
 #include "evac_common.h"
 
 namespace evac {
@@ -37,8 +39,20 @@ struct Wave {
     static constexpr int kEnvsPerBlock = kBlock / kThreadsPerEnv;
     static constexpr const char* kName = WPE == 1 ? "1 wave/env, all pairs" : (WPE == 2 ? "2 waves/env, all pairs" : (WPE == 4 ? "4 waves/env, all pairs" : (WPE == 8 ? "8 waves/env, all pairs" : "16 waves/env, all pairs")));
 
+    // WPE > 1: two tiles used alternately, so that writing step t+1's tile needs no barrier against the waves still
+    // reading step t's (the two barriers of step t+1 lie between a tile's last read and its next write)
+    static constexpr int kTiles = WPE == 1 ? 1 : 2;
+    // WPE > 1: ROW BLOCKING.  A wave-uniform ds_read_b128 costs 4 LDS cycles however many lanes share the address, and
+    // with 16 waves per CU each reading every peer the LDS pipe, not the VALU, bounds the all-pairs loop (N = 256:
+    // 16 x 256 x 4 = 16.4 k cycles per step against ~9 k of VALU).  So a wave tests each peer it fetches against the
+    // rows of kRows waves (its group: kRows pedestrians per lane) and fetches only 1/kRows of the peers; the kRows
+    // partial sums of a row meet in LDS.  Same VALU work, 1/kRows of the LDS reads, one more barrier.
+    static constexpr int kRows = WPE == 1 ? 1 : (WPE == 2 ? 2 : 4);
+
     struct Smem {
-        f4 tile[kEnvsPerBlock][WPE * kWave];   // (x, y, ux, uy) of every pedestrian
+        f4 tile[kTiles][kEnvsPerBlock][WPE * kWave];   // (x, y, ux, uy) of every pedestrian
+        float2 rowpos[kTiles][kEnvsPerBlock][WPE == 1 ? 1 : WPE * kWave];   // (X, Y) of every pedestrian by index (row blocking)
+        float2 part[kRows][kEnvsPerBlock][WPE == 1 ? 1 : WPE * kWave];       // partial heading sums [column share][pedestrian]
         f4 redf[kEnvsPerBlock][WPE];               // per-wave partial sums (reduce)
         i4 redi[kEnvsPerBlock][WPE];               // per-wave partial counts, packed in pairs
         int cols[kEnvsPerBlock][WPE];              // moving pedestrians per wave (tile compaction)
@@ -48,9 +62,14 @@ struct Wave {
     };
 
     struct Ctx {
+        using Family = Wave<WPE_>;
         Smem& sm;
         int env, slot, wave_in_env, lane, i;
         bool owner;
+        // WPE > 1: which tile this step fills; and the moving-pedestrian counts of the NEXT step (how many in the env,
+        // how many in the waves before this one), which the step's own reduction delivers for free
+        int par = 0, next_cols = 0, next_base = 0;
+        bool have_next = false;
 #ifdef EVAC_STAMP
         StampState stamp;
 #endif
@@ -82,6 +101,8 @@ struct Wave {
     }
 
     static __device__ __forceinline__ void init(Ctx&) {}
+    // the statuses changed outside step_env (autoreset): the counts carried over from the last reduction are void
+    static __device__ __forceinline__ void invalidate(Ctx& c) { c.have_next = false; }
 
     // Reduce 3 floats and up to 8 predicates over all lanes of the env.  Result in every lane.
     // GUARD: a barrier in front, for callers whose previous reduction may still be read by another wave.
@@ -116,6 +137,14 @@ struct Wave {
             s.f0 = readlane_f(rf.x, WPE - 1);
             s.f1 = readlane_f(rf.y, WPE - 1);
             s.f2 = readlane_f(rf.z, WPE - 1);
+            if constexpr (!GUARD && std::is_same<typename C::Family, Wave<WPE>>::value) {
+                // the step's own reduction: count 3 is "moves at the next step"; after the DPP steps lane w holds the sum
+                // over waves 0..w, i.e. the tile offsets of the next step's compaction -- no exchange, no barrier then
+                const int before = c.wave_in_env == 0 ? 0 : __builtin_amdgcn_readlane(ri.y, c.wave_in_env - 1);
+                c.next_base = before >> 16;
+                c.next_cols = __builtin_amdgcn_readlane(ri.y, WPE - 1) >> 16;
+                c.have_next = true;
+            }
             const int a = __builtin_amdgcn_readlane(ri.x, WPE - 1), b = __builtin_amdgcn_readlane(ri.y, WPE - 1);
             const int d = __builtin_amdgcn_readlane(ri.z, WPE - 1), g = __builtin_amdgcn_readlane(ri.w, WPE - 1);
             s.i[0] = a & 0xffff; s.i[1] = a >> 16;
@@ -152,7 +181,13 @@ struct Wave {
     static __device__ __forceinline__ void neighbour_sum(const Params& p, Ctx& c, const Ped& q, bool efv, bool fv,
                                                          float ux, float uy, float& sx, float& sy) {
         auto& sm = c.sm;
-        sync();   // tile readers of the previous step are done
+        int par = 0;
+        if constexpr (WPE == 1) {
+            sync();   // tile readers of the previous step are done (a fence: the wave is in lock-step)
+        } else {
+            par = c.par;
+            c.par = par ^ 1;
+        }
         // The tile holds the moving pedestrians first, compacted in ascending pedestrian order -- the columns
         // pos[efv] of the reference's distance matrix (area.py:99-106) -- then the others as padding with
         // weight 0 (X = +inf) and heading 0.  Every lane writes exactly one entry.  Under a
@@ -164,54 +199,108 @@ struct Wave {
             int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
             n_cols = __popcll(m);
             if constexpr (WPE > 1) {
-                if (c.lane == 0) sm.cols[c.slot][c.wave_in_env] = n_cols;
-                __syncthreads();
-                int tot = 0, base = 0;
+                if (c.have_next) {          // uniform: delivered by the previous step's reduction
+                    n_cols = c.next_cols;
+                    before += c.next_base;
+                } else {                    // first step of a launch, or right after an autoreset
+                    if (c.lane == 0) sm.cols[c.slot][c.wave_in_env] = n_cols;
+                    __syncthreads();
+                    int tot = 0, base = 0;
 #pragma unroll
-                for (int w2 = 0; w2 < WPE; ++w2) {
-                    const int k = sm.cols[c.slot][w2];
-                    base += (w2 < c.wave_in_env) ? k : 0;
-                    tot += k;
+                    for (int w2 = 0; w2 < WPE; ++w2) {
+                        const int k = sm.cols[c.slot][w2];
+                        base += (w2 < c.wave_in_env) ? k : 0;
+                        tot += k;
+                    }
+                    n_cols = tot;
+                    before += base;                                             // moving pedestrians before this one
                 }
-                n_cols = tot;
-                before += base;                                                 // moving pedestrians before this one
             }
             const int tid = c.wave_in_env * kWave + c.lane;
             const int idx = efv ? before : n_cols + (tid - before);             // a bijection onto [0, WPE*64)
-            sm.tile[c.slot][idx] = f4{efv ? q.x * kTileScale : __builtin_inff(), q.y * kTileScale, efv ? ux : 0.0f, efv ? uy : 0.0f};
+            sm.tile[par][c.slot][idx] = f4{efv ? q.x * kTileScale : __builtin_inff(), q.y * kTileScale, efv ? ux : 0.0f, efv ? uy : 0.0f};
         }
+        if constexpr (WPE > 1) sm.rowpos[par][c.slot][c.wave_in_env * kWave + c.lane] = make_float2(q.x * kTileScale, q.y * kTileScale);
         sync();   // tile complete
         EVAC_T(c, 2);   // tile write
-        // rows of the distance matrix exist only for FOLLOWER/VISCEK pedestrians (area.py:104)
-        bool any_fv;
-        if constexpr (WPE == 1) any_fv = __ballot(fv) != 0ull;
-        else any_fv = true;   // (a workgroup-wide OR would cost a barrier; the loop is short when n_cols is)
         sx = 0.0f;
         sy = 0.0f;
-        // Branch-free batches: the B wave-uniform ds_read_b128 broadcasts are issued back to
-        // back (LDS latency paid once per batch, no VALU slot), then 6 full-rate VALU ops per pair.
-        const f4* __restrict__ tile = sm.tile[c.slot];
-        const int n8 = __builtin_amdgcn_readfirstlane(any_fv ? ((n_cols + 3) & ~3) : 0);   // no rows -> no loop
+        const f4* __restrict__ tile = sm.tile[par][c.slot];
         const float r2b = kRPed2Big;
-        const float XI = q.x * kTileScale, YI = q.y * kTileScale;
-        // peers per LDS round trip: 16 where registers allow (1-wave kernels: 3.31 vs 3.34 us at 8, 3.49 at 4),
-        // 8 in the multi-wave kernels, 4 in the 1024-thread one whose workgroup size caps it at 128 VGPRs
-        constexpr int B = WPE <= 2 ? 16 : (WPE == 16 ? 4 : 8);
-        int j = 0;
-        if constexpr (!(EVAC_ABLATE & 1)) {
-            for (; j + B <= n8; j += B) {      // full batches
-                f4 t[B];
+        if constexpr (WPE == 1) {
+            // rows of the distance matrix exist only for FOLLOWER/VISCEK pedestrians (area.py:104)
+            const bool any_fv = __ballot(fv) != 0ull;
+            // Branch-free batches: the B wave-uniform ds_read_b128 broadcasts are issued back to
+            // back (LDS latency paid once per batch, no VALU slot), then 6 full-rate VALU ops per pair.
+            const int n8 = __builtin_amdgcn_readfirstlane(any_fv ? ((n_cols + 3) & ~3) : 0);   // no rows -> no loop
+            const float XI = q.x * kTileScale, YI = q.y * kTileScale;
+            // peers per LDS round trip: 16 (3.31 vs 3.34 us at 8, 3.49 at 4)
+            constexpr int B = 16;
+            int j = 0;
+            if constexpr (!(EVAC_ABLATE & 1)) {
+                for (; j + B <= n8; j += B) {      // full batches
+                    f4 t[B];
 #pragma unroll
-                for (int k = 0; k < B; ++k) t[k] = tile[j + k];
+                    for (int k = 0; k < B; ++k) t[k] = tile[j + k];
 #pragma unroll
-                for (int k = 0; k < B; ++k) pair_accumulate(XI, YI, t[k], r2b, sx, sy);
+                    for (int k = 0; k < B; ++k) pair_accumulate(XI, YI, t[k], r2b, sx, sy);
+                }
+                for (; j < n8; j += 4) {           // remainder in groups of 4 (n8 is a multiple of 4)
+                    f4 t[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pair_accumulate(XI, YI, t[k], r2b, sx, sy);
+                }
             }
-            for (; j < n8; j += 4) {           // remainder in groups of 4 (n8 is a multiple of 4)
-                f4 t[4];
+        } else {
+            // this wave: the rows of its group of kRows waves (kRows pedestrians per lane), column share `share`
+            const int share = c.wave_in_env % kRows, gbase = (c.wave_in_env - share) * kWave + c.lane;
+            float X[kRows], Y[kRows], ax[kRows], ay[kRows];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+            for (int r = 0; r < kRows; ++r) {
+                const float2 rp = sm.rowpos[par][c.slot][gbase + r * kWave];
+                X[r] = rp.x; Y[r] = rp.y;
+                ax[r] = 0.0f; ay[r] = 0.0f;
+            }
+            const int groups = (n_cols + 3) >> 2;                                  // peers in groups of 4 (padding weighs 0)
+            const int per = (groups + kRows - 1) / kRows;
+            int j = __builtin_amdgcn_readfirstlane(share * per * 4);
+            const int jend = __builtin_amdgcn_readfirstlane(min((share + 1) * per, groups) * 4);
+            if constexpr (!(EVAC_ABLATE & 1)) {
+                constexpr int B = kRows == 2 ? 8 : 4;                              // peers per LDS round trip (register budget)
+                for (; j + B <= jend; j += B) {
+                    f4 t[B];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) pair_accumulate(XI, YI, t[k], r2b, sx, sy);
+                    for (int k = 0; k < B; ++k) t[k] = tile[j + k];
+#pragma unroll
+                    for (int k = 0; k < B; ++k) {
+#pragma unroll
+                        for (int r = 0; r < kRows; ++r) pair_accumulate(X[r], Y[r], t[k], r2b, ax[r], ay[r]);
+                    }
+                }
+                if constexpr (B == 8) {
+                    if (j < jend) {
+                        f4 t[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                            for (int r = 0; r < kRows; ++r) pair_accumulate(X[r], Y[r], t[k], r2b, ax[r], ay[r]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) sm.part[share][c.slot][gbase + r * kWave] = make_float2(ax[r], ay[r]);
+            __syncthreads();
+            const int tid = c.wave_in_env * kWave + c.lane;
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) {      // fixed order: deterministic
+                const float2 pr = sm.part[r][c.slot][tid];
+                sx += pr.x;
+                sy += pr.y;
             }
         }
     }
@@ -273,6 +362,7 @@ struct Cells {
     };
 
     struct Ctx {
+        using Family = Cells<WPE_>;
         Smem& sm;
         int env, slot, wave_in_env, lane, i;
         bool owner;
@@ -292,6 +382,7 @@ struct Cells {
 
     static __device__ __forceinline__ void sync() { __syncthreads(); }
 
+    static __device__ __forceinline__ void invalidate(Ctx&) {}
     // Once per kernel, before the first step: the counters start at zero (afterwards the prefix wave clears them).
     static __device__ __forceinline__ void init(Ctx& c) {
         for (int k = c.i; k < kCells + 4; k += kThreadsPerEnv) c.sm.cnt[k] = 0;
@@ -460,6 +551,7 @@ struct Sub {
     static __device__ __forceinline__ float fetch(float v, int sub_base, int src_i) { return __shfl(v, sub_base + src_i, kWave); }
 
     // Sums valid in the group's last lane (three chains interleaved, see wave_sum3); counts in every lane of the group.
+    static __device__ __forceinline__ void invalidate(Ctx&) {}
     template <bool GUARD, class C>
     static __device__ __forceinline__ void reduce(C& c, Sums& s, const unsigned long long (&pred)[8]) {
         float &a = s.f0, &b = s.f1, &cc = s.f2;
