@@ -353,6 +353,7 @@ def main(argv=None):
 
     run(W)                                                    # W untimed warm-up steps
     barrier()
+    state0 = [t.clone() for t in (loc.ped, loc.status, loc.agent, loc.clock, loc.acc)]   # for the kernel-timing replay below
     n_blocks = per_sweep * sweeps
     wall, phases, block_events = [], [], []
     launches = 0
@@ -373,11 +374,14 @@ def main(argv=None):
 
     # Duration of the dominant kernel's launches, from HIP events on the launching stream.  An event pair around ONE
     # short launch also times the ~7 us between the markers and the kernel (11 % of a 20-step launch), so the average
-    # launch duration is taken over one more sweep of the same blocks issued back to back between two events
+    # launch duration is taken over a replay of the first sweep's blocks (state restored) issued back to back between two events
     # (elapsed / launches: kernel + the ~1.5 us launch boundary) -- this is the figure a
     # `rocprofv3 --kernel-trace --stats` of this command reproduces; the per-launch pairs of the timed blocks give
     # the dense (all N moving) launch, corrected by the mean difference between the two measurements.
     per_launch = [a.elapsed_time(b) * 1e-3 for evs in block_events for a, b, t in evs if t == inner]
+    barrier()
+    for dst, src in zip((loc.ped, loc.status, loc.agent, loc.clock, loc.acc), state0):   # same phases as the first sweep
+        dst.copy_(src)
     barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     back_to_back = 0
