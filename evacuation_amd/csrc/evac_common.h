@@ -182,6 +182,9 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
     v = dpp_addi<0x143, 0xc>(v);
     return v;
 }
+// Lane mask of a predicate.  HIP's __ballot(int) first materialises the bool as 0/1 in a VGPR and compares it with 0
+// again (v_cndmask + v_cmp per call); the builtin takes the condition's mask as it is.
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // Set bits of a ballot as a 32-bit value the compiler knows nothing else about: otherwise (float)count is expanded as a
 // 64-bit integer conversion (s_lshl_b64 / s_min / s_or / v_cvt / v_ldexp) because ctpop's operand is 64 bits wide.
 __device__ __forceinline__ int mask_count(unsigned long long m) {
@@ -189,7 +192,7 @@ __device__ __forceinline__ int mask_count(unsigned long long m) {
     asm("" : "+s"(n));        // (not volatile: an unused count still disappears)
     return n;
 }
-__device__ __forceinline__ int wave_count(bool p) { return mask_count(__ballot(p)); }
+__device__ __forceinline__ int wave_count(bool p) { return mask_count(ballot(p)); }
 __device__ __forceinline__ float readlane_f(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }

@@ -28,7 +28,7 @@ __device__ __forceinline__ void grav_observation(const Params& p, typename F::Ct
     s.f0 = visc ? gx : 0.0f;
     s.f1 = visc ? gy : 0.0f;
     s.f2 = 0.0f;
-    const unsigned long long pred[8] = {__ballot(active && q.st == kFollower), 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long pred[8] = {ballot(active && q.st == kFollower), 0, 0, 0, 0, 0, 0, 0};
     F::template reduce<true>(c, s, pred);
     float ex, ey;
     grav_term(p, e.ax - kExitX, e.ay - kExitY, ex, ey);              // gravity_encoding.py:28-38
@@ -56,7 +56,7 @@ __device__ __forceinline__ void write_obs(const Params& p, typename F::Ctx& c, b
 template <class F>
 __device__ __forceinline__ void finish_counts(typename F::Ctx& c, const Ped& q, StepOut& o) {
     Sums s{};
-    const unsigned long long pred[8] = {__ballot(q.st == kExiting), __ballot(q.st == kViscek), 0, 0, 0, 0, 0, 0};
+    const unsigned long long pred[8] = {ballot(q.st == kExiting), ballot(q.st == kViscek), 0, 0, 0, 0, 0, 0};
     F::template reduce<true>(c, s, pred);
     o.n_exiting = s.i[0];
     o.n_viscek = s.i[1];
@@ -96,7 +96,7 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     q.y = esc ? kExitY : q.y;
     q.dx = esc ? 0.0f : q.dx;
     q.dy = esc ? 0.0f : q.dy;
-    if (__ballot(exi) != 0ull) {                                            // area.py:84-90 (area.py:85 `if any(exiting)`)
+    if (ballot(exi) != 0ull) {                                            // area.py:84-90 (area.py:85 `if any(exiting)`)
         const float vx = kExitX - q.x, vy = kExitY - q.y;
         const float l2 = vx * vx + vy * vy;
         const float il = frsq(l2);
@@ -184,11 +184,11 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     // per-step counts: the two reward transitions, escaped (termination) and followers (gravity exit term);
     // exiting / viscek counts are only part of the episode record and are taken at episode end.
     const unsigned long long pred[8] = {
-        __ballot((old_st == kViscek || old_st == kFollower) && new_st == kExiting),    // reward.py:35-39
-        __ballot(old_st == kViscek && new_st == kFollower),                             // reward.py:43-46
-        __ballot(new_st == kEscaped),
-        __ballot((unsigned)(new_st - kViscek) < 3u),      // moves at the next step (only the multi-wave all-pairs family uses it)
-        __ballot(new_st == kFollower), 0, 0, 0};
+        ballot((old_st == kViscek || old_st == kFollower) && new_st == kExiting),    // reward.py:35-39
+        ballot(old_st == kViscek && new_st == kFollower),                             // reward.py:43-46
+        ballot(new_st == kEscaped),
+        ballot((unsigned)(new_st - kViscek) < 3u),      // moves at the next step (only the multi-wave all-pairs family uses it)
+        ballot(new_st == kFollower), 0, 0, 0};
     if constexpr (GRAV) F::exit_publish(c, exit_lane, gx, gy);
     if constexpr (!(EVAC_ABLATE & 8)) F::template reduce<false>(c, s, pred);
     if constexpr (GRAV) {
@@ -209,12 +209,19 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     out.n_follower = s.i[4];
     out.n_exiting = out.n_viscek = 0;   // filled by finish_counts() when the episode ends
 
-    const float tf = 1.0f - (float)e.now * p.inv_200n;                      // reward.py:26
     float r_ped = p.init_reward;
-    if constexpr (F::kEnvUniform) {   // uniform branches: usually no transition
-        if ((p.flags & kFlagNewExitingReward) && s.i[0]) r_ped += (15.0f + 10.0f * tf) * (float)s.i[0];
-        if ((p.flags & kFlagNewFollowersReward) && s.i[1]) r_ped += (10.0f + 5.0f * tf) * (float)s.i[1];
+    if constexpr (F::kEnvUniform) {
+        // Real uniform branches (the empty asm keeps the compiler from if-converting them into always-executed
+        // arithmetic + selects): on most steps nobody changes status and the bonus terms are skipped.
+        const int moved = ((p.flags & kFlagNewExitingReward) ? s.i[0] : 0) | ((p.flags & kFlagNewFollowersReward) ? s.i[1] : 0);
+        if (moved != 0) {
+            asm volatile("");
+            const float tf = 1.0f - (float)e.now * p.inv_200n;              // reward.py:26
+            if (p.flags & kFlagNewExitingReward) r_ped += (15.0f + 10.0f * tf) * (float)s.i[0];
+            if (p.flags & kFlagNewFollowersReward) r_ped += (10.0f + 5.0f * tf) * (float)s.i[1];
+        }
     } else {                          // counts differ between the envs of a wave: selects
+        const float tf = 1.0f - (float)e.now * p.inv_200n;                  // reward.py:26
         r_ped += (p.flags & kFlagNewExitingReward) ? (15.0f + 10.0f * tf) * (float)s.i[0] : 0.0f;
         r_ped += (p.flags & kFlagNewFollowersReward) ? (10.0f + 5.0f * tf) * (float)s.i[1] : 0.0f;
     }

@@ -195,7 +195,7 @@ struct Wave {
         // n_efv iterations.
         int n_cols;
         {
-            const unsigned long long m = __ballot(efv);
+            const unsigned long long m = ballot(efv);
             int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
             n_cols = __popcll(m);
             if constexpr (WPE > 1) {
@@ -229,7 +229,7 @@ struct Wave {
         const float r2b = kRPed2Big;
         if constexpr (WPE == 1) {
             // rows of the distance matrix exist only for FOLLOWER/VISCEK pedestrians (area.py:104)
-            const bool any_fv = __ballot(fv) != 0ull;
+            const bool any_fv = ballot(fv) != 0ull;
             // Branch-free batches: the B wave-uniform ds_read_b128 broadcasts are issued back to
             // back (LDS latency paid once per batch, no VALU slot), then 6 full-rate VALU ops per pair.
             const int n8 = __builtin_amdgcn_readfirstlane(any_fv ? ((n_cols + 3) & ~3) : 0);   // no rows -> no loop
@@ -578,7 +578,7 @@ struct Sub {
                                                          float ux, float uy, float& sx, float& sy) {
         auto& sm = c.sm;
         sync();   // tile readers of the previous step are done
-        const unsigned long long m_efv = __ballot(efv);
+        const unsigned long long m_efv = ballot(efv);
         const int n_cols = count(m_efv, c.gmask);
         {
             const int before = rank(m_efv, c.gmask);
@@ -596,7 +596,7 @@ struct Sub {
             const int k = __popcll((m_efv >> (g * G)) & kGroupBits);
             nmax = k > nmax ? k : nmax;
         }
-        const int n4 = (__ballot(fv) != 0ull) ? ((nmax + 3) & ~3) : 0;
+        const int n4 = (ballot(fv) != 0ull) ? ((nmax + 3) & ~3) : 0;
         const f4* __restrict__ tile = sm.tile[c.slot];           // per lane: its group's tile
         const float XI = q.x * kTileScale, YI = q.y * kTileScale;
         int j = 0;

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_step_sub(
     const bool done = (o.terminated || o.truncated) && autoreset;
     const bool owner = valid && w.owner;
     float o6[6] = {e.ax, e.ay, o.ex, o.ey, o.gx, o.gy};
-    if (__ballot(done) != 0ull) {              // wave-uniform: some group finished
+    if (ballot(done) != 0ull) {              // wave-uniform: some group finished
         if (done && valid && final_obs) {
             float* fo = final_obs + (size_t)w.env * p.obs_dim;
             if constexpr (GRAV) {
@@ -154,7 +154,7 @@ __device__ __forceinline__ void rollout_body_sub(typename Sub<G>::Smem& sm, cons
         }
         float o6[6] = {e.ax, e.ay, o.ex, o.ey, o.gx, o.gy};
         const bool done = o.terminated || o.truncated;
-        if (__ballot(done) != 0ull)
+        if (ballot(done) != 0ull)
             autoreset_sub<G, GRAV>(p, w, active, done, gid, q, e, o, o6,
                                    (final_stats && valid) ? final_stats + (size_t)t * E + w.env : nullptr);
         if (valid) {
