@@ -60,6 +60,7 @@ SIGNATURES = {
     "evac_observe": (C.c_int, [_P, _P, _P]),
     "evac_algorithmic_bytes_per_env_step": (C.c_int64, [_P]),
     "evac_norm_state_doubles": (C.c_int64, [_P]),
+    "evac_step_normalized": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "evac_norm_init": (C.c_int, [_P, _P, _P]),
     "evac_norm_reset": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, _P]),
     "evac_norm_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P]),

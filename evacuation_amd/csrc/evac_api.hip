@@ -292,17 +292,36 @@ int evac_reset(evac_handle_t h, const uint8_t* mask, const float* draws, float* 
     return check_launch(h, "evac_reset");
 }
 
+#define EVAC_STEP_ARGS h->p, (const float2*)actions, noise, obs_out, reward_out, terminated_out, truncated_out, (int)autoreset, final_obs, final_stats, na
+
+static int step_common(evac_handle_t h, const char* name, const float* actions, const float* noise, float* obs_out,
+                       float* reward_out, uint8_t* terminated_out, uint8_t* truncated_out, int32_t autoreset, float* final_obs,
+                       evac_episode_stats_t* final_stats, const evac::NormArgs& na, void* stream) {
+    if (!actions || !obs_out || !reward_out || !terminated_out || !truncated_out)
+        return fail(h, EVAC_ERR_INVALID_ARGUMENT, std::string(name) + ": actions/obs/reward/terminated/truncated must be non-NULL");
+    if ((uintptr_t)actions & 7u) return fail(h, EVAC_ERR_INVALID_ARGUMENT, std::string(name) + ": actions must be 8-byte aligned");
+    DeviceGuard g(h->device);
+    if (na.state) EVAC_DISPATCH(h, k_step_norm, stream, EVAC_STEP_ARGS);
+    else EVAC_DISPATCH(h, k_step_raw, stream, EVAC_STEP_ARGS);
+    return check_launch(h, name);
+}
+
 int evac_step(evac_handle_t h, const float* actions, const float* noise, float* obs_out, float* reward_out,
               uint8_t* terminated_out, uint8_t* truncated_out, int32_t autoreset, float* final_obs,
               evac_episode_stats_t* final_stats, void* stream) {
     EVAC_REQUIRE_BOUND(h, "evac_step");
-    if (!actions || !obs_out || !reward_out || !terminated_out || !truncated_out)
-        return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_step: actions/obs/reward/terminated/truncated must be non-NULL");
-    if ((uintptr_t)actions & 7u) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_step: actions must be 8-byte aligned");
-    DeviceGuard g(h->device);
-    EVAC_DISPATCH(h, k_step, stream, h->p, (const float2*)actions, noise, obs_out, reward_out, terminated_out,
-                  truncated_out, (int)autoreset, final_obs, final_stats);
-    return check_launch(h, "evac_step");
+    return step_common(h, "evac_step", actions, noise, obs_out, reward_out, terminated_out, truncated_out, autoreset, final_obs,
+                       final_stats, evac::NormArgs{nullptr, 0.f, 0.f, 0.f, 0.f}, stream);
+}
+
+int evac_step_normalized(evac_handle_t h, const float* actions, const float* noise, float* obs_out, float* reward_out,
+                         uint8_t* terminated_out, uint8_t* truncated_out, int32_t autoreset, float* final_obs,
+                         evac_episode_stats_t* final_stats, double* norm_state, float gamma, float obs_clip,
+                         float reward_clip, float epsilon, void* stream) {
+    EVAC_REQUIRE_BOUND(h, "evac_step_normalized");
+    if (!norm_state) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_step_normalized: norm_state is NULL");
+    return step_common(h, "evac_step_normalized", actions, noise, obs_out, reward_out, terminated_out, truncated_out, autoreset,
+                       final_obs, final_stats, evac::NormArgs{norm_state, gamma, obs_clip, reward_clip, epsilon}, stream);
 }
 
 int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* actions_out, float* slab_out,

@@ -337,10 +337,54 @@ __device__ __forceinline__ void grav_term(const Params& p, float rx, float ry, f
     grav_term2(p, rx, ry, rx * rx + ry * ry, gx, gy);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Running statistics of the trainer's wrapper chain (rpo_agent.py:24-33: NormalizeObservation / NormalizeReward):
+// gymnasium's RunningMeanStd update for a batch of one sample, float64 like gymnasium's.
+// norm_state per env: obs_mean[D] | obs_var[D] | obs_count[D] | ret_mean | ret_var | ret_count | returns
+// (the count is replicated per feature so that threads never share a word).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rms_update1(double& mean, double& var, double& count, double x) {
+    const double delta = x - mean;
+    const double tot = count + 1.0;
+    const double new_mean = mean + delta / tot;
+    const double m2 = var * count + delta * delta * count / tot;
+    mean = new_mean;
+    var = m2 / tot;
+    count = tot;
+}
+__device__ __forceinline__ float norm_clip(double x, double mean, double var, double eps, float clip) {
+    const double v = (x - mean) / sqrt(var + eps);
+    return (float)fmin(fmax(v, -(double)clip), (double)clip);
+}
+// what evac_step_normalized passes to the step kernel (state == nullptr: plain evac_step)
+struct NormArgs {
+    double* state;
+    float gamma, obs_clip, reward_clip, eps;
+};
+// Store policies of the observation epilogue: plain, or counted + normalised + clipped in place (one thread owns one
+// feature of one env, for the terminal observation and the reset observation alike, so the two updates are ordered).
+struct StorePlain {
+    float* __restrict__ p;
+    __device__ __forceinline__ void operator()(int idx, float v) const { p[idx] = v; }
+};
+struct StoreNorm {
+    float* __restrict__ p;
+    double* __restrict__ s;     // norm_state of this env
+    int D;
+    float eps, clip;
+    __device__ __forceinline__ void operator()(int idx, float v) const {
+        double mean = s[idx], var = s[D + idx], cnt = s[2 * D + idx];
+        rms_update1(mean, var, cnt, (double)v);
+        s[idx] = mean; s[D + idx] = var; s[2 * D + idx] = cnt;
+        p[idx] = norm_clip((double)v, mean, var, (double)eps, clip);
+    }
+};
+
 // Positions / statuses observations (abs | rel) x (no | ohe | cat) x (Dict | Box): env.py:98-104, wrappers.py:8-96.
 // Purely per-lane writes (lane i owns pedestrian row i; lane 0 also writes the agent and exit rows).
+template <class Store>
 __device__ __forceinline__ void write_obs_generic(const Params& p, int i, bool active, const Ped& q, const Env& e,
-                                                  float* __restrict__ obs) {
+                                                  Store obs) {
     const bool rel = p.obs_pos == EVAC_POS_REL;
     const float ihyp = 0.70710678118f;                                // wrappers.py:12-18: 1/sqrt(1+1)
     float px = q.x, py = q.y, ex = kExitX, ey = kExitY;
@@ -354,30 +398,30 @@ __device__ __forceinline__ void write_obs_generic(const Params& p, int i, bool a
     if (p.obs_box) {                                                  // wrappers.py:77-96
         const int C = p.obs_stat == EVAC_STAT_OHE ? 6 : (p.obs_stat == EVAC_STAT_CAT ? 3 : 2);
         if (i == 0) {
-            obs[0] = e.ax;
-            obs[1] = e.ay;
-            obs[C + 0] = ex;
-            obs[C + 1] = ey;
+            obs(0, e.ax);
+            obs(1, e.ay);
+            obs(C + 0, ex);
+            obs(C + 1, ey);
             if (p.obs_stat == EVAC_STAT_OHE) {
-                obs[2] = obs[3] = obs[4] = obs[5] = 0.0f;
-                obs[C + 2] = 1.0f;
-                obs[C + 3] = obs[C + 4] = obs[C + 5] = 0.0f;
+                obs(2, 0.0f); obs(3, 0.0f); obs(4, 0.0f); obs(5, 0.0f);
+                obs(C + 2, 1.0f);
+                obs(C + 3, 0.0f); obs(C + 4, 0.0f); obs(C + 5, 0.0f);
             } else if (p.obs_stat == EVAC_STAT_CAT) {
-                obs[2] = 0.0f;
-                obs[C + 2] = 1.0f;
+                obs(2, 0.0f);
+                obs(C + 2, 1.0f);
             }
         }
         if (active) {
-            float* row = obs + (size_t)(i + 2) * C;
-            row[0] = px;
-            row[1] = py;
+            const int row = (i + 2) * C;
+            obs(row + 0, px);
+            obs(row + 1, py);
             if (p.obs_stat == EVAC_STAT_OHE) {
-                row[2] = code == 0 ? 1.0f : 0.0f;
-                row[3] = code == 1 ? 1.0f : 0.0f;
-                row[4] = code == 2 ? 1.0f : 0.0f;
-                row[5] = code == 3 ? 1.0f : 0.0f;
+                obs(row + 2, code == 0 ? 1.0f : 0.0f);
+                obs(row + 3, code == 1 ? 1.0f : 0.0f);
+                obs(row + 4, code == 2 ? 1.0f : 0.0f);
+                obs(row + 5, code == 3 ? 1.0f : 0.0f);
             } else if (p.obs_stat == EVAC_STAT_CAT) {
-                row[2] = (float)code * 0.25f;
+                obs(row + 2, (float)code * 0.25f);
             }
         }
         return;
@@ -385,22 +429,22 @@ __device__ __forceinline__ void write_obs_generic(const Params& p, int i, bool a
     // Dict, flattened in gymnasium key order: agent, exit, pedestrians_positions, pedestrians_statuses
     const int N = p.n_ped;
     if (i == 0) {
-        obs[0] = e.ax;
-        obs[1] = e.ay;
-        obs[2] = ex;
-        obs[3] = ey;
+        obs(0, e.ax);
+        obs(1, e.ay);
+        obs(2, ex);
+        obs(3, ey);
     }
     if (active) {
-        obs[4 + 2 * i] = px;
-        obs[5 + 2 * i] = py;
-        float* st = obs + 4 + 2 * N;
+        obs(4 + 2 * i, px);
+        obs(5 + 2 * i, py);
+        const int st = 4 + 2 * N;
         if (p.obs_stat == EVAC_STAT_OHE) {                            // wrappers.py:50-54
-            st[4 * i + 0] = code == 0 ? 1.0f : 0.0f;
-            st[4 * i + 1] = code == 1 ? 1.0f : 0.0f;
-            st[4 * i + 2] = code == 2 ? 1.0f : 0.0f;
-            st[4 * i + 3] = code == 3 ? 1.0f : 0.0f;
+            obs(st + 4 * i + 0, code == 0 ? 1.0f : 0.0f);
+            obs(st + 4 * i + 1, code == 1 ? 1.0f : 0.0f);
+            obs(st + 4 * i + 2, code == 2 ? 1.0f : 0.0f);
+            obs(st + 4 * i + 3, code == 3 ? 1.0f : 0.0f);
         } else if (p.obs_stat == EVAC_STAT_CAT) {                     // wrappers.py:55-56
-            st[i] = (float)code * 0.25f;
+            obs(st + i, (float)code * 0.25f);
         }
     }
 }

@@ -47,7 +47,7 @@ __device__ __forceinline__ void write_obs(const Params& p, typename F::Ctx& c, b
             for (int k = 0; k < 6; ++k) obs[k] = o6[k];
         }
     } else {
-        if (store) write_obs_generic(p, c.i, active, q, e, obs);
+        if (store) write_obs_generic(p, c.i, active, q, e, StorePlain{obs});
     }
 }
 
@@ -238,12 +238,93 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
 // Kernels of the Wave / Cells families.  __launch_bounds__(block, 4): at least 4 waves per SIMD, i.e. at most
 // 128 VGPRs -- the 4-wave kernel once grew to 135 and silently lost a quarter of its occupancy.
 // ------------------------------------------------------------------------------------------------
-template <class F, bool GRAV>
-__global__ __launch_bounds__(F::kBlock, 4) void k_step(
-    Params p, const float2* __restrict__ actions, const float* __restrict__ noise_in, float* __restrict__ obs_out,
-    float* __restrict__ reward_out, uint8_t* __restrict__ term_out, uint8_t* __restrict__ trunc_out, int autoreset,
-    float* __restrict__ final_obs, evac_episode_stats_t* __restrict__ final_stats) {
-    __shared__ typename F::Smem sm;
+// The observation / reward outputs of one env step, optionally through the trainer's normalisation chain (NORM; the
+// fused form of evac_norm_step): every thread normalises the observation elements it writes, terminal observation
+// before reset observation (the order in which SyncVectorEnv runs the wrapped step() and reset()); for the gravity
+// observation lanes 0..5 of the env take one feature each, lane 6 the reward.
+template <class F, bool GRAV, bool NORM>
+__device__ __forceinline__ void step_outputs(const Params& p, typename F::Ctx& w, bool active, Ped& q, Env& e, StepOut& o,
+                                             uint32_t gid, int autoreset, float* __restrict__ obs_out,
+                                             float* __restrict__ reward_out, uint8_t* __restrict__ term_out,
+                                             uint8_t* __restrict__ trunc_out, float* __restrict__ final_obs,
+                                             evac_episode_stats_t* __restrict__ final_stats, const NormArgs& na) {
+    const bool done = o.terminated || o.truncated;
+    const int D = p.obs_dim;
+    float* obs = obs_out + (size_t)w.env * D;
+    float* fo = final_obs ? final_obs + (size_t)w.env * D : nullptr;
+    double* ns = NORM ? na.state + (size_t)w.env * (3 * D + 4) : nullptr;
+    float o6[6] = {e.ax, e.ay, o.ex, o.ey, o.gx, o.gy};   // GRAV: the observation came out of step_env's reduction
+    float t6[6] = {o6[0], o6[1], o6[2], o6[3], o6[4], o6[5]};
+    const bool reset_now = done && autoreset;
+    if (reset_now) {
+        if constexpr (!GRAV) {
+            if (fo) {
+                if constexpr (NORM) write_obs_generic(p, w.i, active, q, e, StoreNorm{fo, ns, D, na.eps, na.obs_clip});
+                else write_obs_generic(p, w.i, active, q, e, StorePlain{fo});
+            }
+        }
+        if (final_stats) {
+            finish_counts<F>(w, q, o);
+            if (w.owner) write_stats(final_stats + w.env, e, o);
+        }
+        reset_env(p, active, philox_reset_draw(p, gid, w.i, e.n_resets), q, e);
+        if constexpr (GRAV) grav_observation<F>(p, w, active, q, e, o6);
+    }
+    if constexpr (GRAV) {
+        if constexpr (!NORM) {
+            if (w.owner) {
+                if (reset_now && fo) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) fo[k] = t6[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) obs[k] = o6[k];
+            }
+        } else if constexpr (F::kEnvUniform) {
+            // the six numbers are uniform over the env's first wave: lane k owns feature k
+            if (w.i < 6) {
+                const int k = w.i;
+                float tv = t6[0], ov = o6[0];
+#pragma unroll
+                for (int j = 1; j < 6; ++j) { tv = k == j ? t6[j] : tv; ov = k == j ? o6[j] : ov; }
+                if (reset_now && fo) StoreNorm{fo, ns, D, na.eps, na.obs_clip}(k, tv);
+                StoreNorm{obs, ns, D, na.eps, na.obs_clip}(k, ov);
+            }
+        } else if (w.owner) {   // several envs per wave: the sums are valid in the owner lane only
+            if (reset_now && fo) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) StoreNorm{fo, ns, D, na.eps, na.obs_clip}(k, t6[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) StoreNorm{obs, ns, D, na.eps, na.obs_clip}(k, o6[k]);
+        }
+    } else {
+        if constexpr (NORM) write_obs_generic(p, w.i, active, q, e, StoreNorm{obs, ns, D, na.eps, na.obs_clip});
+        else write_obs_generic(p, w.i, active, q, e, StorePlain{obs});
+    }
+    const bool reward_lane = (NORM && GRAV && F::kEnvUniform) ? w.i == 6 : w.owner;
+    if (reward_lane) {
+        float r = o.reward;
+        if constexpr (NORM) {   // gymnasium NormalizeReward: returns = returns * gamma * (1 - terminated) + r; r / sqrt(var + eps)
+            double mean = ns[3 * D], var = ns[3 * D + 1], cnt = ns[3 * D + 2], ret = ns[3 * D + 3];
+            ret = ret * (double)na.gamma * (o.terminated ? 0.0 : 1.0) + (double)r;
+            rms_update1(mean, var, cnt, ret);
+            const double v = (double)r / sqrt(var + (double)na.eps);
+            r = (float)fmin(fmax(v, -(double)na.reward_clip), (double)na.reward_clip);
+            ns[3 * D] = mean; ns[3 * D + 1] = var; ns[3 * D + 2] = cnt; ns[3 * D + 3] = ret;
+        }
+        reward_out[w.env] = r;
+        term_out[w.env] = o.terminated ? 1 : 0;
+        trunc_out[w.env] = o.truncated ? 1 : 0;
+    }
+}
+
+template <class F, bool GRAV, bool NORM>
+__device__ __forceinline__ void step_kernel_body(
+    typename F::Smem& sm, const Params& p, const float2* __restrict__ actions, const float* __restrict__ noise_in,
+    float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ term_out,
+    uint8_t* __restrict__ trunc_out, int autoreset, float* __restrict__ final_obs,
+    evac_episode_stats_t* __restrict__ final_stats, const NormArgs& na) {
     typename F::Ctx w(sm);
     if (w.env >= p.n_envs) return;   // whole waves (WPE == 1) or whole workgroups: no barrier is skipped by a subset
     F::init(w);
@@ -257,43 +338,24 @@ __global__ __launch_bounds__(F::kBlock, 4) void k_step(
     if (active) nz = noise_in ? noise_in[(size_t)w.env * p.n_ped + w.i] : philox_noise(p, gid, w.i, e.total);
     StepOut o;
     step_env<F, GRAV>(p, w, active, q, e, agent_direction(p, a.x, a.y), nz, o);
-    const bool done = o.terminated || o.truncated;
-    float* obs = obs_out + (size_t)w.env * p.obs_dim;
-    float o6[6] = {e.ax, e.ay, o.ex, o.ey, o.gx, o.gy};   // GRAV: the observation came out of step_env's reduction
-    if (done && autoreset) {
-        if (final_obs) {
-            float* fo = final_obs + (size_t)w.env * p.obs_dim;
-            if constexpr (GRAV) {
-                if (w.owner) {
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) fo[k] = o6[k];
-                }
-            } else {
-                write_obs_generic(p, w.i, active, q, e, fo);
-            }
-        }
-        if (final_stats) {
-            finish_counts<F>(w, q, o);
-            if (w.owner) write_stats(final_stats + w.env, e, o);
-        }
-        reset_env(p, active, philox_reset_draw(p, gid, w.i, e.n_resets), q, e);
-        if constexpr (GRAV) grav_observation<F>(p, w, active, q, e, o6);
-    }
-    if constexpr (GRAV) {
-        if (w.owner) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) obs[k] = o6[k];
-        }
-    } else {
-        write_obs_generic(p, w.i, active, q, e, obs);
-    }
+    step_outputs<F, GRAV, NORM>(p, w, active, q, e, o, gid, autoreset, obs_out, reward_out, term_out, trunc_out, final_obs,
+                                final_stats, na);
     store_env(p, w.env, w.i, active, w.owner, q, e);
-    if (w.owner) {
-        reward_out[w.env] = o.reward;
-        term_out[w.env] = o.terminated ? 1 : 0;
-        trunc_out[w.env] = o.truncated ? 1 : 0;
-    }
 }
+// evac_step / evac_step_normalized
+#define EVAC_STEP_KERNEL(NAME, NORM_)                                                                                          \
+    template <class F, bool GRAV>                                                                                              \
+    __global__ __launch_bounds__(F::kBlock, 4) void NAME(                                                                       \
+        Params p, const float2* __restrict__ actions, const float* __restrict__ noise_in, float* __restrict__ obs_out,          \
+        float* __restrict__ reward_out, uint8_t* __restrict__ term_out, uint8_t* __restrict__ trunc_out, int autoreset,         \
+        float* __restrict__ final_obs, evac_episode_stats_t* __restrict__ final_stats, NormArgs na) {                           \
+        __shared__ typename F::Smem sm;                                                                                         \
+        step_kernel_body<F, GRAV, NORM_>(sm, p, actions, noise_in, obs_out, reward_out, term_out, trunc_out, autoreset, final_obs, \
+                                         final_stats, na);                                                                      \
+    }
+EVAC_STEP_KERNEL(k_step_raw, false)
+EVAC_STEP_KERNEL(k_step_norm, true)
+#undef EVAC_STEP_KERNEL
 
 // T steps per launch, state in registers (rpo_agent.py:180-203 rollout loop, RandomAgent or given actions).
 // Output: ONE packed f32 slab [T][E][D+3] = [obs(D) | reward | terminated | truncated] -- a single message
@@ -412,7 +474,7 @@ __device__ __forceinline__ void rollout_body(
                 }
             }
         } else {
-            if constexpr (!(EVAC_ABLATE & 2)) write_obs_generic(p, w.i, active, q, e, rowp);
+            if constexpr (!(EVAC_ABLATE & 2)) write_obs_generic(p, w.i, active, q, e, StorePlain{rowp});
             if (w.owner && !(EVAC_ABLATE & 16)) {
                 rowp[p.obs_dim + 0] = o.reward;
                 rowp[p.obs_dim + 1] = f_term;
@@ -515,25 +577,10 @@ __global__ void k_set_state(Params p, const float2* pos, const float2* dir, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// The trainer's per-env wrapper chain as a device epilogue (rpo_agent.py:24-33): NormalizeObservation,
-// clip, NormalizeReward(gamma), clip.  gymnasium's RunningMeanStd update for a batch of one sample,
-// float64 like gymnasium's.  norm_state per env: obs_mean[D] | obs_var[D] | obs_count[D] | ret_mean |
-// ret_var | ret_count | returns  (the count is replicated per feature so that threads never share a word).
+// The trainer's per-env wrapper chain as a SEPARATE epilogue (rpo_agent.py:24-33): used for resets (evac_norm_reset) and
+// kept as the unfused reference of evac_step_normalized (tests/test_gpu_wrappers.py); the statistics themselves are in
+// evac_common.h (rms_update1, norm_clip).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void rms_update1(double& mean, double& var, double& count, double x) {
-    const double delta = x - mean;
-    const double tot = count + 1.0;
-    const double new_mean = mean + delta / tot;
-    const double m2 = var * count + delta * delta * count / tot;
-    mean = new_mean;
-    var = m2 / tot;
-    count = tot;
-}
-__device__ __forceinline__ float norm_clip(double x, double mean, double var, double eps, float clip) {
-    const double v = (x - mean) / sqrt(var + eps);
-    return (float)fmin(fmax(v, -(double)clip), (double)clip);
-}
-
 __global__ void k_norm_init(int n_envs, int D, double* __restrict__ st) {
     const int W = 3 * D + 4;
     const size_t n = (size_t)n_envs * W;

@@ -30,13 +30,13 @@ __device__ __forceinline__ void autoreset_sub(const Params& p, typename Sub<G>::
     }
 }
 
-template <int G, bool GRAV>
-__global__ __launch_bounds__(256) void k_step_sub(
-    Params p, const float2* __restrict__ actions, const float* __restrict__ noise_in, float* __restrict__ obs_out,
-    float* __restrict__ reward_out, uint8_t* __restrict__ term_out, uint8_t* __restrict__ trunc_out, int autoreset,
-    float* __restrict__ final_obs, evac_episode_stats_t* __restrict__ final_stats) {
+template <int G, bool GRAV, bool NORM>
+__device__ __forceinline__ void step_kernel_body_sub(
+    typename Sub<G>::Smem& sm, const Params& p, const float2* __restrict__ actions, const float* __restrict__ noise_in,
+    float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ term_out,
+    uint8_t* __restrict__ trunc_out, int autoreset, float* __restrict__ final_obs,
+    evac_episode_stats_t* __restrict__ final_stats, const NormArgs& na) {
     using F = Sub<G>;
-    __shared__ typename F::Smem sm;
     typename F::Ctx w(sm);
     const bool valid = w.env < p.n_envs;
     if (!valid) w.env = p.n_envs - 1;          // idle groups shadow the last env (same wave must stay converged); no stores
@@ -52,39 +52,71 @@ __global__ __launch_bounds__(256) void k_step_sub(
     step_env<F, GRAV>(p, w, active, q, e, agent_direction(p, a.x, a.y), nz, o);
     const bool done = (o.terminated || o.truncated) && autoreset;
     const bool owner = valid && w.owner;
+    const int D = p.obs_dim;
+    double* ns = NORM ? na.state + (size_t)w.env * (3 * D + 4) : nullptr;   // the trainer's normalisation chain, fused (see step_outputs)
     float o6[6] = {e.ax, e.ay, o.ex, o.ey, o.gx, o.gy};
     if (ballot(done) != 0ull) {              // wave-uniform: some group finished
         if (done && valid && final_obs) {
-            float* fo = final_obs + (size_t)w.env * p.obs_dim;
+            float* fo = final_obs + (size_t)w.env * D;
             if constexpr (GRAV) {
                 if (owner) {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) fo[k] = o6[k];
+                    for (int k = 0; k < 6; ++k) {
+                        if constexpr (NORM) StoreNorm{fo, ns, D, na.eps, na.obs_clip}(k, o6[k]);
+                        else fo[k] = o6[k];
+                    }
                 }
             } else {
-                write_obs_generic(p, w.i, active, q, e, fo);
+                if constexpr (NORM) write_obs_generic(p, w.i, active, q, e, StoreNorm{fo, ns, D, na.eps, na.obs_clip});
+                else write_obs_generic(p, w.i, active, q, e, StorePlain{fo});
             }
         }
         autoreset_sub<G, GRAV>(p, w, active, done, gid, q, e, o, o6, (final_stats && valid) ? final_stats + w.env : nullptr);
     }
     if (valid) {
-        float* obs = obs_out + (size_t)w.env * p.obs_dim;
+        float* obs = obs_out + (size_t)w.env * D;
         if constexpr (GRAV) {
             if (owner) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) obs[k] = o6[k];
+                for (int k = 0; k < 6; ++k) {
+                    if constexpr (NORM) StoreNorm{obs, ns, D, na.eps, na.obs_clip}(k, o6[k]);
+                    else obs[k] = o6[k];
+                }
             }
         } else {
-            write_obs_generic(p, w.i, active, q, e, obs);
+            if constexpr (NORM) write_obs_generic(p, w.i, active, q, e, StoreNorm{obs, ns, D, na.eps, na.obs_clip});
+            else write_obs_generic(p, w.i, active, q, e, StorePlain{obs});
         }
     }
     store_env(p, w.env, w.i, valid && active, owner, q, e);
     if (owner) {
-        reward_out[w.env] = o.reward;
+        float r = o.reward;
+        if constexpr (NORM) {
+            double mean = ns[3 * D], var = ns[3 * D + 1], cnt = ns[3 * D + 2], ret = ns[3 * D + 3];
+            ret = ret * (double)na.gamma * (o.terminated ? 0.0 : 1.0) + (double)r;
+            rms_update1(mean, var, cnt, ret);
+            const double v = (double)r / sqrt(var + (double)na.eps);
+            r = (float)fmin(fmax(v, -(double)na.reward_clip), (double)na.reward_clip);
+            ns[3 * D] = mean; ns[3 * D + 1] = var; ns[3 * D + 2] = cnt; ns[3 * D + 3] = ret;
+        }
+        reward_out[w.env] = r;
         term_out[w.env] = o.terminated ? 1 : 0;
         trunc_out[w.env] = o.truncated ? 1 : 0;
     }
 }
+#define EVAC_STEP_KERNEL_SUB(NAME, NORM_)                                                                                       \
+    template <int G, bool GRAV>                                                                                                \
+    __global__ __launch_bounds__(256) void NAME(                                                                                \
+        Params p, const float2* __restrict__ actions, const float* __restrict__ noise_in, float* __restrict__ obs_out,          \
+        float* __restrict__ reward_out, uint8_t* __restrict__ term_out, uint8_t* __restrict__ trunc_out, int autoreset,         \
+        float* __restrict__ final_obs, evac_episode_stats_t* __restrict__ final_stats, NormArgs na) {                           \
+        __shared__ typename Sub<G>::Smem sm;                                                                                    \
+        step_kernel_body_sub<G, GRAV, NORM_>(sm, p, actions, noise_in, obs_out, reward_out, term_out, trunc_out, autoreset,      \
+                                             final_obs, final_stats, na);                                                       \
+    }
+EVAC_STEP_KERNEL_SUB(k_step_raw_sub, false)
+EVAC_STEP_KERNEL_SUB(k_step_norm_sub, true)
+#undef EVAC_STEP_KERNEL_SUB
 
 template <int G, bool GRAV, bool DIAG>
 __device__ __forceinline__ void rollout_body_sub(typename Sub<G>::Smem& sm, const Params& p, int n_steps,
@@ -165,7 +197,7 @@ __device__ __forceinline__ void rollout_body_sub(typename Sub<G>::Smem& sm, cons
                     for (int k = 0; k < 6; ++k) rowp[k] = o6[k];
                 }
             } else {
-                write_obs_generic(p, w.i, active, q, e, rowp);
+                write_obs_generic(p, w.i, active, q, e, StorePlain{rowp});
             }
             if (owner) {
                 rowp[p.obs_dim + 0] = o.reward;

@@ -217,7 +217,7 @@ class BatchedEvacuationEnv:
         self._was_reset = True
         return self.obs, {}
 
-    def step(self, actions, noise=None, *, out_obs=None, out_reward=None, out_terminated=None, out_truncated=None):
+    def step(self, actions, noise=None, *, out_obs=None, out_reward=None, out_terminated=None, out_truncated=None, _norm=None):
         """EvacuationEnv.step + wrappers for the batch (env.py:141-171).  ``actions`` [E,2] f32 on
         the device; ``noise`` [E,N] injects the per-pedestrian angular noise (parity tests).
 
@@ -236,10 +236,16 @@ class BatchedEvacuationEnv:
         rew = self.reward if out_reward is None else self._check_tensor(out_reward, (E,), torch.float32, "out_reward")
         term = self.terminated if out_terminated is None else self._check_tensor(out_terminated, (E,), torch.uint8, "out_terminated")
         trunc = self.truncated if out_truncated is None else self._check_tensor(out_truncated, (E,), torch.uint8, "out_truncated")
-        _lib.check(self.lib.evac_step(self._h, _ptr(act), _ptr(nz), _ptr(obs), _ptr(rew), _ptr(term), _ptr(trunc),
-                                      int(self.autoreset),
-                                      _ptr(self.final_obs) if self.autoreset else None,
-                                      _ptr(self.final_stats) if self.autoreset else None, self._stream()), self._h)
+        fo = _ptr(self.final_obs) if self.autoreset else None
+        fs = _ptr(self.final_stats) if self.autoreset else None
+        if _norm is None:
+            _lib.check(self.lib.evac_step(self._h, _ptr(act), _ptr(nz), _ptr(obs), _ptr(rew), _ptr(term), _ptr(trunc),
+                                          int(self.autoreset), fo, fs, self._stream()), self._h)
+        else:       # NormalizedVectorEnv: the trainer's normalisation chain fused into the same launch
+            state, gamma, obs_clip, reward_clip, eps = _norm
+            _lib.check(self.lib.evac_step_normalized(self._h, _ptr(act), _ptr(nz), _ptr(obs), _ptr(rew), _ptr(term), _ptr(trunc),
+                                                     int(self.autoreset), fo, fs, _ptr(state), gamma, obs_clip, reward_clip,
+                                                     eps, self._stream()), self._h)
         infos = {}
         if self.autoreset:
             # device tensors; rows are meaningful where terminated | truncated (no host sync unless "final_info" is asked for)

@@ -5,8 +5,8 @@ thunk of ``gym.vector.SyncVectorEnv`` (rpo_agent.py:35-39,123-126): FlattenObser
 observations are already flat, in gymnasium's key order), RecordEpisodeStatistics (episode records of
 the step kernel), ClipAction (``EnvConfig.clip_action``, fused into the step kernel),
 NormalizeObservation + clip(-1,1), NormalizeReward(gamma) + clip(-100,100) -- one set of running
-statistics per env, updated by a small epilogue kernel (``evac_norm_step``) on the same stream, so
-observations never leave the GPU."""
+statistics per env, updated inside the step kernel itself (``evac_step_normalized``; ``evac_norm_step`` is the same
+chain as a separate launch), so observations never leave the GPU."""
 from __future__ import annotations
 
 import dataclasses
@@ -47,10 +47,14 @@ class NormalizedVectorEnv:
                                             self.epsilon, self.env._stream()), self.env._h)
         return obs, info
 
-    def step(self, actions, noise=None, **out):
-        """Wrapped step.  ``out_obs= / out_reward= / out_terminated= / out_truncated=`` (see
-        ``BatchedEvacuationEnv.step``) make the kernels write -- and normalise in place -- the caller's rollout
-        storage directly."""
+    def step(self, actions, noise=None, *, fused: bool = True, **out):
+        """Wrapped step: ONE kernel launch (``evac_step_normalized``: the step and the normalisation chain fused).
+        ``out_obs= / out_reward= / out_terminated= / out_truncated=`` (see ``BatchedEvacuationEnv.step``) make the
+        kernel write -- normalised -- straight into the caller's rollout storage.  ``fused=False`` runs the step and the
+        chain as two launches (``evac_step`` + ``evac_norm_step``): same results bit for bit, kept as a cross-check."""
+        if fused:
+            return self.env.step(actions, noise=noise, _norm=(self.norm_state, self.gamma, self.obs_clip, self.reward_clip,
+                                                              self.epsilon), **out)
         obs, reward, term, trunc, infos = self.env.step(actions, noise=noise, **out)
         _lib.check(self.lib.evac_norm_step(self.env._h, _ptr(obs), _ptr(infos["final_observation"]), _ptr(reward),
                                            _ptr(term), _ptr(trunc), _ptr(self.norm_state), self.gamma, self.obs_clip,

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="step and normalisation chain as two launches (cross-check)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg = ea.EnvConfig(number_of_pedestrians=60, is_new_exiting_reward=True)
@@ -50,7 +51,7 @@ def main():
                 mean = actor(obs[t])
                 torch.add(mean, torch.randn_like(mean), alpha=0.5, out=actions[t])
                 envs.step(actions[t], out_obs=obs[t + 1], out_reward=rewards[t], out_terminated=terminated[t],
-                          out_truncated=truncated[t])
+                          out_truncated=truncated[t], fused=not args.unfused)
             obs[0].copy_(obs[T])                             # the next rollout continues from here
 
     rollout()

@@ -201,6 +201,13 @@ int64_t evac_algorithmic_bytes_per_env_step(evac_handle_t h);
  * observation, may be NULL) is normalised and counted first, then obs (the reset observation) -- the order in
  * which SyncVectorEnv calls the wrapped step() and reset(). */
 int64_t evac_norm_state_doubles(evac_handle_t h);
+/* evac_step with the chain FUSED into the step kernel (one launch; the form the trainer's loop uses): the outputs come
+ * out normalised and clipped, norm_state is updated, final_obs (terminal observation of finished envs) is counted
+ * before obs.  Same results as evac_step followed by evac_norm_step, bit for bit. */
+int evac_step_normalized(evac_handle_t h, const float* actions, const float* noise_or_null, float* obs_out,
+                         float* reward_out, uint8_t* terminated_out, uint8_t* truncated_out, int32_t autoreset,
+                         float* final_obs_or_null, evac_episode_stats_t* final_stats_or_null, double* norm_state,
+                         float gamma, float obs_clip, float reward_clip, float epsilon, void* stream);
 int evac_norm_init(evac_handle_t h, double* norm_state, void* stream);
 int evac_norm_reset(evac_handle_t h, const uint8_t* mask_or_null, float* obs, double* norm_state, float obs_clip,
                     float epsilon, void* stream);

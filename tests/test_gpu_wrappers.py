@@ -82,3 +82,60 @@ def test_normalized_masked_reset_counts_only_reset_envs():
     c1 = env.norm_state[:, 2 * D]
     assert torch.allclose(c1 - c0, torch.tensor([1.0, 0.0, 0.0, 1.0], dtype=torch.float64, device=c1.device))
     env.close()
+
+
+@pytest.mark.parametrize("n,wrap_kw", [(10, dict(positions="grav", alpha=3)),            # sub-wave family, 6-feature obs
+                                       (60, dict(positions="grav", alpha=3)),            # one wave per env
+                                       (100, dict(positions="grav", alpha=5)),           # two waves per env
+                                       (24, dict(positions="rel", statuses="ohe", type="Box")),     # generic obs, sub-wave
+                                       (60, dict(positions="abs", statuses="ohe", type="Box")),
+                                       (130, dict(positions="rel", statuses="no", type="Box"))])
+def test_fused_normalised_step_equals_step_plus_chain_bit_for_bit(n, wrap_kw):
+    """evac_step_normalized (one launch) against evac_step + evac_norm_step (two launches): identical outputs and
+    identical running statistics, across autoresets (terminal observation counted before the reset observation)."""
+    import torch
+    import evacuation_amd as ea
+    E, T, seed = 9, 45, 77
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=11, is_new_exiting_reward=True)
+    wrap = ea.EnvWrappersConfig(**wrap_kw)
+    a = ea.NormalizedVectorEnv.make(cfg, wrap, num_envs=E, gamma=0.95, seed=seed)
+    b = ea.NormalizedVectorEnv.make(cfg, wrap, num_envs=E, gamma=0.95, seed=seed)
+    oa, _ = a.reset(); ob, _ = b.reset()
+    assert torch.equal(oa, ob)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n_done = 0
+    for t in range(T):
+        act = (torch.rand(E, 2, generator=g) * 3.0 - 1.5).cuda()
+        ra = a.step(act, fused=True)
+        rb = b.step(act, fused=False)
+        for k, (x, y) in enumerate(zip(ra[:4], rb[:4])):
+            assert torch.equal(x, y), f"t={t} output {k}"
+        done = (ra[2] | ra[3]).bool()
+        n_done += int(done.sum())
+        if done.any():
+            assert torch.equal(ra[4]["final_observation"][done], rb[4]["final_observation"][done]), f"t={t} final obs"
+        assert torch.equal(a.norm_state, b.norm_state), f"t={t} statistics"
+    assert n_done >= 2 * E
+    a.close(); b.close()
+
+
+def test_fused_normalised_step_writes_into_caller_storage():
+    import torch
+    import evacuation_amd as ea
+    E, n = 5, 60
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=7)
+    wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
+    a = ea.NormalizedVectorEnv.make(cfg, wrap, num_envs=E, seed=3)
+    b = ea.NormalizedVectorEnv.make(cfg, wrap, num_envs=E, seed=3)
+    a.reset(); b.reset()
+    T = 12
+    obs = torch.zeros(T, E, a.env.obs_dim, device="cuda"); rew = torch.zeros(T, E, device="cuda")
+    te = torch.zeros(T, E, dtype=torch.uint8, device="cuda"); tr = torch.zeros(T, E, dtype=torch.uint8, device="cuda")
+    for t in range(T):
+        act = torch.full((E, 2), 0.3, device="cuda")
+        a.step(act, out_obs=obs[t], out_reward=rew[t], out_terminated=te[t], out_truncated=tr[t])
+        o, r, x, y, _ = b.step(act, fused=False)
+        assert torch.equal(obs[t], o) and torch.equal(rew[t], r) and torch.equal(te[t], x.view(torch.uint8)) \
+            and torch.equal(tr[t], y.view(torch.uint8))
+    assert int(tr.sum()) >= E
+    a.close(); b.close()
