@@ -15,7 +15,7 @@ POS = {"abs": 0, "rel": 1, "grav": 2}
 STAT = {"no": 0, "ohe": 1, "cat": 2}
 TYPE = {"Dict": 0, "Box": 1}
 MAX_PEDESTRIANS = 1024
-VERSION = 110
+VERSION = 120
 EPISODE_STATS_WORDS = 10       # evac_episode_stats_t: 8 floats + 2 int32
 
 
@@ -52,6 +52,7 @@ SIGNATURES = {
     "evac_num_envs": (C.c_int32, [_P]),
     "evac_kernel_variant": (C.c_char_p, [_P, C.c_int32]),
     "evac_bind_state": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "evac_bind_schedule": (C.c_int, [_P, _P]),
     "evac_reset": (C.c_int, [_P, _P, _P, _P, _P]),
     "evac_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     "evac_rollout": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),

@@ -63,6 +63,9 @@ struct evac_handle {
     bool bound;
     int sub_lanes;      // 0: one wave (or more) per env; 16 / 32: sub-wave kernels (evac_subwave.h)
     bool cells;         // workgroup-per-env kernels with the cell list (N > 64) instead of all pairs
+    bool cu_wide;       // rollouts of one-wave envs in CU-wide workgroups (the batch fills every CU with 16 envs)
+    int32_t* sched;     // caller-owned scratch of evac_bind_schedule: moving[E] | perm[E], or NULL
+    int sched_age;      // env steps rolled out since the schedule was last rebuilt (< 0: never built)
     std::string err;
     std::string variant[2];
 };
@@ -232,6 +235,15 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         const int64_t cap = (int64_t)0x7fffffff / cfg->number_of_pedestrians - 16;
         p.head_scale = (float)(cap < 0x7ffff0 ? cap : (int64_t)0x7ffff0);     // exact in f32 (< 2^24)
     }
+    {   // CU-wide rollout workgroups pay off once every CU gets its 16 one-wave envs (EVAC_CU_WIDE=1 / 0 forces, for tests)
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+        const char* cw = std::getenv("EVAC_CU_WIDE");
+        const bool one_wave = h->sub_lanes == 0 && cfg->number_of_pedestrians <= evac::kWave;
+        h->cu_wide = one_wave && (cw && cw[0] == '1' ? true : (cw && cw[0] == '0' ? false : num_envs >= 16 * cus));
+        h->sched = nullptr;
+        h->sched_age = -1;
+    }
     p.seed_lo = (uint32_t)(seed & 0xffffffffull);
     p.seed_hi = (uint32_t)(seed >> 32);
     p.env_id_offset = (uint32_t)env_id_offset;
@@ -243,6 +255,7 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
                           h->cells ? (wpe == 2 ? evac::Cells<2>::kName : wpe == 4 ? evac::Cells<4>::kName : wpe == 8 ? evac::Cells<8>::kName : evac::Cells<16>::kName)
                                    : (wpe == 2 ? evac::Wave<2>::kName : wpe == 4 ? evac::Wave<4>::kName : wpe == 8 ? evac::Wave<8>::kName : evac::Wave<16>::kName);
         h->variant[0] = "k_step<" + fam + (grav ? ", grav obs>" : ", generic obs>");
+        if (h->cu_wide) fam = evac::Wave<1, 1024>::kName;
         h->variant[1] = "k_rollout<" + fam + (grav ? ", grav obs>" : ", generic obs>");
     }
     *out = h;
@@ -277,6 +290,14 @@ int evac_bind_state(evac_handle_t h, float* ped, uint8_t* status, float* agent, 
     h->p.clock = (int4*)clock;
     h->p.acc = (float4*)acc;
     h->bound = true;
+    return EVAC_OK;
+}
+
+int evac_bind_schedule(evac_handle_t h, int32_t* scratch) {
+    if (!h) return EVAC_ERR_INVALID_ARGUMENT;
+    if (scratch && ((uintptr_t)scratch & 3u)) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_bind_schedule: scratch must be 4-byte aligned");
+    h->sched = scratch;
+    h->sched_age = -1;
     return EVAC_OK;
 }
 
@@ -338,8 +359,30 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
     if (capture || actions_out || noise)
         EVAC_DISPATCH(h, k_rollout_diag, stream, h->p, (int)n_steps, (const float2*)actions, (float2*)actions_out, slab_out,
                       final_stats, (int)capture_envs, capture, noise);
-    else
-        EVAC_DISPATCH(h, k_rollout, stream, h->p, (int)n_steps, (const float2*)actions, slab_out, final_stats);
+    else if (h->cu_wide) {
+        // one-wave envs, batch >= 16 envs per CU: CU-wide workgroups, envs dealt to the SIMDs by load when a schedule scratch
+        // is bound (rebuilt every kScheduleEvery env steps: the loads drift slowly)
+        constexpr int kScheduleEvery = 50;
+        using FW = evac::Wave<1, 1024>;
+        hipStream_t s_ = (hipStream_t)stream;
+        const int E = h->p.n_envs;
+        int32_t* moving = h->sched;
+        const int32_t* perm = h->sched ? h->sched + E : nullptr;
+        if (h->sched && (h->sched_age < 0 || h->sched_age >= kScheduleEvery)) {
+            hipLaunchKernelGGL(evac::k_schedule, dim3(1), dim3(1024), 0, s_, E, (const int*)moving, h->sched + E);
+            h->sched_age = 0;
+        }
+        if (h->sched) h->sched_age += n_steps;
+        const dim3 grid((unsigned)((E + FW::kEnvsPerBlock - 1) / FW::kEnvsPerBlock));
+        if (h->p.obs_pos == EVAC_POS_GRAV)
+            hipLaunchKernelGGL((evac::k_rollout<FW, true>), grid, dim3(FW::kBlock), 0, s_, h->p, (int)n_steps, (const float2*)actions,
+                               slab_out, final_stats, (const int*)perm, (int*)moving);
+        else
+            hipLaunchKernelGGL((evac::k_rollout<FW, false>), grid, dim3(FW::kBlock), 0, s_, h->p, (int)n_steps, (const float2*)actions,
+                               slab_out, final_stats, (const int*)perm, (int*)moving);
+    } else
+        EVAC_DISPATCH(h, k_rollout, stream, h->p, (int)n_steps, (const float2*)actions, slab_out, final_stats, (const int*)nullptr,
+                      (int*)nullptr);
     return check_launch(h, "evac_rollout");
 }
 

@@ -7,6 +7,8 @@
 // No MFMA: there is no dense contraction here (output width 2).
 #pragma once
 
+#include <type_traits>
+
 #include "evac_common.h"
 #include "evac_families.h"
 
@@ -357,6 +359,33 @@ EVAC_STEP_KERNEL(k_step_raw, false)
 EVAC_STEP_KERNEL(k_step_norm, true)
 #undef EVAC_STEP_KERNEL
 
+// ------------------------------------------------------------------------------------------------
+// Even progress of the waves that share a SIMD.  With equal priorities the SIMD's issue arbiter serves its OLDEST wave
+// first: of the four one-wave envs of a SIMD the first runs at the speed of a lone wave and leaves early, the last ends
+// the launch alone on a mostly idle SIMD (wave lifetimes of one launch spread 1 : 4).  s_setprio outranks age, so:
+//   * kernels whose SIMD-mates sit in other workgroups rotate the priorities by the step counter, offset by the wave's
+//     slot in its SIMD (HW_ID): over four steps every wave has held every priority once (C2: 3.02 -> 2.74 us per step);
+//   * the CU-wide workgroup (Wave<1, 1024>) knows its SIMD-mates (waves w, w+4, w+8, w+12): every wave publishes its step
+//     counter in LDS and takes as priority the number of mates that are ahead of it.
+// A hint only: results do not depend on it.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void set_wave_priority(int k) {   // k in 0..3, wave-uniform
+    switch (k & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+__device__ __forceinline__ int simd_wave_slot() {   // slot of this wave among the waves of its SIMD (HW_ID bits 3:0)
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    return (int)(hw & 3u);
+}
+#ifndef EVAC_PRIO
+#define EVAC_PRIO 1     // 0: leave the arbitration to wave age (A/B builds)
+#endif
+
 // T steps per launch, state in registers (rpo_agent.py:180-203 rollout loop, RandomAgent or given actions).
 // Output: ONE packed f32 slab [T][E][D+3] = [obs(D) | reward | terminated | truncated] -- a single message
 // for the all-gather and a single coalesced store stream for the kernel.  GRAV kernels stage the 9 words
@@ -368,9 +397,12 @@ template <class F, bool GRAV, bool DIAG>
 __device__ __forceinline__ void rollout_body(
     typename F::Smem& sm, const Params& p, int n_steps, const float2* __restrict__ actions, float2* __restrict__ actions_out,
     float* __restrict__ slab_out, evac_episode_stats_t* __restrict__ final_stats, int capture_envs,
-    float* __restrict__ capture, const float* __restrict__ noise_in) {
+    float* __restrict__ capture, const float* __restrict__ noise_in, const int* __restrict__ perm = nullptr,
+    int* __restrict__ moving_out = nullptr) {
     typename F::Ctx w(sm);
     if (w.env >= p.n_envs) return;
+    // the schedule of the CU-wide workgroups (k_schedule): which env this wave carries; any permutation gives the same results
+    if (perm) w.env = __builtin_amdgcn_readfirstlane(perm[w.env]);
     F::init(w);
     const bool active = w.i < p.n_ped;
     Ped q;
@@ -390,10 +422,27 @@ __device__ __forceinline__ void rollout_body(
     // Retire the state loads HERE, or their first use inside the loop puts `s_waitcnt vmcnt(0)` -- which
     // also waits for the previous step's stores -- into every iteration.
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
+    constexpr bool kRotate = EVAC_PRIO && !F::kPace && std::is_same<F, Wave<F::WPE>>::value && F::WPE < 16;
+    int prio_slot = 0;
+    if constexpr (kRotate) prio_slot = simd_wave_slot();
+    if constexpr (EVAC_PRIO && F::kPace) {
+        if (w.lane == 0) sm.progress[(w.slot & 3) * 4 + (w.slot >> 2)] = 0;
+    }
 #ifdef EVAC_STAMP
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w.stamp.last)::"memory");
+    unsigned long long rt0_;   // constant 100 MHz counter next to the shader-clock one: their ratio is the clock the kernel ran at
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0_)::"memory");
+    const unsigned long long ck0_ = w.stamp.last;
 #endif
     for (int t = 0; t < n_steps; ++t) {
+        if constexpr (kRotate) set_wave_priority(t + prio_slot);
+        if constexpr (EVAC_PRIO && F::kPace) {
+            int* mine = &sm.progress[(w.slot & 3) * 4];
+            if (w.lane == 0) mine[w.slot >> 2] = t;
+            const i4 pr = *(const i4*)mine;     // the mates' counters may be a step old: good enough
+            const int ahead = (pr.x > t ? 1 : 0) + (pr.y > t ? 1 : 0) + (pr.z > t ? 1 : 0) + (pr.w > t ? 1 : 0);
+            set_wave_priority(__builtin_amdgcn_readfirstlane(ahead));
+        }
         const int slot64 = t & 63;
         if (slot64 == 0) {
             if (actions) {
@@ -484,18 +533,65 @@ __device__ __forceinline__ void rollout_body(
         EVAC_T(w, 7);   // autoreset check, observation epilogue, output stores
     }
 #ifdef EVAC_STAMP
-    if (w.lane == 0)
+    unsigned long long rt1_;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1_)::"memory");
+    if (w.lane == 0) {
         for (int k = 0; k < 8; ++k) atomicAdd(&g_stamps[k], w.stamp.acc[k]);
+        atomicAdd(&g_stamps[8], w.stamp.last - ck0_);
+        atomicAdd(&g_stamps[9], rt1_ - rt0_);
+        atomicMax(&g_stamps[10], rt1_ - rt0_);                      // slowest / fastest wave of the launch
+        atomicMax(&g_stamps[11], ~0ull - (rt1_ - rt0_));
+    }
 #endif
+    if constexpr (F::kThreadsPerEnv == kWave) {   // what k_schedule sorts the envs of the next launches by
+        if (moving_out) {
+            const int nm = wave_count((unsigned)(q.st - kViscek) < 3u);
+            if (w.owner) moving_out[w.env] = nm;
+        }
+    }
     store_env(p, w.env, w.i, active, w.owner, q, e);
 }
 
 template <class F, bool GRAV>
 __global__ __launch_bounds__(F::kBlock, 4) void k_rollout(
     Params p, int n_steps, const float2* __restrict__ actions, float* __restrict__ slab_out,
-    evac_episode_stats_t* __restrict__ final_stats) {
+    evac_episode_stats_t* __restrict__ final_stats, const int* __restrict__ perm, int* __restrict__ moving_out) {
     __shared__ typename F::Smem sm;
-    rollout_body<F, GRAV, false>(sm, p, n_steps, actions, nullptr, slab_out, final_stats, 0, nullptr, nullptr);
+    rollout_body<F, GRAV, false>(sm, p, n_steps, actions, nullptr, slab_out, final_stats, 0, nullptr, nullptr, perm, moving_out);
+}
+
+// The schedule of the CU-wide rollout workgroups: envs sorted by the pedestrians still moving (the length of their pair
+// loop, as the previous launch left it in `moving`) and dealt to the SIMDs in snake order, so that the four envs of every
+// SIMD -- and the sixteen of every CU -- carry about the same load.  A launch lasts as long as its slowest SIMD; with
+// random placement that is 1.25-1.35x the mean load for most of an episode (tools/moving_distribution.py).
+// One workgroup; perm[slot] = env, slot = workgroup * 16 + wave.  Ties are placed in arrival order (LDS atomics): the
+// permutation may differ from run to run, the results cannot.
+__global__ __launch_bounds__(1024) void k_schedule(int n_envs, const int* __restrict__ moving, int* __restrict__ perm) {
+    __shared__ int hist[kWave + 2];
+    const int tid = threadIdx.x;
+    if (tid < kWave + 2) hist[tid] = 0;
+    __syncthreads();
+    for (int e = tid; e < n_envs; e += 1024) atomicAdd(&hist[min(max(moving[e], 0), kWave)], 1);
+    __syncthreads();
+    if (tid < kWave) {                       // exclusive prefix over the 65 bins (bin 64 = everything at or above 64)
+        const int v = hist[tid];
+        const int incl = wave_inclusive_scan(v);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        hist[tid] = incl - v;
+        if (tid == kWave - 1) hist[kWave] = incl;
+    }
+    __syncthreads();
+    const int e16 = n_envs & ~15, G = e16 >> 2;      // groups of four (one SIMD each) among the full workgroups
+    for (int e = tid; e < n_envs; e += 1024) {
+        const int r = atomicAdd(&hist[min(max(moving[e], 0), kWave)], 1);   // rank by load, ascending
+        int slot = r;
+        if (r < e16) {
+            const int k = r / G, j = r - k * G;
+            const int g = (k & 1) ? G - 1 - j : j;   // snake: quarters 0 and 2 ascending, 1 and 3 descending
+            slot = (g >> 2) * 16 + k * 4 + (g & 3);  // workgroup g / 4, SIMD g % 4, the SIMD's k-th wave
+        }
+        perm[slot] = e;
+    }
 }
 template <class F, bool GRAV>
 __global__ __launch_bounds__(F::kBlock, 4) void k_rollout_diag(

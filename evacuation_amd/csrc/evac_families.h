@@ -28,16 +28,21 @@ namespace evac {
 #define EVAC_BLOCK1 256
 #endif
 
-template <int WPE_>
+// BLOCK1 (WPE == 1 only): threads per workgroup.  256 = four one-wave envs per workgroup (the default); 1024 = the
+// CU-WIDE workgroup of the rollout kernel for batches that fill the chip (16 envs, one workgroup per CU, four waves per
+// SIMD): the waves that share a SIMD are then known (wave w runs on SIMD w % 4), so the host can deal the envs to SIMDs by
+// load (k_schedule) and the waves of a SIMD can keep pace with each other through LDS (rollout_body, kPace).
+template <int WPE_, int BLOCK1_ = EVAC_BLOCK1>
 struct Wave {
     static constexpr int WPE = WPE_;
     static constexpr bool kEnvUniform = true;
     static constexpr int kThreadsPerEnv = WPE * kWave;
     // WPE == 1: several one-wave envs share a workgroup (no workgroup barrier is ever used there);
     // WPE >= 2: exactly one env per workgroup, so that __syncthreads() is a per-env barrier
-    static constexpr int kBlock = WPE == 1 ? EVAC_BLOCK1 : kThreadsPerEnv;
+    static constexpr int kBlock = WPE == 1 ? BLOCK1_ : kThreadsPerEnv;
     static constexpr int kEnvsPerBlock = kBlock / kThreadsPerEnv;
-    static constexpr const char* kName = WPE == 1 ? "1 wave/env, all pairs" : (WPE == 2 ? "2 waves/env, all pairs" : (WPE == 4 ? "4 waves/env, all pairs" : (WPE == 8 ? "8 waves/env, all pairs" : "16 waves/env, all pairs")));
+    static constexpr bool kPace = WPE == 1 && kBlock == 1024;
+    static constexpr const char* kName = WPE == 1 ? (kPace ? "1 wave/env, all pairs, CU-wide workgroups" : "1 wave/env, all pairs") : (WPE == 2 ? "2 waves/env, all pairs" : (WPE == 4 ? "4 waves/env, all pairs" : (WPE == 8 ? "8 waves/env, all pairs" : "16 waves/env, all pairs")));
 
     // WPE > 1: two tiles used alternately, so that writing step t+1's tile needs no barrier against the waves still
     // reading step t's (the two barriers of step t+1 lie between a tile's last read and its next write)
@@ -59,10 +64,11 @@ struct Wave {
         float exitg[kEnvsPerBlock][2];            // gravity exit term from the lane that computed it (WPE > 1)
         // rollout outputs of up to kStageSteps steps, flushed with ONE 64-lane store (GRAV kernels)
         alignas(16) float stage[kEnvsPerBlock][kStageSteps][12];   // rows written as two 16-byte vectors + 1 word
+        alignas(16) int progress[kPace ? 16 : 4];                  // kPace: step counter of every wave, [SIMD][wave of the SIMD]
     };
 
     struct Ctx {
-        using Family = Wave<WPE_>;
+        using Family = Wave<WPE_, BLOCK1_>;
         Smem& sm;
         int env, slot, wave_in_env, lane, i;
         bool owner;
@@ -137,7 +143,7 @@ struct Wave {
             s.f0 = readlane_f(rf.x, WPE - 1);
             s.f1 = readlane_f(rf.y, WPE - 1);
             s.f2 = readlane_f(rf.z, WPE - 1);
-            if constexpr (!GUARD && std::is_same<typename C::Family, Wave<WPE>>::value) {
+            if constexpr (!GUARD && std::is_same<typename C::Family, Wave>::value) {
                 // the step's own reduction: count 3 is "moves at the next step"; after the DPP steps lane w holds the sum
                 // over waves 0..w, i.e. the tile offsets of the next step's compaction -- no exchange, no barrier then
                 const int before = c.wave_in_env == 0 ? 0 : __builtin_amdgcn_readlane(ri.y, c.wave_in_env - 1);
@@ -338,6 +344,7 @@ struct Cells {
     static constexpr int kThreadsPerEnv = WPE * kWave;
     static constexpr int kBlock = kThreadsPerEnv;
     static constexpr int kEnvsPerBlock = 1;
+    static constexpr bool kPace = false;
     static constexpr int kPad = 8;   // +inf entries behind the last moving pedestrian (>= entries per batch)
 #ifndef EVAC_ROW_BATCH
 #define EVAC_ROW_BATCH 8

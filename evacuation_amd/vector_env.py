@@ -12,6 +12,7 @@ HIP stream; all compute is in libevac.so (csrc/), reached through ctypes (includ
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict as TDict, Optional
 
 import numpy as np
@@ -159,6 +160,12 @@ class BatchedEvacuationEnv:
         self.acc = torch.zeros((E, 4), dtype=torch.float32, device=dev)
         _lib.check(self.lib.evac_bind_state(self._h, _ptr(self.ped), _ptr(self.status), _ptr(self.agent),
                                             _ptr(self.clock), _ptr(self.acc)), self._h)
+        # scheduling scratch of evac_rollout (moving[E] | perm[E]): lets large batches of one-wave envs be dealt to the
+        # SIMDs by load; a performance hint, results do not depend on it (EVAC_SCHEDULE=0 leaves it unbound, for A/B runs)
+        self.schedule = None
+        if os.environ.get("EVAC_SCHEDULE", "1") != "0":
+            self.schedule = torch.zeros((2, E), dtype=torch.int32, device=dev)
+            _lib.check(self.lib.evac_bind_schedule(self._h, _ptr(self.schedule)), self._h)
         # step outputs (reused every step; callers that keep them must clone, like the reference's
         # live-reference observations, env.py:98-104)
         self.obs = torch.zeros((E, self.obs_dim), dtype=torch.float32, device=dev)

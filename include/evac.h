@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define EVAC_VERSION 110          /* 0.1.1 */
+#define EVAC_VERSION 120          /* 0.1.2 */
 #define EVAC_MAX_PEDESTRIANS 1024 /* one workgroup (<=16 waves) per env */
 
 typedef enum evac_status {
@@ -174,6 +174,14 @@ int evac_step(evac_handle_t h, const float* actions, const float* noise_or_null,
 int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions_or_null, float* actions_out_or_null,
                  float* slab_out, evac_episode_stats_t* final_stats_or_null, int32_t capture_envs,
                  float* capture_or_null, const float* noise_or_null, void* stream);
+
+/* Optional scheduling scratch of evac_rollout (no reference analogue: the reference steps its envs one after another,
+ * rpo_agent.py:123-126).  scratch: int32 [2][E] on the device, zero-initialised by the caller = moving[E] | perm[E].
+ * When bound and the batch is large enough for CU-wide workgroups (one-wave envs, >= 16 envs per CU), every rollout
+ * launch leaves the pedestrians still moving of each env in moving[] and, every 50 env steps, the envs are re-dealt to
+ * the SIMDs by that load (perm[]).  A performance hint only: results are bit-identical with and without it.
+ * NULL unbinds.  The scratch must stay alive, and be used on one stream at a time, like the state buffers. */
+int evac_bind_schedule(evac_handle_t h, int32_t* scratch_or_null);
 
 /* State exchange in the reference's own shapes (needed for parity tests, checkpoints):
  * pos/dir float [E][N][2], status uint8 [E][N], agent_pos/agent_dir float [E][2], now int32 [E]. */

@@ -1,0 +1,104 @@
+"""The CU-wide rollout workgroups and their load schedule (evac_bind_schedule, k_schedule) are performance devices:
+which wave carries which env, and with which issue priority, must not change a single bit of the results."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ea():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import evacuation_amd
+    return evacuation_amd
+
+
+def _make(ea, cfg, wrap, E, seed, cu_wide, schedule):
+    old = {k: os.environ.get(k) for k in ("EVAC_CU_WIDE", "EVAC_SCHEDULE")}
+    try:
+        os.environ["EVAC_CU_WIDE"] = "1" if cu_wide else "0"
+        os.environ["EVAC_SCHEDULE"] = "1" if schedule else "0"
+        return ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("n,E,wrap_kw", [
+    (60, 1000, dict(positions="grav", alpha=3)),                          # E not a multiple of 16: identity tail of the schedule
+    (60, 512, dict(positions="rel", statuses="ohe", type="Box")),
+    (33, 77, dict(positions="grav", alpha=2)),
+    (64, 160, dict(positions="abs", statuses="cat", type="Dict")),        # the env fills its wave
+])
+def test_cu_wide_scheduled_rollout_is_bit_identical(ea, n, E, wrap_kw):
+    import torch
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=70, is_new_exiting_reward=True, intrinsic_reward_coef=0.5)
+    wrap = ea.EnvWrappersConfig(**wrap_kw)
+    ref = _make(ea, cfg, wrap, E, 7, cu_wide=False, schedule=False)       # four envs per 256-thread workgroup
+    wide = _make(ea, cfg, wrap, E, 7, cu_wide=True, schedule=False)       # sixteen per CU-wide workgroup, identity order
+    sched = _make(ea, cfg, wrap, E, 7, cu_wide=True, schedule=True)       # + envs dealt to SIMDs by load
+    assert "CU-wide" in wide.kernel_variant("rollout") and "CU-wide" not in ref.kernel_variant("rollout")
+    for env in (ref, wide, sched):
+        env.reset()
+    outs = [[], [], []]
+    for chunk in (30, 60, 25, 60):                                        # the schedule is rebuilt every 50 env steps; episodes end inside
+        for k, env in enumerate((ref, wide, sched)):
+            r = env.rollout(chunk)
+            outs[k].append({key: r[key].clone() for key in ("obs", "reward", "terminated", "truncated", "episode_stats")})
+    torch.cuda.synchronize()
+    for c in range(len(outs[0])):
+        for key in outs[0][c]:
+            a = outs[0][c][key]
+            for k in (1, 2):
+                b = outs[k][c][key]
+                assert torch.equal(a.view(torch.uint8) if a.dtype != torch.uint8 else a,
+                                   b.view(torch.uint8) if b.dtype != torch.uint8 else b), (c, key, k)
+    sa = ref.get_state()
+    for env in (wide, sched):
+        sb = env.get_state()
+        for key in sa:
+            assert torch.equal(sa[key], sb[key]), key
+    # the schedule is a permutation of the envs, heaviest and lightest envs sharing SIMDs
+    perm = sched.schedule[1].cpu().numpy()
+    assert sorted(perm.tolist()) == list(range(E))
+    moving = sched.schedule[0].cpu().numpy()
+    st = sa["status"].cpu().numpy()
+    assert (moving == ((st >= 1) & (st <= 3)).sum(1)).all()               # what the last launch left behind
+    for env in (ref, wide, sched):
+        env.close()
+
+
+def test_schedule_balances_simd_groups(ea):
+    """k_schedule on the loads a real episode produces: every group of four SIMD-mates (waves w, w+4, w+8, w+12 of a
+    workgroup) gets one env of each load quartile, and the heaviest SIMD is lighter than with random placement."""
+    import torch
+    E = 4096
+    cfg = ea.EnvConfig(number_of_pedestrians=60)
+    env = _make(ea, cfg, ea.EnvWrappersConfig(positions="grav"), E, 1, cu_wide=True, schedule=True)
+    env.reset()
+    for _ in range(6):
+        env.rollout(100)
+    torch.cuda.synchronize()
+    load = env.schedule[0].cpu().numpy().copy()                            # pedestrians still moving, per env, at t = 600
+    assert load.min() >= 0 and load.max() <= 60 and load.std() > 3
+    env.rollout(1)                                                         # >= 50 steps since the last schedule: re-sorted by `load`
+    torch.cuda.synchronize()
+    perm = env.schedule[1].cpu().numpy()
+    assert sorted(perm.tolist()) == list(range(E))
+    slot_load = load[perm].reshape(E // 16, 4, 4)                          # [workgroup][k-th wave of the SIMD][SIMD]
+    sums = slot_load.sum(1)                                                # per SIMD
+    rng = np.random.default_rng(0)
+    rand = load[rng.permutation(E)].reshape(-1, 4).sum(1)
+    assert sums.max() < rand.max() and sums.max() - sums.min() < 0.5 * (rand.max() - rand.min())
+    q = np.sort(load)
+    for k in range(4):                                                     # one env per quartile in every SIMD
+        lo, hi = q[k * E // 4], q[(k + 1) * E // 4 - 1]
+        assert ((slot_load[:, k, :] >= lo) & (slot_load[:, k, :] <= hi)).all()
+    env.close()

@@ -27,7 +27,8 @@ for phase in range(4):
     lib.evac_debug_stamps(buf)
     waves = E * (1 if n <= 64 else 2 if n <= 128 else 4 if n <= 256 else 8 if n <= 512 else 16)
     tot = sum(buf[:8])
-    print(f"-- steps {phase*600+500}..{phase*600+600}: {tot / waves / T:.0f} cycles per wave-step")
+    print(f"-- steps {phase*600+500}..{phase*600+600}: {tot / waves / T:.0f} cycles per wave-step; shader clock {buf[8] / max(1, buf[9]) * 100:.0f} MHz, "
+          f"{buf[9] / waves / T * 10:.0f} ns per wave-step (s_memrealtime); wave lifetime per step: fastest {((1 << 64) - 1 - buf[11]) / T * 10:.0f} ns, slowest {buf[10] / T * 10:.0f} ns")
     for k in range(8):
         print(f"   {names[k]:34s} {buf[k] / waves / T:8.1f} cycles/wave-step  {100.0 * buf[k] / tot:5.1f} %")
 PY
