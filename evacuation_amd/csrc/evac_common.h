@@ -325,6 +325,12 @@ __device__ __forceinline__ int classify(const Params& p, float x, float y, float
     return st;
 }
 
+// Does this pedestrian's row of the neighbour sum have to be evaluated (see step_env)?  VISCEK always; FOLLOWER unless the
+// enslaving blend multiplies its Vicsek heading by exactly 0 (area.py:139-142 with enslaving_degree = 1).
+__device__ __forceinline__ bool needs_row(const Params& p, int st) {
+    return st == kViscek || (st == kFollower && p.one_minus_ens != 0.0f);
+}
+
 // gravity_encoding.py:15-16,35-37:  -alpha / (|R| + eps)^(alpha+2) * R, with |R|^2 given
 __device__ __forceinline__ void grav_term2(const Params& p, float rx, float ry, float r2, float& gx, float& gy) {
     const float nrm = fsqrt(r2) + p.eps;

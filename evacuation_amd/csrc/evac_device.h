@@ -112,6 +112,14 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     const bool efv = (unsigned)(q.st - kViscek) < 3u;                       // area.py:99  (V | F | E) = codes 1..3
     const bool fv = (unsigned)(q.st - kViscek) < 2u;                        // area.py:104 (V | F) = codes 1..2
     const bool fol = q.st == kFollower;
+    // Which pedestrians need their row of the distance matrix evaluated.  The reference evaluates FOLLOWER and VISCEK rows
+    // (area.py:104) and then blends a follower's new heading as e * leader + (1 - e) * heading (area.py:139-142): with
+    // enslaving_degree = 1 -- the reference's default (config.py:32) -- the follower's own Vicsek mean is multiplied by
+    // exactly 0, so only the VISCEK rows are evaluated (late in an episode most moving pedestrians are followers:
+    // tools/moving_distribution.py).  A follower lane then sees a zero sum -> a finite heading -> times 0; the one way the
+    // product is not 0, the reference's NaN poisoning (any NaN heading makes every row NaN, area.py:118-119), is kept
+    // by the families (a flag wherever rows are skipped).
+    const bool row = needs_row(p, q.st);
 
     // unit headings of the moving pedestrians: area.py:100-101.  0 * rsq(0) = 0 * inf = NaN, as 0/0.
     // A NaN heading reaches every FOLLOWER/VISCEK pedestrian's sum (w * NaN = NaN even for w = 0 in the all-pairs
@@ -127,7 +135,7 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
 
     // ---- neighbour sum: area.py:104-119 ----
     float sx, sy;
-    F::neighbour_sum(p, c, q, efv, fv, ux, uy, sx, sy);
+    F::neighbour_sum(p, c, q, efv, row, ux, uy, sx, sy);
     EVAC_T(c, 3);   // neighbour sum
 
     // ---- new heading = mean heading rotated by the noise: area.py:120-136.
@@ -544,8 +552,8 @@ __device__ __forceinline__ void rollout_body(
     }
 #endif
     if constexpr (F::kThreadsPerEnv == kWave) {   // what k_schedule sorts the envs of the next launches by
-        if (moving_out) {
-            const int nm = wave_count((unsigned)(q.st - kViscek) < 3u);
+        if (moving_out) {   // the length of the env's pair loop: its moving pedestrians, or 0 if no row needs evaluating
+            const int nm = ballot(needs_row(p, q.st)) != 0ull ? wave_count((unsigned)(q.st - kViscek) < 3u) : 0;
             if (w.owner) moving_out[w.env] = nm;
         }
     }

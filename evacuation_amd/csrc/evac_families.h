@@ -234,8 +234,11 @@ struct Wave {
         const f4* __restrict__ tile = sm.tile[par][c.slot];
         const float r2b = kRPed2Big;
         if constexpr (WPE == 1) {
-            // rows of the distance matrix exist only for FOLLOWER/VISCEK pedestrians (area.py:104)
+            // rows of the distance matrix exist only for FOLLOWER/VISCEK pedestrians (area.py:104); `fv` = this lane's row is
+            // needed (step_env: needs_row).  No row at all -> no loop; then the reference's NaN poisoning, which the loop's
+            // w * NaN carries otherwise, is applied by hand (it reaches the followers whose rows are not evaluated).
             const bool any_fv = ballot(fv) != 0ull;
+            if (!any_fv && ballot(efv && (ux != ux || uy != uy)) != 0ull) sx = sy = __builtin_nanf("");
             // Branch-free batches: the B wave-uniform ds_read_b128 broadcasts are issued back to
             // back (LDS latency paid once per batch, no VALU slot), then 6 full-rate VALU ops per pair.
             const int n8 = __builtin_amdgcn_readfirstlane(any_fv ? ((n_cols + 3) & ~3) : 0);   // no rows -> no loop
@@ -451,7 +454,7 @@ struct Cells {
             const float hs = p.head_scale;
             const int hx = (int)__builtin_rintf(ux * hs), hy = (int)__builtin_rintf(uy * hs);
             sm.tile[0][s] = f4{q.x * kTileScale, q.y * kTileScale, __builtin_bit_cast(float, hx), __builtin_bit_cast(float, hy)};
-            sm.who[s] = c.i | (cell << 16);
+            sm.who[s] = c.i | (fv ? 0x8000 : 0) | (cell << 16);   // bit 15: this pedestrian's row is needed
         }
         if (c.i < kPad) sm.tile[0][n_cols + c.i] = f4{__builtin_inff(), 0.0f, 0.0f, 0.0f};
         __syncthreads();
@@ -459,9 +462,9 @@ struct Cells {
         // ---- 4. rows in tile order ----
         if constexpr (!(EVAC_ABLATE & 1)) {
             const int s = c.i;
-            if (s < n_cols) {
+            const int wc = s < n_cols ? sm.who[s] : 0;
+            if (wc & 0x8000) {    // a moving pedestrian whose row is needed (a wave whose slots hold followers only does nothing)
                 const f4 me = sm.tile[0][s];
-                const int wc = sm.who[s];
                 const int rc = wc >> 16;
                 int lo[3], hi[3];
 #pragma unroll
@@ -485,7 +488,7 @@ struct Cells {
                         j += kRowBatch;
                     }
                 }
-                sm.res[wc & 0xffff] = i2{ax, ay};
+                sm.res[wc & 0x7fff] = i2{ax, ay};
             }
         }
         __syncthreads();
@@ -603,7 +606,12 @@ struct Sub {
             const int k = __popcll((m_efv >> (g * G)) & kGroupBits);
             nmax = k > nmax ? k : nmax;
         }
-        const int n4 = (ballot(fv) != 0ull) ? ((nmax + 3) & ~3) : 0;
+        const bool any_row = ballot(fv) != 0ull;
+        const int n4 = any_row ? ((nmax + 3) & ~3) : 0;
+        if (!any_row) {   // no loop: the NaN poisoning it would carry (area.py:118-119), per group
+            const unsigned long long m_nan = ballot(efv && (ux != ux || uy != uy));
+            if ((m_nan & c.gmask) != 0ull) sx = sy = __builtin_nanf("");
+        }
         const f4* __restrict__ tile = sm.tile[c.slot];           // per lane: its group's tile
         const float XI = q.x * kTileScale, YI = q.y * kTileScale;
         int j = 0;

@@ -22,3 +22,16 @@ for phase in range(0, 2000, 100):
           f"balanced max {bal.max() / 4:6.1f} ({bal.max() / 4 / cost.mean():.3f}x)")
     env.rollout(100)
     torch.cuda.synchronize()
+
+# status composition of the moving pedestrians (which rows the neighbour sum really needs: with enslaving_degree = 1 a
+# follower's own Vicsek mean is multiplied by 0, area.py:139-142)
+for n2, E2, wrap in ((60, 4096, dict(positions="grav")), (256, 1024, dict(positions="grav")), (1024, 32, dict(positions="rel", statuses="ohe", type="Box"))):
+    env = ea.BatchedEvacuationEnv(ea.EnvConfig(number_of_pedestrians=n2, is_new_exiting_reward=True), ea.EnvWrappersConfig(**wrap), num_envs=E2, seed=1)
+    env.reset()
+    for phase in range(0, 2000, 200):
+        st = env.get_state()["status"].cpu().numpy()
+        v, f, x = (st == 1).sum(1), (st == 2).sum(1), (st == 3).sum(1)
+        print(f"N={n2} t={phase:5d} viscek mean {v.mean():6.1f} max {v.max():4d} zero in {100.0 * (v == 0).mean():5.1f}% | follower mean {f.mean():6.1f} max {f.max():4d} | exiting mean {x.mean():5.1f}")
+        env.rollout(200)
+        torch.cuda.synchronize()
+    env.close()
