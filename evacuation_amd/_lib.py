@@ -52,7 +52,9 @@ SIGNATURES = {
     "evac_num_envs": (C.c_int32, [_P]),
     "evac_kernel_variant": (C.c_char_p, [_P, C.c_int32]),
     "evac_bind_state": (C.c_int, [_P, _P, _P, _P, _P, _P]),
-    "evac_bind_schedule": (C.c_int, [_P, _P]),
+    "evac_workspace_bytes": (C.c_int64, [_P]),
+    "evac_bind_workspace": (C.c_int, [_P, _P, C.c_int64]),
+    "evac_team_error": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "evac_reset": (C.c_int, [_P, _P, _P, _P, _P]),
     "evac_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     "evac_rollout": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),

@@ -12,6 +12,7 @@
 
 #include "evac_device.h"
 #include "evac_subwave.h"
+#include "evac_team.h"
 
 namespace {
 
@@ -64,8 +65,10 @@ struct evac_handle {
     int sub_lanes;      // 0: one wave (or more) per env; 16 / 32: sub-wave kernels (evac_subwave.h)
     bool cells;         // workgroup-per-env kernels with the cell list (N > 64) instead of all pairs
     bool cu_wide;       // rollouts of one-wave envs in CU-wide workgroups (the batch fills every CU with 16 envs)
-    int32_t* sched;     // caller-owned scratch of evac_bind_schedule: moving[E] | perm[E], or NULL
+    int team_k;         // rollouts of 513..1024-pedestrian envs by teams of 2 / 4 / 8 workgroups per env (0: one workgroup per env)
+    int32_t* sched;     // inside the caller's workspace (evac_bind_workspace): moving[E] | perm[E], or NULL
     int sched_age;      // env steps rolled out since the schedule was last rebuilt (< 0: never built)
+    bool team_bound;    // the workspace holds the teams' exchange areas
     std::string err;
     std::string variant[2];
 };
@@ -243,6 +246,18 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         h->cu_wide = one_wave && (cw && cw[0] == '1' ? true : (cw && cw[0] == '0' ? false : num_envs >= 16 * cus));
         h->sched = nullptr;
         h->sched_age = -1;
+        // teams: as many CUs per env as the batch leaves free -- all members must be resident together (one 1024-thread
+        // workgroup per CU), teams are laid out in rows of 8 (one per XCD).  EVAC_TEAM=0 disables, 2 / 4 / 8 forces a size.
+        h->team_k = 0;
+        h->team_bound = false;
+        if (cfg->number_of_pedestrians > 512) {
+            const char* tm = std::getenv("EVAC_TEAM");
+            const int want = tm ? std::atoi(tm) : -1;
+            const int rows = (num_envs + 7) / 8 * 8;
+            for (int k = 8; k >= 2; k >>= 1)
+                if ((want < 0 || want == k) && rows * k <= cus) { h->team_k = k; break; }
+            if (want == 0) h->team_k = 0;
+        }
     }
     p.seed_lo = (uint32_t)(seed & 0xffffffffull);
     p.seed_hi = (uint32_t)(seed >> 32);
@@ -256,6 +271,7 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
                                    : (wpe == 2 ? evac::Wave<2>::kName : wpe == 4 ? evac::Wave<4>::kName : wpe == 8 ? evac::Wave<8>::kName : evac::Wave<16>::kName);
         h->variant[0] = "k_step<" + fam + (grav ? ", grav obs>" : ", generic obs>");
         if (h->cu_wide) fam = evac::Wave<1, 1024>::kName;
+        if (h->team_k) fam = h->team_k == 8 ? evac::Team<8>::kName : (h->team_k == 4 ? evac::Team<4>::kName : evac::Team<2>::kName);
         h->variant[1] = "k_rollout<" + fam + (grav ? ", grav obs>" : ", generic obs>");
     }
     *out = h;
@@ -293,11 +309,60 @@ int evac_bind_state(evac_handle_t h, float* ped, uint8_t* status, float* agent, 
     return EVAC_OK;
 }
 
-int evac_bind_schedule(evac_handle_t h, int32_t* scratch) {
+namespace {
+struct WorkspaceLayout {
+    size_t sched, team_err, team_ctr, team_cnt, team_rec, team_tile, total;
+};
+WorkspaceLayout workspace_layout(const evac_handle* h) {
+    const size_t E = (size_t)h->p.n_envs;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    WorkspaceLayout w{};
+    size_t o = 0;
+    w.sched = o; o = up(o + 2 * E * sizeof(int32_t));
+    if (h->team_k) {
+        w.team_err = o; o = up(o + 128);
+        w.team_ctr = o; o = up(o + E * 128);
+        w.team_cnt = o; o = up(o + 2 * E * 64);
+        w.team_rec = o; o = up(o + 2 * E * 32 * 16);
+        w.team_tile = o; o = up(o + 2 * E * 1024 * 16);
+    }
+    w.total = o;
+    return w;
+}
+}  // namespace
+
+int64_t evac_workspace_bytes(evac_handle_t h) { return h ? (int64_t)workspace_layout(h).total : -1; }
+
+int evac_bind_workspace(evac_handle_t h, void* workspace, int64_t bytes) {
     if (!h) return EVAC_ERR_INVALID_ARGUMENT;
-    if (scratch && ((uintptr_t)scratch & 3u)) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_bind_schedule: scratch must be 4-byte aligned");
-    h->sched = scratch;
+    h->sched = nullptr;
     h->sched_age = -1;
+    h->team_bound = false;
+    if (!workspace) return EVAC_OK;
+    const WorkspaceLayout w = workspace_layout(h);
+    if (bytes < (int64_t)w.total) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_bind_workspace: workspace smaller than evac_workspace_bytes()");
+    if ((uintptr_t)workspace & 255u) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_bind_workspace: workspace must be 256-byte aligned");
+    char* base = (char*)workspace;
+    h->sched = (int32_t*)(base + w.sched);
+    if (h->team_k) {
+        h->p.team_err = (unsigned*)(base + w.team_err);
+        h->p.team_ctr = (unsigned*)(base + w.team_ctr);
+        h->p.team_cnt = base + w.team_cnt;
+        h->p.team_rec = base + w.team_rec;
+        h->p.team_tile = base + w.team_tile;
+        h->team_bound = true;
+    }
+    return EVAC_OK;
+}
+
+int evac_team_error(evac_handle_t h, int32_t* out) {
+    if (!h || !out) return EVAC_ERR_INVALID_ARGUMENT;
+    *out = 0;
+    if (!h->team_bound) return EVAC_OK;
+    DeviceGuard g(h->device);
+    unsigned v = 0;
+    if (hipMemcpy(&v, h->p.team_err, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return fail(h, EVAC_ERR_HIP, "evac_team_error: hipMemcpy failed");
+    *out = (int32_t)v;
     return EVAC_OK;
 }
 
@@ -359,7 +424,26 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
     if (capture || actions_out || noise)
         EVAC_DISPATCH(h, k_rollout_diag, stream, h->p, (int)n_steps, (const float2*)actions, (float2*)actions_out, slab_out,
                       final_stats, (int)capture_envs, capture, noise);
-    else if (h->cu_wide) {
+    else if (h->team_k && h->team_bound) {
+        // 513..1024 pedestrians, few envs: K workgroups (CUs) per env (evac_team.h).  The teams' barrier counters start
+        // every launch at zero; workgroup b = j * 8 + xcd carries team (j / K) * 8 + xcd.
+        hipStream_t s_ = (hipStream_t)stream;
+        const int E = h->p.n_envs, K = h->team_k;
+        if (hipMemsetAsync(h->p.team_ctr, 0, (size_t)E * 128, s_) != hipSuccess) return fail(h, EVAC_ERR_HIP, "evac_rollout: hipMemsetAsync failed");
+        const dim3 grid((unsigned)((E + 7) / 8 * 8 * K)), block(1024);
+        const bool grav = h->p.obs_pos == EVAC_POS_GRAV;
+#define EVAC_LAUNCH_TEAM(K_)                                                                                              \
+    do {                                                                                                                  \
+        if (grav) hipLaunchKernelGGL((evac::k_rollout<evac::Team<K_>, true>), grid, block, 0, s_, h->p, (int)n_steps,      \
+                                     (const float2*)actions, slab_out, final_stats, (const int*)nullptr, (int*)nullptr);   \
+        else hipLaunchKernelGGL((evac::k_rollout<evac::Team<K_>, false>), grid, block, 0, s_, h->p, (int)n_steps,          \
+                                (const float2*)actions, slab_out, final_stats, (const int*)nullptr, (int*)nullptr);        \
+    } while (0)
+        if (K == 8) EVAC_LAUNCH_TEAM(8);
+        else if (K == 4) EVAC_LAUNCH_TEAM(4);
+        else EVAC_LAUNCH_TEAM(2);
+#undef EVAC_LAUNCH_TEAM
+    } else if (h->cu_wide) {
         // one-wave envs, batch >= 16 envs per CU: CU-wide workgroups, envs dealt to the SIMDs by load when a schedule scratch
         // is bound (rebuilt every kScheduleEvery env steps: the loads drift slowly)
         constexpr int kScheduleEvery = 50;

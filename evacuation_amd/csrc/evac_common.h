@@ -96,6 +96,10 @@ struct Params {
     float4* agent;
     int4* clock;
     float4* acc;
+    // exchange areas of the team kernels (evac_team.h), inside the caller's workspace: tile [2][E][1024] x 16 B,
+    // cnt [2][E][8] x 8 B, rec [2][E][32] x 16 B, ctr [E][32] x 4 B (zeroed by the host before every launch), err [32] x 4 B
+    void *team_tile, *team_cnt, *team_rec;
+    unsigned *team_ctr, *team_err;
 };
 
 // ------------------------------------------------------------------------------------------------

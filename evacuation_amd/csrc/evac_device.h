@@ -31,7 +31,7 @@ __device__ __forceinline__ void grav_observation(const Params& p, typename F::Ct
     s.f1 = visc ? gy : 0.0f;
     s.f2 = 0.0f;
     const unsigned long long pred[8] = {ballot(active && q.st == kFollower), 0, 0, 0, 0, 0, 0, 0};
-    F::template reduce<true>(c, s, pred);
+    F::template reduce<true>(p, c, s, pred);
     float ex, ey;
     grav_term(p, e.ax - kExitX, e.ay - kExitY, ex, ey);              // gravity_encoding.py:28-38
     const float nf = (float)s.i[0];
@@ -56,10 +56,10 @@ __device__ __forceinline__ void write_obs(const Params& p, typename F::Ctx& c, b
 // exiting / viscek counts of the final state for the episode record (env.py:120-123); called by all lanes
 // of the env when an episode ends (rare), so the per-step reduction does not carry them.
 template <class F>
-__device__ __forceinline__ void finish_counts(typename F::Ctx& c, const Ped& q, StepOut& o) {
+__device__ __forceinline__ void finish_counts(const Params& p, typename F::Ctx& c, const Ped& q, StepOut& o) {
     Sums s{};
     const unsigned long long pred[8] = {ballot(q.st == kExiting), ballot(q.st == kViscek), 0, 0, 0, 0, 0, 0};
-    F::template reduce<true>(c, s, pred);
+    F::template reduce<true>(p, c, s, pred);
     o.n_exiting = s.i[0];
     o.n_viscek = s.i[1];
 }
@@ -92,7 +92,14 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     const bool term_agent = hit && (p.flags & kFlagTermOnWall) != 0;
 
     // ---- Area.pedestrians_step: area.py:76-180 ----
+    // (team kernels: a wave without pedestrians -- a "helper" wave -- skips the per-pedestrian arithmetic and only takes part
+    // in the neighbour sum and the reductions; `work` is constant true for every other family)
+    bool work = true;
+    if constexpr (F::kHelpers) work = !c.helper;
     const int old_st = q.st;
+    bool efv = false, fv = false, fol = false, row = false;
+    float ux = 0.0f, uy = 0.0f;
+    if (work) {
     const bool esc = q.st == kEscaped, exi = q.st == kExiting;
     q.x = esc ? kExitX : q.x;                                               // area.py:79-81
     q.y = esc ? kExitY : q.y;
@@ -109,9 +116,9 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
         q.dy = exi ? vy * k : q.dy;
     }
     // lanes beyond n_ped carry status 0, so status tests need no `active &&` (saves mask algebra on the SALU)
-    const bool efv = (unsigned)(q.st - kViscek) < 3u;                       // area.py:99  (V | F | E) = codes 1..3
-    const bool fv = (unsigned)(q.st - kViscek) < 2u;                        // area.py:104 (V | F) = codes 1..2
-    const bool fol = q.st == kFollower;
+    efv = (unsigned)(q.st - kViscek) < 3u;                                  // area.py:99  (V | F | E) = codes 1..3
+    fv = (unsigned)(q.st - kViscek) < 2u;                                   // area.py:104 (V | F) = codes 1..2
+    fol = q.st == kFollower;
     // Which pedestrians need their row of the distance matrix evaluated.  The reference evaluates FOLLOWER and VISCEK rows
     // (area.py:104) and then blends a follower's new heading as e * leader + (1 - e) * heading (area.py:139-142): with
     // enslaving_degree = 1 -- the reference's default (config.py:32) -- the follower's own Vicsek mean is multiplied by
@@ -119,18 +126,20 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     // tools/moving_distribution.py).  A follower lane then sees a zero sum -> a finite heading -> times 0; the one way the
     // product is not 0, the reference's NaN poisoning (any NaN heading makes every row NaN, area.py:118-119), is kept
     // by the families (a flag wherever rows are skipped).
-    const bool row = needs_row(p, q.st);
+    row = needs_row(p, q.st);
 
     // unit headings of the moving pedestrians: area.py:100-101.  0 * rsq(0) = 0 * inf = NaN, as 0/0.
     // A NaN heading reaches every FOLLOWER/VISCEK pedestrian's sum (w * NaN = NaN even for w = 0 in the all-pairs
     // families, a flag in the cell-list family) -- exactly the reference's (intersection * u).sum() with
     // NaN * 0 = NaN (area.py:118-119).  nan_guard (non-reference) zeroes it instead.
     const float inrm = frsq(q.dx * q.dx + q.dy * q.dy);
-    float ux = q.dx * inrm, uy = q.dy * inrm;
+    ux = q.dx * inrm;
+    uy = q.dy * inrm;
     if (p.flags & kFlagNanGuard) {          // uniform
         ux = (ux != ux) ? 0.0f : ux;
         uy = (uy != uy) ? 0.0f : uy;
     }
+    }   // work
     EVAC_T(c, 1);   // leader + per-lane pre-pair work
 
     // ---- neighbour sum: area.py:104-119 ----
@@ -138,6 +147,11 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     F::neighbour_sum(p, c, q, efv, row, ux, uy, sx, sy);
     EVAC_T(c, 3);   // neighbour sum
 
+    Sums s{};
+    unsigned long long pred[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float gx = 0.0f, gy = 0.0f;
+    bool exit_lane = false;
+    if (work) {
     // ---- new heading = mean heading rotated by the noise: area.py:120-136.
     // cos/sin(arctan2(my,mx)+eta) = rotation of (mx,my)/|m| by eta; arctan2(0,0) = 0.
     {
@@ -174,17 +188,15 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     // The first idle lane (i == N, if the env does not fill its lanes) stands on the exit: it evaluates the
     // gravity exit term (gravity_encoding.py:28-38) with the very same instructions as the pedestrians'
     // terms instead of a separate single-lane block.  Its classifier result is discarded (inactive).
-    const bool exit_lane = GRAV && i == p.n_ped;
+    exit_lane = GRAV && F::kExitLane && i == p.n_ped;
     const float px = exit_lane ? kExitX : q.x, py = exit_lane ? kExitY : q.y;
     float de, lx, ly, dl2;
     const int cls = classify(p, px, py, e.ax, e.ay, de, lx, ly, dl2);
     const int new_st = active ? cls : 0;
     q.st = new_st;
-    Sums s{};
     s.f0 = active ? de : 0.0f;
     // gravity observation of the post-step state, fused into the same reduction (gravity_encoding.py:8-25);
     // R = agent - pos = -(pos - agent) reuses the classifier's offset and squared distance.
-    float gx = 0.0f, gy = 0.0f;
     if constexpr (GRAV) {
         grav_term2(p, -lx, -ly, dl2, gx, gy);
         const bool visc = new_st == kViscek;
@@ -193,17 +205,17 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     }
     // per-step counts: the two reward transitions, escaped (termination) and followers (gravity exit term);
     // exiting / viscek counts are only part of the episode record and are taken at episode end.
-    const unsigned long long pred[8] = {
-        ballot((old_st == kViscek || old_st == kFollower) && new_st == kExiting),    // reward.py:35-39
-        ballot(old_st == kViscek && new_st == kFollower),                             // reward.py:43-46
-        ballot(new_st == kEscaped),
-        ballot((unsigned)(new_st - kViscek) < 3u),      // moves at the next step (only the multi-wave all-pairs family uses it)
-        ballot(new_st == kFollower), 0, 0, 0};
+    pred[0] = ballot((old_st == kViscek || old_st == kFollower) && new_st == kExiting);    // reward.py:35-39
+    pred[1] = ballot(old_st == kViscek && new_st == kFollower);                             // reward.py:43-46
+    pred[2] = ballot(new_st == kEscaped);
+    pred[3] = ballot((unsigned)(new_st - kViscek) < 3u);      // moves at the next step (only the multi-wave all-pairs family uses it)
+    pred[4] = ballot(new_st == kFollower);
+    }   // work
     if constexpr (GRAV) F::exit_publish(c, exit_lane, gx, gy);
-    if constexpr (!(EVAC_ABLATE & 8)) F::template reduce<false>(c, s, pred);
+    if constexpr (!(EVAC_ABLATE & 8)) F::template reduce<false>(p, c, s, pred);
     if constexpr (GRAV) {
         float ex = 0.0f, ey = 0.0f;
-        if (p.n_ped < F::kThreadsPerEnv) {    // uniform: the env leaves a lane idle
+        if (F::kExitLane && p.n_ped < F::kThreadsPerEnv) {    // uniform: the env leaves a lane idle
             F::exit_fetch(c, gx, gy, p.n_ped, ex, ey);
         } else {                              // the env fills its lanes
             grav_term(p, e.ax - kExitX, e.ay - kExitY, ex, ey);
@@ -274,7 +286,7 @@ __device__ __forceinline__ void step_outputs(const Params& p, typename F::Ctx& w
             }
         }
         if (final_stats) {
-            finish_counts<F>(w, q, o);
+            finish_counts<F>(p, w, q, o);
             if (w.owner) write_stats(final_stats + w.env, e, o);
         }
         reset_env(p, active, philox_reset_draw(p, gid, w.i, e.n_resets), q, e);
@@ -472,7 +484,9 @@ __device__ __forceinline__ void rollout_body(
         if (DIAG && actions_out && w.owner) actions_out[(size_t)t * E + w.env] = a;   // diagnostic face only
         // one Philox call serves four consecutive steps of this pedestrian
         const uint32_t sel = e.total & 3u;
-        if ((!have || sel == 0u) && !(EVAC_ABLATE & 4)) {
+        bool draws = true;                      // (team kernels: waves without pedestrians draw no noise)
+        if constexpr (F::kHelpers) draws = !w.helper;
+        if (draws && (!have || sel == 0u) && !(EVAC_ABLATE & 4)) {
             nzr = philox4x32_10(make_uint4(gid, (uint32_t)w.i, e.total >> 2, kStreamNoise), p.seed_lo, p.seed_hi);
             have = true;
         }
@@ -502,7 +516,7 @@ __device__ __forceinline__ void rollout_body(
         float o6[6] = {e.ax, e.ay, o.ex, o.ey, o.gx, o.gy};
         if (o.terminated || o.truncated) {   // wave-/workgroup-uniform, rare
             if (final_stats) {
-                finish_counts<F>(w, q, o);
+                finish_counts<F>(p, w, q, o);
                 if (w.owner) write_stats(final_stats + (size_t)t * E + w.env, e, o);
             }
             reset_env(p, active, philox_reset_draw(p, gid, w.i, e.n_resets), q, e);

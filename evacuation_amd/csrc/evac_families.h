@@ -42,6 +42,7 @@ struct Wave {
     static constexpr int kBlock = WPE == 1 ? BLOCK1_ : kThreadsPerEnv;
     static constexpr int kEnvsPerBlock = kBlock / kThreadsPerEnv;
     static constexpr bool kPace = WPE == 1 && kBlock == 1024;
+    static constexpr bool kHelpers = false, kExitLane = true;
     static constexpr const char* kName = WPE == 1 ? (kPace ? "1 wave/env, all pairs, CU-wide workgroups" : "1 wave/env, all pairs") : (WPE == 2 ? "2 waves/env, all pairs" : (WPE == 4 ? "4 waves/env, all pairs" : (WPE == 8 ? "8 waves/env, all pairs" : "16 waves/env, all pairs")));
 
     // WPE > 1: two tiles used alternately, so that writing step t+1's tile needs no barrier against the waves still
@@ -116,7 +117,7 @@ struct Wave {
     // 1024); after the barrier lane w of every wave reads record w and the records are folded with DPP row_shr steps
     // (a fixed tree: deterministic), 2 LDS reads per wave instead of 11 * WPE.
     template <bool GUARD, class C>
-    static __device__ __forceinline__ void reduce(C& c, Sums& s, const unsigned long long (&pred)[8]) {
+    static __device__ __forceinline__ void reduce(const Params&, C& c, Sums& s, const unsigned long long (&pred)[8]) {
         wave_sum3(s.f0, s.f1, s.f2);
 #pragma unroll
         for (int k = 0; k < 8; ++k) s.i[k] = mask_count(pred[k]);
@@ -347,7 +348,7 @@ struct Cells {
     static constexpr int kThreadsPerEnv = WPE * kWave;
     static constexpr int kBlock = kThreadsPerEnv;
     static constexpr int kEnvsPerBlock = 1;
-    static constexpr bool kPace = false;
+    static constexpr bool kPace = false, kHelpers = false, kExitLane = true;
     static constexpr int kPad = 8;   // +inf entries behind the last moving pedestrian (>= entries per batch)
 #ifndef EVAC_ROW_BATCH
 #define EVAC_ROW_BATCH 8
@@ -400,8 +401,8 @@ struct Cells {
     }
 
     template <bool GUARD, class C>
-    static __device__ __forceinline__ void reduce(C& c, Sums& s, const unsigned long long (&pred)[8]) {
-        Wave<WPE>::template reduce<GUARD>(c, s, pred);
+    static __device__ __forceinline__ void reduce(const Params& p, C& c, Sums& s, const unsigned long long (&pred)[8]) {
+        Wave<WPE>::template reduce<GUARD>(p, c, s, pred);
     }
     template <class C>
     static __device__ __forceinline__ void exit_publish(C& c, bool exit_lane, float gx, float gy) {
@@ -515,7 +516,7 @@ template <int G_>
 struct Sub {
     static constexpr int G = G_;
     static_assert(G == 16 || G == 32, "sub-wave groups are 16 or 32 lanes");
-    static constexpr bool kEnvUniform = false;
+    static constexpr bool kEnvUniform = false, kHelpers = false, kExitLane = true;
     static constexpr int kThreadsPerEnv = G;
     static constexpr int kEnvsPerWave = kWave / G;
     static constexpr int kBlock = 256;
@@ -563,7 +564,7 @@ struct Sub {
     // Sums valid in the group's last lane (three chains interleaved, see wave_sum3); counts in every lane of the group.
     static __device__ __forceinline__ void invalidate(Ctx&) {}
     template <bool GUARD, class C>
-    static __device__ __forceinline__ void reduce(C& c, Sums& s, const unsigned long long (&pred)[8]) {
+    static __device__ __forceinline__ void reduce(const Params&, C& c, Sums& s, const unsigned long long (&pred)[8]) {
         float &a = s.f0, &b = s.f1, &cc = s.f2;
         {
             float& c = cc;

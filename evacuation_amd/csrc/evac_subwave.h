@@ -15,7 +15,7 @@ namespace evac {
 template <int G, bool GRAV>
 __device__ __forceinline__ void autoreset_sub(const Params& p, typename Sub<G>::Ctx& w, bool active, bool done, uint32_t gid,
                                               Ped& q, Env& e, StepOut& o, float (&o6)[6], evac_episode_stats_t* stats_row) {
-    finish_counts<Sub<G>>(w, q, o);
+    finish_counts<Sub<G>>(p, w, q, o);
     if (done && stats_row && w.owner) write_stats(stats_row, e, o);
     Ped nq = q;
     Env ne = e;

@@ -160,12 +160,17 @@ class BatchedEvacuationEnv:
         self.acc = torch.zeros((E, 4), dtype=torch.float32, device=dev)
         _lib.check(self.lib.evac_bind_state(self._h, _ptr(self.ped), _ptr(self.status), _ptr(self.agent),
                                             _ptr(self.clock), _ptr(self.acc)), self._h)
-        # scheduling scratch of evac_rollout (moving[E] | perm[E]): lets large batches of one-wave envs be dealt to the
-        # SIMDs by load; a performance hint, results do not depend on it (EVAC_SCHEDULE=0 leaves it unbound, for A/B runs)
+        # workspace of evac_rollout (include/evac.h): the load schedule of large batches of one-wave envs and the exchange
+        # areas of the team kernels; performance devices, results do not depend on them (EVAC_WORKSPACE=0 leaves it unbound,
+        # for A/B runs)
+        self.workspace = None
         self.schedule = None
-        if os.environ.get("EVAC_SCHEDULE", "1") != "0":
-            self.schedule = torch.zeros((2, E), dtype=torch.int32, device=dev)
-            _lib.check(self.lib.evac_bind_schedule(self._h, _ptr(self.schedule)), self._h)
+        if os.environ.get("EVAC_WORKSPACE", "1") != "0":
+            nbytes = int(self.lib.evac_workspace_bytes(self._h))
+            self.workspace = torch.zeros((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=dev)
+            assert self.workspace.data_ptr() % 256 == 0
+            _lib.check(self.lib.evac_bind_workspace(self._h, _ptr(self.workspace), C.c_int64(nbytes)), self._h)
+            self.schedule = self.workspace[:8 * E].view(torch.int32).view(2, E)     # moving[E] | perm[E]
         # step outputs (reused every step; callers that keep them must clone, like the reference's
         # live-reference observations, env.py:98-104)
         self.obs = torch.zeros((E, self.obs_dim), dtype=torch.float32, device=dev)
@@ -199,6 +204,12 @@ class BatchedEvacuationEnv:
             x = torch.as_tensor(np.asarray(x))
         x = x.to(device=self.device, dtype=dtype).contiguous()
         return self._check_tensor(x, shape, dtype, name)
+
+    def team_error(self) -> int:
+        """Non-zero if a barrier of a team rollout (N > 512, few envs) timed out; synchronises."""
+        v = C.c_int32(0)
+        _lib.check(self.lib.evac_team_error(self._h, C.byref(v)), self._h)
+        return int(v.value)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

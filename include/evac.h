@@ -175,13 +175,18 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions_or_null,
                  float* slab_out, evac_episode_stats_t* final_stats_or_null, int32_t capture_envs,
                  float* capture_or_null, const float* noise_or_null, void* stream);
 
-/* Optional scheduling scratch of evac_rollout (no reference analogue: the reference steps its envs one after another,
- * rpo_agent.py:123-126).  scratch: int32 [2][E] on the device, zero-initialised by the caller = moving[E] | perm[E].
- * When bound and the batch is large enough for CU-wide workgroups (one-wave envs, >= 16 envs per CU), every rollout
- * launch leaves the pedestrians still moving of each env in moving[] and, every 50 env steps, the envs are re-dealt to
- * the SIMDs by that load (perm[]).  A performance hint only: results are bit-identical with and without it.
- * NULL unbinds.  The scratch must stay alive, and be used on one stream at a time, like the state buffers. */
-int evac_bind_schedule(evac_handle_t h, int32_t* scratch_or_null);
+/* Optional workspace of evac_rollout (no reference analogue: the reference steps its envs one after another,
+ * rpo_agent.py:123-126).  `workspace`: evac_workspace_bytes(h) bytes on the device, 256-byte aligned, ZERO-INITIALISED by the
+ * caller, alive and used on one stream at a time like the state buffers.  It holds
+ *   - the rollout schedule of large batches of one-wave envs (>= 16 envs per CU): moving[E] | perm[E] int32 -- every launch
+ *     leaves the pedestrians still moving of each env in moving[] and, every 50 env steps, the envs are re-dealt to the
+ *     SIMDs by that load;
+ *   - the exchange areas of the team kernels (513..1024 pedestrians, few envs: 2 / 4 / 8 workgroups per env).
+ * Performance devices only: results are bit-identical with and without the workspace.  NULL unbinds.
+ * evac_team_error: non-zero if a team barrier of an earlier launch timed out (its results are void); synchronises. */
+int64_t evac_workspace_bytes(evac_handle_t h);
+int evac_bind_workspace(evac_handle_t h, void* workspace_or_null, int64_t bytes);
+int evac_team_error(evac_handle_t h, int32_t* out);
 
 /* State exchange in the reference's own shapes (needed for parity tests, checkpoints):
  * pos/dir float [E][N][2], status uint8 [E][N], agent_pos/agent_dir float [E][2], now int32 [E]. */

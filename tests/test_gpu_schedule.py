@@ -1,4 +1,4 @@
-"""The CU-wide rollout workgroups and their load schedule (evac_bind_schedule, k_schedule) are performance devices:
+"""The CU-wide rollout workgroups and their load schedule (evac_bind_workspace, k_schedule) are performance devices:
 which wave carries which env, and with which issue priority, must not change a single bit of the results."""
 import os
 
@@ -18,10 +18,10 @@ def ea():
 
 
 def _make(ea, cfg, wrap, E, seed, cu_wide, schedule):
-    old = {k: os.environ.get(k) for k in ("EVAC_CU_WIDE", "EVAC_SCHEDULE")}
+    old = {k: os.environ.get(k) for k in ("EVAC_CU_WIDE", "EVAC_WORKSPACE")}
     try:
         os.environ["EVAC_CU_WIDE"] = "1" if cu_wide else "0"
-        os.environ["EVAC_SCHEDULE"] = "1" if schedule else "0"
+        os.environ["EVAC_WORKSPACE"] = "1" if schedule else "0"
         return ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed)
     finally:
         for k, v in old.items():

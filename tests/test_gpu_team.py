@@ -1,0 +1,93 @@
+"""Team kernels (csrc/evac_team.h): one env of 513..1024 pedestrians on 2 / 4 / 8 CUs.  They must reproduce the
+one-workgroup-per-env cell-list kernels bit for bit -- integer heading sums, the same reduction tree -- whatever the team
+size, and never leave a barrier hanging."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ea():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import evacuation_amd
+    return evacuation_amd
+
+
+def _make(ea, cfg, wrap, E, seed, team):
+    old = os.environ.get("EVAC_TEAM")
+    try:
+        os.environ["EVAC_TEAM"] = str(team)
+        return ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed)
+    finally:
+        if old is None:
+            os.environ.pop("EVAC_TEAM", None)
+        else:
+            os.environ["EVAC_TEAM"] = old
+
+
+@pytest.mark.parametrize("n,E,team,wrap_kw,ens", [
+    (1024, 8, 8, dict(positions="rel", statuses="ohe", type="Box"), 1.0),     # BASELINE config 5's observation
+    (1024, 5, 8, dict(positions="grav", alpha=3), 1.0),                       # E not a multiple of 8: idle team slots
+    (1000, 32, 8, dict(positions="grav", alpha=2), 0.5),                      # follower rows needed (enslaving_degree < 1)
+    (600, 16, 4, dict(positions="abs", statuses="cat", type="Dict"), 1.0),    # members without pedestrians (600 < 1024)
+    (1024, 16, 2, dict(positions="rel", statuses="no", type="Box"), 1.0),
+    (777, 40, 4, dict(positions="grav", alpha=3), 0.1),
+])
+def test_team_rollout_equals_one_workgroup_per_env(ea, n, E, team, wrap_kw, ens):
+    import torch
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=35, is_new_exiting_reward=True, intrinsic_reward_coef=0.5,
+                       enslaving_degree=ens)
+    wrap = ea.EnvWrappersConfig(**wrap_kw)
+    ref = _make(ea, cfg, wrap, E, 11, team=0)
+    tm = _make(ea, cfg, wrap, E, 11, team=team)
+    assert "CUs/env" in tm.kernel_variant("rollout") and "CUs/env" not in ref.kernel_variant("rollout")
+    ref.reset(); tm.reset()
+    for chunk in (20, 30, 1, 25):                        # episodes end (and envs reset) inside the launches
+        a = ref.rollout(chunk)
+        b = tm.rollout(chunk)
+        torch.cuda.synchronize()
+        assert tm.team_error() == 0
+        for key in ("obs", "reward", "terminated", "truncated", "episode_stats"):
+            assert torch.equal(a[key].view(torch.int32), b[key].view(torch.int32)), (chunk, key)
+    sa, sb = ref.get_state(), tm.get_state()
+    for key in sa:
+        assert torch.equal(sa[key], sb[key]), key
+    # and the step API of the team handle (one workgroup per env) continues the same trajectory
+    act = torch.rand((E, 2), device=ref.device) * 2 - 1
+    o1, r1, t1, u1, _ = ref.step(act)
+    o2, r2, t2, u2, _ = tm.step(act)
+    assert torch.equal(o1.view(torch.int32), o2.view(torch.int32)) and torch.equal(r1.view(torch.int32), r2.view(torch.int32))
+    ref.close(); tm.close()
+
+
+def test_team_nan_poisoning_reaches_every_member(ea):
+    """A zero direction (0/0 heading, area.py:101) poisons every FOLLOWER / VISCEK pedestrian of the env in the reference
+    (area.py:118-119): the flag has to cross the team."""
+    import torch
+    n, E = 1024, 8
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=1000)
+    wrap = ea.EnvWrappersConfig(positions="rel", statuses="ohe", type="Box")
+    ref = _make(ea, cfg, wrap, E, 3, team=0)
+    tm = _make(ea, cfg, wrap, E, 3, team=8)
+    for env in (ref, tm):
+        env.reset()
+        st = env.get_state()
+        d = st["dir"].clone()
+        who = 640 + int((st["status"][2, 640:] == 1).nonzero()[0])    # env 2, a VISCEK pedestrian of the sixth member or later
+        d[2, who] = 0.0
+        env.set_state(dir=d)
+    a = ref.rollout(3); b = tm.rollout(3)
+    torch.cuda.synchronize()
+    assert tm.team_error() == 0
+    sa, sb = ref.get_state(), tm.get_state()
+    assert torch.isnan(sa["pos"][2]).any() and not torch.isnan(sa["pos"][1]).any()
+    for key in sa:
+        assert torch.equal(sa[key].view(torch.uint8) if sa[key].dtype == torch.uint8 else sa[key].view(torch.int32),
+                           sb[key].view(torch.uint8) if sb[key].dtype == torch.uint8 else sb[key].view(torch.int32)), key
+    assert torch.equal(a["obs"].view(torch.int32), b["obs"].view(torch.int32))
+    ref.close(); tm.close()

@@ -26,6 +26,7 @@ for phase in range(4):
     env.rollout(T); torch.cuda.synchronize()
     lib.evac_debug_stamps(buf)
     waves = E * (1 if n <= 64 else 2 if n <= 128 else 4 if n <= 256 else 8 if n <= 512 else 16)
+    if "CUs/env" in env.kernel_variant(): waves *= int(env.kernel_variant().split("<")[1].split()[0])   # team kernels: K workgroups per env
     tot = sum(buf[:8])
     print(f"-- steps {phase*600+500}..{phase*600+600}: {tot / waves / T:.0f} cycles per wave-step; shader clock {buf[8] / max(1, buf[9]) * 100:.0f} MHz, "
           f"{buf[9] / waves / T * 10:.0f} ns per wave-step (s_memrealtime); wave lifetime per step: fastest {((1 << 64) - 1 - buf[11]) / T * 10:.0f} ns, slowest {buf[10] / T * 10:.0f} ns")
