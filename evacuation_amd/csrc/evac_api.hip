@@ -256,7 +256,7 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
             const int rows = (num_envs + 7) / 8 * 8;
             for (int k = 8; k >= 2; k >>= 1)
                 if ((want < 0 || want == k) && rows * k <= cus) { h->team_k = k; break; }
-            if (want == 0) h->team_k = 0;
+            if (want == 0 || (want < 0 && std::getenv("EVAC_CELLS"))) h->team_k = 0;   // an A/B run of the one-workgroup families
         }
     }
     p.seed_lo = (uint32_t)(seed & 0xffffffffull);

@@ -335,6 +335,57 @@ __device__ __forceinline__ bool needs_row(const Params& p, int st) {
     return st == kViscek || (st == kFollower && p.one_minus_ens != 0.0f);
 }
 
+// The head of Area.pedestrians_step (area.py:79-101), per pedestrian: escaped pedestrians are pinned to the exit, exiting
+// ones head for it, and every moving pedestrian gets its unit heading.  Mutates q (position / direction of escaped and
+// exiting pedestrians).  A function of the pedestrian's own state only -- the team kernels evaluate it a second time, on a
+// copy of the post-step state, to publish the next step's tile entry together with this step's reduction (evac_team.h).
+struct PrePair {
+    bool efv, fv, fol, row;   // moves (V | F | E); has a row in the reference (V | F); FOLLOWER; row must be evaluated
+    float ux, uy;             // unit heading (NaN for a zero direction, as the reference's 0/0)
+};
+__device__ __forceinline__ PrePair pre_pair(const Params& p, Ped& q) {
+    PrePair r;
+    const bool esc = q.st == kEscaped, exi = q.st == kExiting;
+    q.x = esc ? kExitX : q.x;                                               // area.py:79-81
+    q.y = esc ? kExitY : q.y;
+    q.dx = esc ? 0.0f : q.dx;
+    q.dy = esc ? 0.0f : q.dy;
+    if (ballot(exi) != 0ull) {                                            // area.py:84-90 (area.py:85 `if any(exiting)`)
+        const float vx = kExitX - q.x, vy = kExitY - q.y;
+        const float l2 = vx * vx + vy * vy;
+        const float il = frsq(l2);
+        const float ln = l2 * il;                                           // |v|
+        const float sz = ln > p.step_size ? p.step_size : ln;
+        const float k = il * sz;                                            // (v / |v|) * min(|v|, step)
+        q.dx = exi ? vx * k : q.dx;
+        q.dy = exi ? vy * k : q.dy;
+    }
+    // lanes beyond n_ped carry status 0, so status tests need no `active &&` (saves mask algebra on the SALU)
+    r.efv = (unsigned)(q.st - kViscek) < 3u;                                // area.py:99  (V | F | E) = codes 1..3
+    r.fv = (unsigned)(q.st - kViscek) < 2u;                                 // area.py:104 (V | F) = codes 1..2
+    r.fol = q.st == kFollower;
+    // Which pedestrians need their row of the distance matrix evaluated.  The reference evaluates FOLLOWER and VISCEK rows
+    // (area.py:104) and then blends a follower's new heading as e * leader + (1 - e) * heading (area.py:139-142): with
+    // enslaving_degree = 1 -- the reference's default (config.py:32) -- the follower's own Vicsek mean is multiplied by
+    // exactly 0, so only the VISCEK rows are evaluated (late in an episode most moving pedestrians are followers:
+    // tools/moving_distribution.py).  A follower lane then sees a zero sum -> a finite heading -> times 0; the one way the
+    // product is not 0, the reference's NaN poisoning (any NaN heading makes every row NaN, area.py:118-119), is kept
+    // by the families (a flag wherever rows are skipped).
+    r.row = needs_row(p, q.st);
+    // unit headings of the moving pedestrians: area.py:100-101.  0 * rsq(0) = 0 * inf = NaN, as 0/0.
+    // A NaN heading reaches every FOLLOWER/VISCEK pedestrian's sum (w * NaN = NaN even for w = 0 in the all-pairs
+    // families, a flag in the cell-list and team families) -- exactly the reference's (intersection * u).sum() with
+    // NaN * 0 = NaN (area.py:118-119).  nan_guard (non-reference) zeroes it instead.
+    const float inrm = frsq(q.dx * q.dx + q.dy * q.dy);
+    r.ux = q.dx * inrm;
+    r.uy = q.dy * inrm;
+    if (p.flags & kFlagNanGuard) {          // uniform
+        r.ux = (r.ux != r.ux) ? 0.0f : r.ux;
+        r.uy = (r.uy != r.uy) ? 0.0f : r.uy;
+    }
+    return r;
+}
+
 // gravity_encoding.py:15-16,35-37:  -alpha / (|R| + eps)^(alpha+2) * R, with |R|^2 given
 __device__ __forceinline__ void grav_term2(const Params& p, float rx, float ry, float r2, float& gx, float& gy) {
     const float nrm = fsqrt(r2) + p.eps;

@@ -97,49 +97,10 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     bool work = true;
     if constexpr (F::kHelpers) work = !c.helper;
     const int old_st = q.st;
-    bool efv = false, fv = false, fol = false, row = false;
-    float ux = 0.0f, uy = 0.0f;
-    if (work) {
-    const bool esc = q.st == kEscaped, exi = q.st == kExiting;
-    q.x = esc ? kExitX : q.x;                                               // area.py:79-81
-    q.y = esc ? kExitY : q.y;
-    q.dx = esc ? 0.0f : q.dx;
-    q.dy = esc ? 0.0f : q.dy;
-    if (ballot(exi) != 0ull) {                                            // area.py:84-90 (area.py:85 `if any(exiting)`)
-        const float vx = kExitX - q.x, vy = kExitY - q.y;
-        const float l2 = vx * vx + vy * vy;
-        const float il = frsq(l2);
-        const float ln = l2 * il;                                           // |v|
-        const float sz = ln > p.step_size ? p.step_size : ln;
-        const float k = il * sz;                                            // (v / |v|) * min(|v|, step)
-        q.dx = exi ? vx * k : q.dx;
-        q.dy = exi ? vy * k : q.dy;
-    }
-    // lanes beyond n_ped carry status 0, so status tests need no `active &&` (saves mask algebra on the SALU)
-    efv = (unsigned)(q.st - kViscek) < 3u;                                  // area.py:99  (V | F | E) = codes 1..3
-    fv = (unsigned)(q.st - kViscek) < 2u;                                   // area.py:104 (V | F) = codes 1..2
-    fol = q.st == kFollower;
-    // Which pedestrians need their row of the distance matrix evaluated.  The reference evaluates FOLLOWER and VISCEK rows
-    // (area.py:104) and then blends a follower's new heading as e * leader + (1 - e) * heading (area.py:139-142): with
-    // enslaving_degree = 1 -- the reference's default (config.py:32) -- the follower's own Vicsek mean is multiplied by
-    // exactly 0, so only the VISCEK rows are evaluated (late in an episode most moving pedestrians are followers:
-    // tools/moving_distribution.py).  A follower lane then sees a zero sum -> a finite heading -> times 0; the one way the
-    // product is not 0, the reference's NaN poisoning (any NaN heading makes every row NaN, area.py:118-119), is kept
-    // by the families (a flag wherever rows are skipped).
-    row = needs_row(p, q.st);
-
-    // unit headings of the moving pedestrians: area.py:100-101.  0 * rsq(0) = 0 * inf = NaN, as 0/0.
-    // A NaN heading reaches every FOLLOWER/VISCEK pedestrian's sum (w * NaN = NaN even for w = 0 in the all-pairs
-    // families, a flag in the cell-list family) -- exactly the reference's (intersection * u).sum() with
-    // NaN * 0 = NaN (area.py:118-119).  nan_guard (non-reference) zeroes it instead.
-    const float inrm = frsq(q.dx * q.dx + q.dy * q.dy);
-    ux = q.dx * inrm;
-    uy = q.dy * inrm;
-    if (p.flags & kFlagNanGuard) {          // uniform
-        ux = (ux != ux) ? 0.0f : ux;
-        uy = (uy != uy) ? 0.0f : uy;
-    }
-    }   // work
+    PrePair pp{};
+    if (work) pp = pre_pair(p, q);
+    const bool efv = pp.efv, fv = pp.fv, fol = pp.fol, row = pp.row;
+    const float ux = pp.ux, uy = pp.uy;
     EVAC_T(c, 1);   // leader + per-lane pre-pair work
 
     // ---- neighbour sum: area.py:104-119 ----
@@ -212,6 +173,7 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     pred[4] = ballot(new_st == kFollower);
     }   // work
     if constexpr (GRAV) F::exit_publish(c, exit_lane, gx, gy);
+    if constexpr (F::kPipelined) F::stage_next(p, c, q, work);   // team kernels: the next step's tile entry travels with this reduction
     if constexpr (!(EVAC_ABLATE & 8)) F::template reduce<false>(p, c, s, pred);
     if constexpr (GRAV) {
         float ex = 0.0f, ey = 0.0f;
@@ -557,8 +519,11 @@ __device__ __forceinline__ void rollout_body(
 #ifdef EVAC_STAMP
     unsigned long long rt1_;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1_)::"memory");
-    if (w.lane == 0) {
+    bool stamp_me = w.lane == 0;
+    if constexpr (F::kHelpers) stamp_me = stamp_me && !w.helper;   // team kernels: the critical path runs through the ped waves
+    if (stamp_me) {
         for (int k = 0; k < 8; ++k) atomicAdd(&g_stamps[k], w.stamp.acc[k]);
+        for (int k = 12; k < 16; ++k) atomicAdd(&g_stamps[k], w.stamp.acc[k]);   // family-specific sub-phases
         atomicAdd(&g_stamps[8], w.stamp.last - ck0_);
         atomicAdd(&g_stamps[9], rt1_ - rt0_);
         atomicMax(&g_stamps[10], rt1_ - rt0_);                      // slowest / fastest wave of the launch

@@ -42,7 +42,7 @@ struct Wave {
     static constexpr int kBlock = WPE == 1 ? BLOCK1_ : kThreadsPerEnv;
     static constexpr int kEnvsPerBlock = kBlock / kThreadsPerEnv;
     static constexpr bool kPace = WPE == 1 && kBlock == 1024;
-    static constexpr bool kHelpers = false, kExitLane = true;
+    static constexpr bool kHelpers = false, kExitLane = true, kPipelined = false;
     static constexpr const char* kName = WPE == 1 ? (kPace ? "1 wave/env, all pairs, CU-wide workgroups" : "1 wave/env, all pairs") : (WPE == 2 ? "2 waves/env, all pairs" : (WPE == 4 ? "4 waves/env, all pairs" : (WPE == 8 ? "8 waves/env, all pairs" : "16 waves/env, all pairs")));
 
     // WPE > 1: two tiles used alternately, so that writing step t+1's tile needs no barrier against the waves still
@@ -348,7 +348,7 @@ struct Cells {
     static constexpr int kThreadsPerEnv = WPE * kWave;
     static constexpr int kBlock = kThreadsPerEnv;
     static constexpr int kEnvsPerBlock = 1;
-    static constexpr bool kPace = false, kHelpers = false, kExitLane = true;
+    static constexpr bool kPace = false, kHelpers = false, kExitLane = true, kPipelined = false;
     static constexpr int kPad = 8;   // +inf entries behind the last moving pedestrian (>= entries per batch)
 #ifndef EVAC_ROW_BATCH
 #define EVAC_ROW_BATCH 8
@@ -516,7 +516,7 @@ template <int G_>
 struct Sub {
     static constexpr int G = G_;
     static_assert(G == 16 || G == 32, "sub-wave groups are 16 or 32 lanes");
-    static constexpr bool kEnvUniform = false, kHelpers = false, kExitLane = true;
+    static constexpr bool kEnvUniform = false, kHelpers = false, kExitLane = true, kPipelined = false;
     static constexpr int kThreadsPerEnv = G;
     static constexpr int kEnvsPerWave = kWave / G;
     static constexpr int kBlock = 256;

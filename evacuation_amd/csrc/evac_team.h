@@ -4,18 +4,22 @@
 // crowd has flocked into one corner of the room, the neighbour sum of ONE env is ~350 k true pairs -- tools/row_lengths.py).
 //
 // Member k of a team owns pedestrians [k P, (k+1) P), P = 1024 / K, in the lanes of its first P / 64 waves ("ped waves");
-// all 16 waves of the workgroup share the member's part of the pair work.  Per step the members meet twice through global
+// all 16 waves of the workgroup share the member's part of the pair work.  The members meet ONCE per step through global
 // memory (device-scope write-through stores, device-scope loads, a counter per team; no cache flush or invalidation:
-// tools/microbench/team_barrier.hip measures 1.5 us per publish -> barrier -> gather round of 16 KiB among 8 CUs):
-//   1. neighbour sum: every member publishes its moving pedestrians (position x 2^40, integer heading), compacted inside
-//      its segment, and their count; after the barrier every member gathers all segments into its own LDS tile -- the
-//      columns of the distance matrix.  The rows are the member's own pedestrians that need one (step_env: needs_row),
-//      compacted, two per lane and pass; each of the 16 waves takes 1/16 of the columns (wave-uniform ds_read_b128
-//      broadcasts) and the 16 partial sums of a row meet in LDS.  Heading sums are INTEGERS (pair_accumulate_int), so the
-//      result does not depend on how the pairs were split -- it is bit-identical to the cell-list kernel's (Cells<16>).
-//   2. reduction: every ped wave publishes the same 32-byte record as a wave of Cells<16> does through LDS; after the barrier
-//      every wave folds the 16 records with the same DPP tree, so rewards / observations / flags are bit-identical too and
-//      every member takes the same decisions (autoreset, termination) without further talk.
+// tools/microbench/team_barrier.hip measures 1.5 us per publish -> barrier -> gather round of 16 KiB among 8 CUs).  What
+// travels in that round:
+//   * the step's reduction: every ped wave publishes the same 32-byte record as a wave of Cells<16> leaves in LDS; after the
+//     barrier every wave folds the 16 records with the same DPP tree, so rewards / observations / flags are bit-identical to
+//     the one-workgroup kernels' and every member takes the same decisions (autoreset, termination) without further talk;
+//   * the NEXT step's tile: the head of the next step (pre_pair: escaped pin, exiting heading, unit heading) depends on the
+//     pedestrian's own post-step state only, so every ped wave already publishes its moving pedestrians (position x 2^40,
+//     integer heading), compacted inside the wave's 64-entry segment, and their count; after the barrier every member
+//     gathers all 16 segments into its LDS tile -- the columns of the next step's distance matrix.  (The first step of a
+//     launch and the step after an autoreset run the same exchange on their own.)
+// The rows are the member's own pedestrians that need one (step_env: needs_row), compacted per ped wave, two ped waves per
+// pass (two rows per lane); each of the 16 waves takes 1/16 of the columns (wave-uniform ds_read_b128 broadcasts) and the 16
+// partial sums of a row meet in LDS.  Heading sums are INTEGERS (pair_accumulate_int), so the result does not depend on
+// how the pairs were split -- it is bit-identical to the cell-list kernel's (Cells<16>).
 // Everything else is the common step body (step_env) and rollout scaffolding (rollout_body); waves without pedestrians
 // ("helper" waves) skip the per-pedestrian arithmetic.
 //
@@ -30,15 +34,15 @@
 namespace evac {
 
 __device__ __forceinline__ void store_dev(void* ptr, f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
-__device__ __forceinline__ void store_dev(void* ptr, i2 v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_dev_i32(void* ptr, int v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
 __device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int K_>
 struct Team {
     static constexpr int K = K_;
     static_assert(K == 2 || K == 4 || K == 8, "a team has 2, 4 or 8 members");
-    static constexpr int WPE = 16;                       // waves per workgroup
-    static constexpr bool kEnvUniform = true, kPace = false, kHelpers = true, kExitLane = false;
+    static constexpr int WPE = 16;                       // waves per workgroup = ped waves per team
+    static constexpr bool kEnvUniform = true, kPace = false, kHelpers = true, kExitLane = false, kPipelined = true;
     static constexpr int kBlock = 1024, kThreadsPerEnv = 1024, kEnvsPerBlock = 1;
     static constexpr int P = 1024 / K;                   // pedestrians per member
     static constexpr int PW = P / kWave;                 // ped waves per member
@@ -47,10 +51,14 @@ struct Team {
 
     struct Smem {
         f4 tile[1024 + kPad];                 // the team's moving pedestrians: (X, Y, heading x, heading y as integers)
-        float2 rowpos[P];                     // this member's rows, compacted
-        i2 part[WPE][P];                      // partial heading sums [column share][row slot]
-        int cols[PW], rows[PW], nans[PW];     // per ped wave: moving pedestrians, needed rows, NaN headings
+        float2 rowpos[PW][kWave];             // this member's needed rows, compacted per ped wave
+        i2 part[WPE][PW][kWave];              // partial heading sums [column share][ped wave][row slot]
+        int rows[PW];                         // needed rows per ped wave
         int abort;                            // sticky: a barrier timed out
+        alignas(16) f4 red_f;                 // the folded records (wave 0 -> everybody)
+        alignas(16) i4 red_i;
+        i2 seg[WPE];                          // where segment w of the exchange area lands in the tile: (offset, entries)
+        i2 totals;                            // entries of the tile, NaN headings among them
         alignas(16) float stage[1][kStageSteps][12];
     };
 
@@ -61,6 +69,9 @@ struct Team {
         bool owner, helper;
         unsigned round = 0;                   // barrier rounds of this launch so far
         int par_tile = 0, par_rec = 0;        // double buffering of the exchange areas
+        // the tile in LDS: valid for the coming step?  its size, its NaN headings, this lane's row slot in it
+        bool tile_valid = false, staged = false;
+        int n_cols = 0, n_nan = 0, row_slot = 0;
 #ifdef EVAC_STAMP
         StampState stamp;
 #endif
@@ -81,7 +92,7 @@ struct Team {
     };
 
     static __device__ __forceinline__ void sync() { __syncthreads(); }
-    static __device__ __forceinline__ void invalidate(Ctx&) {}
+    static __device__ __forceinline__ void invalidate(Ctx& c) { c.tile_valid = false; }   // the state changed outside step_env (autoreset)
     static __device__ __forceinline__ void init(Ctx& c) {
         if (threadIdx.x == 0) c.sm.abort = 0;
         __syncthreads();
@@ -110,6 +121,75 @@ struct Team {
         __syncthreads();
     }
 
+    // A pedestrian's tile entry for the step that starts from state `q` goes to its wave's segment of the exchange area
+    // (compacted inside the wave: no barrier), the wave's count with it; the row position to LDS.
+    static __device__ __forceinline__ void publish_entry(const Params& p, Ctx& c, const Ped& q, bool efv, bool row, float ux, float uy) {
+        auto& sm = c.sm;
+        const int par = c.par_tile;
+        const unsigned long long m_col = ballot(efv), m_row = ballot(row);
+        const int col_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m_col >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_col, 0u));
+        c.row_slot = __builtin_amdgcn_mbcnt_hi((unsigned)(m_row >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_row, 0u));
+        f4* gtile = (f4*)p.team_tile + ((size_t)par * p.n_envs + c.env) * 1024;
+        int* gcnt = (int*)p.team_cnt + ((size_t)par * p.n_envs + c.env) * WPE;
+        const float X = q.x * kTileScale, Y = q.y * kTileScale;
+        if (efv) {
+            const float hs = p.head_scale;
+            const int hx = (int)__builtin_rintf(ux * hs), hy = (int)__builtin_rintf(uy * hs);
+            store_dev(gtile + c.wave_in_env * kWave + col_rank, f4{X, Y, __builtin_bit_cast(float, hx), __builtin_bit_cast(float, hy)});
+        }
+        const int n_nan = __popcll(ballot(efv && (ux != ux || uy != uy)));
+        if (c.lane == 0) {
+            store_dev_i32(gcnt + c.wave_in_env, __popcll(m_col) | (n_nan << 16));
+            sm.rows[c.wave] = __popcll(m_row);
+        }
+        if (row) sm.rowpos[c.wave][c.row_slot] = make_float2(X, Y);
+    }
+
+    // after the barrier: all 16 segments -> the LDS tile (thread t fetches entry t % 64 of ped wave t / 64)
+    static __device__ __forceinline__ void gather_tile(const Params& p, Ctx& c) {
+        auto& sm = c.sm;
+        const int par = c.par_tile;
+        c.par_tile = par ^ 1;
+        const f4* gtile = (const f4*)p.team_tile + ((size_t)par * p.n_envs + c.env) * 1024;
+        const int* gcnt = (const int*)p.team_cnt + ((size_t)par * p.n_envs + c.env) * WPE;
+        i4 cv[4];                            // count | NaN headings << 16 of the 16 ped waves; the loads and their wait in ONE statement
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(cv[0]), "=&v"(cv[1]), "=&v"(cv[2]), "=&v"(cv[3]) : "v"(gcnt) : "memory");
+        const int t = threadIdx.x, gw = t >> 6, e = t & (kWave - 1);
+        int off = 0, cnt = 0, n_cols = 0, n_nan = 0;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int w4[4] = {cv[h].x, cv[h].y, cv[h].z, cv[h].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int k16 = 4 * h + k, ck = w4[k] & 0xffff;
+                off += k16 < gw ? ck : 0;
+                cnt = k16 == gw ? ck : cnt;
+                n_cols += ck;
+                n_nan += w4[k] >> 16;
+            }
+        }
+        if (e < cnt) {
+            f4 v;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(gtile + gw * kWave + e) : "memory");
+            sm.tile[off + e] = v;
+        }
+        if (t < kPad) sm.tile[n_cols + t] = f4{__builtin_inff(), 0.0f, 0.0f, 0.0f};
+        c.n_cols = n_cols;
+        c.n_nan = n_nan;
+        c.tile_valid = true;
+    }
+
+    // step_env, after the move and the classifier: the next step's entry, from a copy of the post-step state
+    static __device__ __forceinline__ void stage_next(const Params& p, Ctx& c, const Ped& q, bool work) {
+        Ped n = q;
+        PrePair pp{};
+        if (work) pp = pre_pair(p, n);
+        if (work) publish_entry(p, c, n, pp.efv, pp.row, pp.ux, pp.uy);
+        c.staged = true;
+    }
+
     template <bool GUARD, class C>
     static __device__ __forceinline__ void reduce(const Params& p, C& c, Sums& s, const unsigned long long (&pred)[8]) {
         wave_sum3(s.f0, s.f1, s.f2);
@@ -118,32 +198,77 @@ struct Team {
         const int par = c.par_rec;
         c.par_rec = par ^ 1;
         f4* rec = (f4*)p.team_rec + ((size_t)par * p.n_envs + c.env) * (2 * WPE);
+        const bool staged = c.staged;          // uniform over the team: this round also carries the next step's tile
+        c.staged = false;
         if (!c.helper && c.lane == 0) {
             store_dev(rec + 2 * c.wave_in_env, f4{s.f0, s.f1, s.f2, 0.0f});
             const i4 ri = i4{s.i[0] | (s.i[1] << 16), s.i[2] | (s.i[3] << 16), s.i[4] | (s.i[5] << 16), s.i[6] | (s.i[7] << 16)};
             store_dev(rec + 2 * c.wave_in_env + 1, __builtin_bit_cast(f4, ri));
         }
+        EVAC_T(c, 12);   // (sub-phase: per-pedestrian work of the ped waves / waiting for them, record stores)
         team_round(p, c);
-        const int w = c.lane < WPE ? c.lane : WPE - 1;
-        f4 rf, rb;
-        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
-                     : "=&v"(rf), "=&v"(rb) : "v"(rec + 2 * w) : "memory");
-        i4 ri = __builtin_bit_cast(i4, rb);
-        // the fold of Wave<16>::reduce, instruction for instruction: same tree, same rounding
+        EVAC_T(c, 13);   // (sub-phase: the team barrier)
+        // ONE load phase.  Wave 0 reads the 16 records (lane w: record w) and the 16 segment counts, folds the records and
+        // leaves the result in LDS for the other waves (every wave reading them itself costs 7 device-scope loads of the
+        // same three cache lines by 128 waves of a team: 5000 cycles of the step); every wave reads entry `lane` of the
+        // segment of ped wave `c.wave` (wave w of every member gathers segment w; which of its 64 entries are real is known
+        // from the counts, so that load need not wait for them).
+        const f4* gtile = (const f4*)p.team_tile + ((size_t)c.par_tile * p.n_envs + c.env) * 1024 + c.wave * kWave + c.lane;
+        f4 ev;
+        if (c.wave == 0) {
+            const int w = c.lane < WPE ? c.lane : WPE - 1;
+            const int* gcnt = (const int*)p.team_cnt + ((size_t)c.par_tile * p.n_envs + c.env) * WPE + w;
+            f4 rf, rb;
+            int cw;
+            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                         "global_load_dwordx4 %2, %5, off sc1\n\tglobal_load_dword %3, %6, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(rf), "=&v"(rb), "=&v"(ev), "=&v"(cw) : "v"(rec + 2 * w), "v"(gtile), "v"(gcnt) : "memory");
+            i4 ri = __builtin_bit_cast(i4, rb);
+            // the fold of Wave<16>::reduce, instruction for instruction: same tree, same rounding
 #define EVAC_RED_STEP(CTRL)                                                                                      \
     rf.x = dpp_add<CTRL, 0xf>(rf.x); rf.y = dpp_add<CTRL, 0xf>(rf.y); rf.z = dpp_add<CTRL, 0xf>(rf.z);           \
     ri.x = dpp_addi<CTRL, 0xf>(ri.x); ri.y = dpp_addi<CTRL, 0xf>(ri.y); ri.z = dpp_addi<CTRL, 0xf>(ri.z);        \
     ri.w = dpp_addi<CTRL, 0xf>(ri.w);
-        EVAC_RED_STEP(0x111)
-        EVAC_RED_STEP(0x112)
-        EVAC_RED_STEP(0x114)
-        EVAC_RED_STEP(0x118)
+            EVAC_RED_STEP(0x111)
+            EVAC_RED_STEP(0x112)
+            EVAC_RED_STEP(0x114)
+            EVAC_RED_STEP(0x118)
 #undef EVAC_RED_STEP
-        s.f0 = readlane_f(rf.x, WPE - 1);
-        s.f1 = readlane_f(rf.y, WPE - 1);
-        s.f2 = readlane_f(rf.z, WPE - 1);
-        const int a = __builtin_amdgcn_readlane(ri.x, WPE - 1), b = __builtin_amdgcn_readlane(ri.y, WPE - 1);
-        const int d = __builtin_amdgcn_readlane(ri.z, WPE - 1), g = __builtin_amdgcn_readlane(ri.w, WPE - 1);
+            // where segment w lands in the tile: exclusive prefix of the 16 counts (lanes 0..15, one DPP row)
+            const int cnt = cw & 0xffff;
+            int incl = cnt, nans = cw >> 16;
+            incl = dpp_addi<0x111, 0xf>(incl); nans = dpp_addi<0x111, 0xf>(nans);
+            incl = dpp_addi<0x112, 0xf>(incl); nans = dpp_addi<0x112, 0xf>(nans);
+            incl = dpp_addi<0x114, 0xf>(incl); nans = dpp_addi<0x114, 0xf>(nans);
+            incl = dpp_addi<0x118, 0xf>(incl); nans = dpp_addi<0x118, 0xf>(nans);
+            if (c.lane < WPE) c.sm.seg[c.lane] = i2{incl - cnt, cnt};
+            if (c.lane == WPE - 1) {
+                c.sm.red_f = rf;
+                c.sm.red_i = ri;
+                c.sm.totals = i2{incl, nans};
+            }
+        } else {
+            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(ev) : "v"(gtile) : "memory");
+        }
+        __syncthreads();
+        EVAC_T(c, 14);   // (sub-phase: loads of records, counts, tile entry)
+        const f4 rf = c.sm.red_f;
+        const i4 ri = c.sm.red_i;
+        if (staged) {
+            const i2 sg = c.sm.seg[c.wave], tot = c.sm.totals;
+            if (c.lane < sg.y) c.sm.tile[sg.x + c.lane] = ev;
+            if (threadIdx.x < kPad) c.sm.tile[tot.x + threadIdx.x] = f4{__builtin_inff(), 0.0f, 0.0f, 0.0f};
+            c.n_cols = tot.x;
+            c.n_nan = tot.y;
+            c.par_tile ^= 1;
+            c.tile_valid = true;
+            __syncthreads();
+        }
+        EVAC_T(c, 15);   // (sub-phase: LDS tile of the next step)
+        s.f0 = rf.x;
+        s.f1 = rf.y;
+        s.f2 = rf.z;
+        const int a = ri.x, b = ri.y, d = ri.z, g = ri.w;
         s.i[0] = a & 0xffff; s.i[1] = a >> 16;
         s.i[2] = b & 0xffff; s.i[3] = b >> 16;
         s.i[4] = d & 0xffff; s.i[5] = d >> 16;
@@ -157,123 +282,70 @@ struct Team {
     static __device__ __forceinline__ void neighbour_sum(const Params& p, Ctx& c, const Ped& q, bool efv, bool row,
                                                          float ux, float uy, float& sx, float& sy) {
         auto& sm = c.sm;
-        // ---- 1. compaction inside the member: moving pedestrians (columns) and needed rows ----
-        const unsigned long long m_col = ballot(efv), m_row = ballot(row);
-        int col_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m_col >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_col, 0u));
-        int row_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m_row >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_row, 0u));
-        if (!c.helper && c.lane == 0) {
-            sm.cols[c.wave] = __popcll(m_col);
-            sm.rows[c.wave] = __popcll(m_row);
-            sm.nans[c.wave] = __popcll(ballot(efv && (ux != ux || uy != uy)));
+        if (!c.tile_valid) {      // first step of a launch, or the step after an autoreset: the exchange on its own (uniform over the team)
+            if (!c.helper) publish_entry(p, c, q, efv, row, ux, uy);
+            team_round(p, c);
+            gather_tile(p, c);
+            __syncthreads();
         }
-        __syncthreads();
-        int n_member = 0, n_rows = 0, n_nan_member = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < PW; ++w2) {
-            const int kc = sm.cols[w2], kr = sm.rows[w2];
-            col_rank += (w2 < c.wave) ? kc : 0;
-            row_rank += (w2 < c.wave) ? kr : 0;
-            n_member += kc;
-            n_rows += kr;
-            n_nan_member += sm.nans[w2];
-        }
-        // ---- 2. publish the member's segment ----
-        const int par = c.par_tile;
-        c.par_tile = par ^ 1;
-        f4* gtile = (f4*)p.team_tile + ((size_t)par * p.n_envs + c.env) * 1024;
-        i2* gcnt = (i2*)p.team_cnt + ((size_t)par * p.n_envs + c.env) * 8;
-        const float X = q.x * kTileScale, Y = q.y * kTileScale;
-        if (efv) {
-            const float hs = p.head_scale;
-            const int hx = (int)__builtin_rintf(ux * hs), hy = (int)__builtin_rintf(uy * hs);
-            store_dev(gtile + c.member * P + col_rank, f4{X, Y, __builtin_bit_cast(float, hx), __builtin_bit_cast(float, hy)});
-        }
-        if (threadIdx.x == 0) store_dev(gcnt + c.member, i2{n_member, n_nan_member});
-        if (row) sm.rowpos[row_rank] = make_float2(X, Y);
-        team_round(p, c);
-        // ---- 3. gather the team's tile ----
-        int n_cols = 0, n_nan = 0;
-        {
-            i4 cv[4] = {};                       // (count, NaN headings) of two members per vector; loads and their wait in ONE statement
-            if constexpr (K == 8)
-                asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
-                             "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
-                             : "=&v"(cv[0]), "=&v"(cv[1]), "=&v"(cv[2]), "=&v"(cv[3]) : "v"(gcnt) : "memory");
-            else if constexpr (K == 4)
-                asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
-                             : "=&v"(cv[0]), "=&v"(cv[1]) : "v"(gcnt) : "memory");
-            else
-                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(cv[0]) : "v"(gcnt) : "memory");
-            const int t = threadIdx.x, j = t / P, e = t - j * P;     // thread -> (member j, entry e of its segment)
-            int off = 0, cnt_j = 0;
-#pragma unroll
-            for (int h = 0; h < K / 2; ++h) {
-                const int c0 = cv[h].x, c1 = cv[h].z;
-                off += (2 * h < j ? c0 : 0) + (2 * h + 1 < j ? c1 : 0);
-                cnt_j = 2 * h == j ? c0 : (2 * h + 1 == j ? c1 : cnt_j);
-                n_cols += c0 + c1;
-                n_nan += cv[h].y + cv[h].w;
-            }
-            if (e < cnt_j) {
-                f4 v;
-                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(gtile + j * P + e) : "memory");
-                sm.tile[off + e] = v;
-            }
-            if (t < kPad) sm.tile[n_cols + t] = f4{__builtin_inff(), 0.0f, 0.0f, 0.0f};
-        }
-        __syncthreads();
-        EVAC_T(c, 2);   // compaction + exchange
-        // ---- 4. the member's rows against the tile: two rows per lane and pass, 1/16 of the columns per wave ----
+        c.tile_valid = false;     // consumed: the step's reduction brings the next one
+        EVAC_T(c, 2);   // exchange (only when the tile was not delivered by the previous step)
+        const int n_cols = c.n_cols;
+        // ---- the member's rows against the tile: two ped waves (two rows per lane) per pass, 1/16 of the columns per wave ----
         if constexpr (!(EVAC_ABLATE & 1)) {
-            if (n_rows > 0) {
-                const int groups = (n_cols + 3) >> 2;
-                const int per = (groups + WPE - 1) / WPE;
-                const int jbeg = __builtin_amdgcn_readfirstlane(c.wave * per * 4);
-                const int jend = __builtin_amdgcn_readfirstlane(min((c.wave + 1) * per, groups) * 4);
-                const f4* __restrict__ tile = sm.tile;
-                for (int r0 = 0; r0 < n_rows; r0 += 2 * kWave) {
-                    const float2 ra = sm.rowpos[r0 + c.lane], rb = sm.rowpos[min(r0 + kWave + c.lane, P - 1)];
-                    int ax0 = 0, ay0 = 0, ax1 = 0, ay1 = 0;
-                    const bool two = r0 + kWave < n_rows;              // uniform: a second row per lane in this pass
-                    if (two) {
-                        for (int j = jbeg; j < jend; j += 4) {
-                            f4 t[4];
+            const int groups = (n_cols + 3) >> 2;
+            const int per = (groups + WPE - 1) / WPE;
+            const int jbeg = __builtin_amdgcn_readfirstlane(c.wave * per * 4);
+            const int jend = __builtin_amdgcn_readfirstlane(min((c.wave + 1) * per, groups) * 4);
+            const f4* __restrict__ tile = sm.tile;
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+            for (int pw = 0; pw < PW; pw += 2) {
+                const int na = sm.rows[pw], nb = sm.rows[pw + 1];
+                if (na + nb == 0) continue;                                    // uniform
+                const float2 ra = sm.rowpos[pw][c.lane], rb = sm.rowpos[pw + 1][c.lane];   // slots beyond the counts hold stale rows: computed, never read
+                int ax0 = 0, ay0 = 0, ax1 = 0, ay1 = 0;
+                if (na != 0 && nb != 0) {
+                    for (int j = jbeg; j < jend; j += 4) {
+                        f4 t[4];
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                pair_accumulate_int(ra.x, ra.y, t[k], kRPed2Big, ax0, ay0);
-                                pair_accumulate_int(rb.x, rb.y, t[k], kRPed2Big, ax1, ay1);
-                            }
-                        }
-                    } else {
-                        for (int j = jbeg; j < jend; j += 4) {
-                            f4 t[4];
+                        for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) pair_accumulate_int(ra.x, ra.y, t[k], kRPed2Big, ax0, ay0);
+                        for (int k = 0; k < 4; ++k) {
+                            pair_accumulate_int(ra.x, ra.y, t[k], kRPed2Big, ax0, ay0);
+                            pair_accumulate_int(rb.x, rb.y, t[k], kRPed2Big, ax1, ay1);
                         }
                     }
-                    sm.part[c.wave][r0 + c.lane] = i2{ax0, ay0};
-                    if (two) sm.part[c.wave][r0 + kWave + c.lane] = i2{ax1, ay1};
+                } else {
+                    const float2 rr = na != 0 ? ra : rb;
+                    int ax = 0, ay = 0;
+                    for (int j = jbeg; j < jend; j += 4) {
+                        f4 t[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) pair_accumulate_int(rr.x, rr.y, t[k], kRPed2Big, ax, ay);
+                    }
+                    ax0 = ax1 = ax;
+                    ay0 = ay1 = ay;
                 }
+                sm.part[c.wave][pw][c.lane] = i2{ax0, ay0};
+                sm.part[c.wave][pw + 1][c.lane] = i2{ax1, ay1};
             }
         }
         __syncthreads();
-        // ---- 5. the 16 partial sums of a row (integers: any order) ----
+        // ---- the 16 partial sums of a row (integers: any order) ----
         int tx = 0, ty = 0;
         if (row) {
 #pragma unroll
             for (int w2 = 0; w2 < WPE; ++w2) {
-                const i2 v = sm.part[w2][row_rank];
+                const i2 v = sm.part[w2][c.wave][c.row_slot];
                 tx += v.x;
                 ty += v.y;
             }
         }
         sx = row ? (float)tx : 0.0f;
         sy = row ? (float)ty : 0.0f;
-        if (n_nan != 0) sx = sy = __builtin_nanf("");
+        if (c.n_nan != 0) sx = sy = __builtin_nanf("");
     }
 };
 

@@ -18,7 +18,10 @@
  * Environment switches (diagnostics only): EVAC_SUBWAVE=0 read by evac_create() selects the one-wave-per-env
  * kernels also for N <= 32 (default: 4 envs per wave for N <= 16, 2 for N <= 32; same results, see
  * tests/test_gpu_parity.py::test_subwave_kernels_match_one_wave_per_env); EVAC_CELLS=1 / 0 forces the cell-list
- * kernels on (for every N > 64) / off (default: N > 512; the all-pairs kernels give the same neighbour sets); the Python host honours
+ * kernels on (for every N > 64) / off (default: N > 512; the all-pairs kernels give the same neighbour sets); EVAC_CU_WIDE=1 / 0
+ * forces / forbids the CU-wide rollout workgroups of one-wave envs (default: batches of >= 16 envs per CU); EVAC_TEAM=0 / 2 / 4 / 8
+ * forbids / forces the team rollout kernels of rooms of more than 512 pedestrians (default: as many CUs per env as the batch leaves
+ * free; not under EVAC_CELLS); all of them give bit-identical results.  The Python host honours EVAC_WORKSPACE=0 (no workspace) and
  * EVAC_LIB=<path> to load a profiling build of this library instead of evacuation_amd/libevac.so.
  *
  * Device layouts (row-major, E = num_envs, N = n_ped)

@@ -26,11 +26,13 @@ for phase in range(4):
     env.rollout(T); torch.cuda.synchronize()
     lib.evac_debug_stamps(buf)
     waves = E * (1 if n <= 64 else 2 if n <= 128 else 4 if n <= 256 else 8 if n <= 512 else 16)
-    if "CUs/env" in env.kernel_variant(): waves *= int(env.kernel_variant().split("<")[1].split()[0])   # team kernels: K workgroups per env
+    if "CUs/env" in env.kernel_variant(): waves = E * 16                                                 # team kernels: only the 16 ped waves of an env are stamped
     tot = sum(buf[:8])
     print(f"-- steps {phase*600+500}..{phase*600+600}: {tot / waves / T:.0f} cycles per wave-step; shader clock {buf[8] / max(1, buf[9]) * 100:.0f} MHz, "
           f"{buf[9] / waves / T * 10:.0f} ns per wave-step (s_memrealtime); wave lifetime per step: fastest {((1 << 64) - 1 - buf[11]) / T * 10:.0f} ns, slowest {buf[10] / T * 10:.0f} ns")
     for k in range(8):
         print(f"   {names[k]:34s} {buf[k] / waves / T:8.1f} cycles/wave-step  {100.0 * buf[k] / tot:5.1f} %")
+    if any(buf[12:16]):   # sub-phases a family stamps on its own (they are NOT part of the total: their time is taken out of the phase they sit in)
+        print("   sub-phases 12..15: " + "  ".join(f"{buf[k] / waves / T:.0f}" for k in range(12, 16)))
 PY
 fi
