@@ -330,6 +330,13 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
 
+    def drain():
+        """Poll the stream until the issued work is done, so that the synchronize() that closes a timed block returns at
+        once: a blocking wait adds the host's sleep / wake-up latency (~10 us) to a block that is itself ~60 us."""
+        st = torch.cuda.current_stream()
+        while not st.query():
+            pass
+
     # Exercise the collective once before anything is timed.  If RCCL cannot gather on this node the
     # benchmark degrades to independent shards (and says so) instead of dying without a number.
     gather_note = None
@@ -359,13 +366,12 @@ def main(argv=None):
     launches = 0
     for b in range(n_blocks):
         phases.append((W + b * K) % EPISODE)                  # RandomAgent episodes end by truncation at 2000
-        events = []
         barrier()
         t0 = time.perf_counter()
-        launches = run(K, events)                             # EXACTLY K steps
+        launches = run(K)                                     # EXACTLY K steps (no event markers inside the timed region)
+        drain()
         barrier()
         wall.append(time.perf_counter() - t0)
-        block_events.append(events)
     if world > 1:
         tt = torch.tensor(wall, dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)             # per block: the slowest rank
@@ -378,11 +384,19 @@ def main(argv=None):
     # (elapsed / launches: kernel + the ~1.5 us launch boundary) -- this is the figure a
     # `rocprofv3 --kernel-trace --stats` of this command reproduces; the per-launch pairs of the timed blocks give
     # the dense (all N moving) launch, corrected by the mean difference between the two measurements.
+    def restore():
+        barrier()
+        for dst, src in zip((loc.ped, loc.status, loc.agent, loc.clock, loc.acc), state0):   # same phases as the first sweep
+            dst.copy_(src)
+        barrier()
+    restore()
+    for b in range(per_sweep):                                # replay 1: an event pair around every launch
+        events = []
+        run(K, events)
+        block_events.append(events)
+    barrier()
     per_launch = [a.elapsed_time(b) * 1e-3 for evs in block_events for a, b, t in evs if t == inner]
-    barrier()
-    for dst, src in zip((loc.ped, loc.status, loc.agent, loc.clock, loc.acc), state0):   # same phases as the first sweep
-        dst.copy_(src)
-    barrier()
+    restore()                                                 # replay 2: back to back between two events
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     back_to_back = 0
     e0.record()
@@ -394,7 +408,7 @@ def main(argv=None):
     kernel_s = e0.elapsed_time(e1) * 1e-3 / max(1, back_to_back) if not tail_launches else sum(per_launch) / max(1, len(per_launch))
     event_overhead_s = max(0.0, sum(per_launch) / max(1, len(per_launch)) - kernel_s) if not tail_launches else 0.0
     dense_b = min(range(min(per_sweep, n_blocks)), key=lambda k: phases[k])
-    dense_l = [a.elapsed_time(b) * 1e-3 for k in range(dense_b, n_blocks, per_sweep) for a, b, t in block_events[k] if t == inner]
+    dense_l = [a.elapsed_time(b) * 1e-3 for a, b, t in block_events[dense_b] if t == inner]
     kernel_dense_s = (sorted(dense_l)[len(dense_l) // 2] - event_overhead_s) if dense_l else kernel_s
     full = per_launch
     bytes_per_env_step = loc.algorithmic_bytes_per_env_step

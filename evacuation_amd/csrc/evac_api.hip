@@ -238,12 +238,20 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         const int64_t cap = (int64_t)0x7fffffff / cfg->number_of_pedestrians - 16;
         p.head_scale = (float)(cap < 0x7ffff0 ? cap : (int64_t)0x7ffff0);     // exact in f32 (< 2^24)
     }
-    {   // CU-wide rollout workgroups pay off once every CU gets its 16 one-wave envs (EVAC_CU_WIDE=1 / 0 forces, for tests)
+    {   // CU-wide rollout workgroups pay off once every CU gets its 16 one-wave envs, and as long as the launch is a few
+        // rounds deep: a 16-wave workgroup needs a whole CU, so in a long launch every CU idles while the last waves of its
+        // workgroup finish (524 288 envs: 1.44e9 against 1.62e9 env-steps/s with 4-wave workgroups; 8 192 envs: 1.75e9
+        // against 1.59e9).  EVAC_CU_WIDE=1 / 0 forces, for tests.
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
         const char* cw = std::getenv("EVAC_CU_WIDE");
         const bool one_wave = h->sub_lanes == 0 && cfg->number_of_pedestrians <= evac::kWave;
-        h->cu_wide = one_wave && (cw && cw[0] == '1' ? true : (cw && cw[0] == '0' ? false : num_envs >= 16 * cus));
+        h->cu_wide = one_wave && (cw && cw[0] == '1' ? true : (cw && cw[0] == '0' ? false : (num_envs >= 16 * cus && num_envs <= 64 * cus)));
+        // priority rotation (rollout_body) evens out the waves of a SIMD in launches of one or two rounds; deeper launches
+        // even out by themselves and run ~2 % faster without it
+        const int wpe = waves_per_env(cfg->number_of_pedestrians);
+        const long long waves = h->sub_lanes ? ((long long)num_envs * h->sub_lanes + 63) / 64 : (long long)num_envs * wpe;
+        h->p.fair = waves <= 2ll * 16 * cus ? 1 : 0;
         h->sched = nullptr;
         h->sched_age = -1;
         // teams: as many CUs per env as the batch leaves free -- all members must be resident together (one 1024-thread
@@ -445,8 +453,9 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
 #undef EVAC_LAUNCH_TEAM
     } else if (h->cu_wide) {
         // one-wave envs, batch >= 16 envs per CU: CU-wide workgroups, envs dealt to the SIMDs by load when a schedule scratch
-        // is bound (rebuilt every kScheduleEvery env steps: the loads drift slowly)
-        constexpr int kScheduleEvery = 50;
+        // is bound (rebuilt every 50..200 env steps: the loads drift slowly)
+        // (short launches re-sort less often: the sort is a launch of its own, ~4 us next to a 20-step launch of ~55 us)
+        const int kScheduleEvery = n_steps >= 50 ? 50 : (8 * n_steps < 200 ? (8 * n_steps > 50 ? 8 * n_steps : 50) : 200);
         using FW = evac::Wave<1, 1024>;
         hipStream_t s_ = (hipStream_t)stream;
         const int E = h->p.n_envs;

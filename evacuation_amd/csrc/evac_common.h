@@ -87,6 +87,7 @@ struct Params {
     int32_t grav_pow_int;                           // alpha+2 if it is an integer in [1,63], else 0
     int32_t small_noise;                            // sin/cos regime: 2 short Taylor, 1 long Taylor, 0 ocml sincosf (noise_sincos)
     uint32_t seed_lo, seed_hi, env_id_offset;
+    int32_t fair;                                   // rollouts rotate the wave priorities (launches of one or two rounds: evac_create)
     // cell list (Cells family): cell = (int)((x + cell_ox) * cell_inv_hx) clamped to [0, 15], same in y;
     // head_scale = min(2^23 - 1, (2^31 - 1) / N): unit headings are summed as integers (exact, order-independent)
     float cell_ox, cell_oy, cell_inv_hx, cell_inv_hy, head_scale;

@@ -171,6 +171,7 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     pred[2] = ballot(new_st == kEscaped);
     pred[3] = ballot((unsigned)(new_st - kViscek) < 3u);      // moves at the next step (only the multi-wave all-pairs family uses it)
     pred[4] = ballot(new_st == kFollower);
+    pred[5] = ballot(needs_row(p, new_st));                   // its row is needed at the next step (multi-wave all-pairs family)
     }   // work
     if constexpr (GRAV) F::exit_publish(c, exit_lane, gx, gy);
     if constexpr (F::kPipelined) F::stage_next(p, c, q, work);   // team kernels: the next step's tile entry travels with this reduction
@@ -417,7 +418,9 @@ __device__ __forceinline__ void rollout_body(
     const unsigned long long ck0_ = w.stamp.last;
 #endif
     for (int t = 0; t < n_steps; ++t) {
-        if constexpr (kRotate) set_wave_priority(t + prio_slot);
+        if constexpr (kRotate) {
+            if (p.fair) set_wave_priority(t + prio_slot);
+        }
         if constexpr (EVAC_PRIO && F::kPace) {
             int* mine = &sm.progress[(w.slot & 3) * 4];
             if (w.lane == 0) mine[w.slot >> 2] = t;

@@ -63,6 +63,7 @@ struct Wave {
         i4 redi[kEnvsPerBlock][WPE];               // per-wave partial counts, packed in pairs
         int cols[kEnvsPerBlock][WPE];              // moving pedestrians per wave (tile compaction)
         float exitg[kEnvsPerBlock][2];            // gravity exit term from the lane that computed it (WPE > 1)
+        int poison[2][kEnvsPerBlock];             // WPE > 1: a moving pedestrian has a NaN heading (by step parity)
         // rollout outputs of up to kStageSteps steps, flushed with ONE 64-lane store (GRAV kernels)
         alignas(16) float stage[kEnvsPerBlock][kStageSteps][12];   // rows written as two 16-byte vectors + 1 word
         alignas(16) int progress[kPace ? 16 : 4];                  // kPace: step counter of every wave, [SIMD][wave of the SIMD]
@@ -75,7 +76,7 @@ struct Wave {
         bool owner;
         // WPE > 1: which tile this step fills; and the moving-pedestrian counts of the NEXT step (how many in the env,
         // how many in the waves before this one), which the step's own reduction delivers for free
-        int par = 0, next_cols = 0, next_base = 0;
+        int par = 0, next_cols = 0, next_base = 0, next_rows = 0, next_rbase = 0;   // (rows: the pedestrians whose row is needed)
         bool have_next = false;
 #ifdef EVAC_STAMP
         StampState stamp;
@@ -107,7 +108,12 @@ struct Wave {
         }
     }
 
-    static __device__ __forceinline__ void init(Ctx&) {}
+    static __device__ __forceinline__ void init(Ctx& c) {
+        if constexpr (WPE > 1) {
+            if (c.wave_in_env == 0 && c.lane < 2) c.sm.poison[c.lane][c.slot] = 0;
+            __syncthreads();
+        }
+    }
     // the statuses changed outside step_env (autoreset): the counts carried over from the last reduction are void
     static __device__ __forceinline__ void invalidate(Ctx& c) { c.have_next = false; }
 
@@ -150,6 +156,10 @@ struct Wave {
                 const int before = c.wave_in_env == 0 ? 0 : __builtin_amdgcn_readlane(ri.y, c.wave_in_env - 1);
                 c.next_base = before >> 16;
                 c.next_cols = __builtin_amdgcn_readlane(ri.y, WPE - 1) >> 16;
+                // count 5 is "needs its row at the next step": the offsets of the next step's ROW compaction, likewise
+                const int rbefore = c.wave_in_env == 0 ? 0 : __builtin_amdgcn_readlane(ri.z, c.wave_in_env - 1);
+                c.next_rbase = rbefore >> 16;
+                c.next_rows = __builtin_amdgcn_readlane(ri.z, WPE - 1) >> 16;
                 c.have_next = true;
             }
             const int a = __builtin_amdgcn_readlane(ri.x, WPE - 1), b = __builtin_amdgcn_readlane(ri.y, WPE - 1);
@@ -200,17 +210,24 @@ struct Wave {
         // weight 0 (X = +inf) and heading 0.  Every lane writes exactly one entry.  Under a
         // RandomAgent most pedestrians have escaped by mid-episode, so the all-pairs loop shrinks from N to
         // n_efv iterations.
-        int n_cols;
+        int n_cols, n_rows = 0, row_rank = 0;
         {
             const unsigned long long m = ballot(efv);
             int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
             n_cols = __popcll(m);
             if constexpr (WPE > 1) {
+                // the ROWS are compacted too (`fv`: this pedestrian's row is needed, step_env: needs_row): late in an episode
+                // most moving pedestrians are followers whose rows are not evaluated, and a lane then carries 1 row instead of kRows
+                const unsigned long long mr = ballot(fv);
+                row_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mr >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mr, 0u));
+                n_rows = __popcll(mr);
                 if (c.have_next) {          // uniform: delivered by the previous step's reduction
                     n_cols = c.next_cols;
                     before += c.next_base;
+                    n_rows = c.next_rows;
+                    row_rank += c.next_rbase;
                 } else {                    // first step of a launch, or right after an autoreset
-                    if (c.lane == 0) sm.cols[c.slot][c.wave_in_env] = n_cols;
+                    if (c.lane == 0) sm.cols[c.slot][c.wave_in_env] = n_cols | (n_rows << 16);
                     __syncthreads();
                     int tot = 0, base = 0;
 #pragma unroll
@@ -219,16 +236,28 @@ struct Wave {
                         base += (w2 < c.wave_in_env) ? k : 0;
                         tot += k;
                     }
-                    n_cols = tot;
-                    before += base;                                             // moving pedestrians before this one
+                    n_cols = tot & 0xffff;
+                    before += base & 0xffff;                                    // moving pedestrians before this one
+                    n_rows = tot >> 16;
+                    row_rank += base >> 16;
                 }
             }
             const int tid = c.wave_in_env * kWave + c.lane;
             const int idx = efv ? before : n_cols + (tid - before);             // a bijection onto [0, WPE*64)
             sm.tile[par][c.slot][idx] = f4{efv ? q.x * kTileScale : __builtin_inff(), q.y * kTileScale, efv ? ux : 0.0f, efv ? uy : 0.0f};
         }
-        if constexpr (WPE > 1) sm.rowpos[par][c.slot][c.wave_in_env * kWave + c.lane] = make_float2(q.x * kTileScale, q.y * kTileScale);
+        if constexpr (WPE > 1) {
+            if (fv) sm.rowpos[par][c.slot][row_rank] = make_float2(q.x * kTileScale, q.y * kTileScale);
+            // The reference's NaN poisoning (a NaN heading makes every FOLLOWER / VISCEK row NaN, area.py:118-119) reaches the
+            // evaluated rows through w * NaN; the followers whose rows are skipped get it through this flag.
+            if (ballot(efv && (ux != ux || uy != uy)) != 0ull && c.lane == 0) sm.poison[par][c.slot] = 1;
+        }
         sync();   // tile complete
+        bool poisoned = false;
+        if constexpr (WPE > 1) {
+            poisoned = sm.poison[par][c.slot] != 0;
+            if (c.wave_in_env == 0 && c.lane == 0) sm.poison[par ^ 1][c.slot] = 0;   // the other parity's flag: last read before this barrier
+        }
         EVAC_T(c, 2);   // tile write
         sx = 0.0f;
         sy = 0.0f;
@@ -264,54 +293,68 @@ struct Wave {
                 }
             }
         } else {
-            // this wave: the rows of its group of kRows waves (kRows pedestrians per lane), column share `share`
+            // this wave: up to kRows row slices (64 compacted rows each) of its group of kRows waves, column share `share`
             const int share = c.wave_in_env % kRows, gbase = (c.wave_in_env - share) * kWave + c.lane;
-            float X[kRows], Y[kRows], ax[kRows], ay[kRows];
-#pragma unroll
-            for (int r = 0; r < kRows; ++r) {
-                const float2 rp = sm.rowpos[par][c.slot][gbase + r * kWave];
-                X[r] = rp.x; Y[r] = rp.y;
-                ax[r] = 0.0f; ay[r] = 0.0f;
-            }
+            const int slices = __builtin_amdgcn_readfirstlane(min(max((n_rows - (c.wave_in_env - share) * kWave + kWave - 1) / kWave, 0), kRows));
             const int groups = (n_cols + 3) >> 2;                                  // peers in groups of 4 (padding weighs 0)
             const int per = (groups + kRows - 1) / kRows;
-            int j = __builtin_amdgcn_readfirstlane(share * per * 4);
+            const int jbeg = __builtin_amdgcn_readfirstlane(share * per * 4);
             const int jend = __builtin_amdgcn_readfirstlane(min((share + 1) * per, groups) * 4);
             if constexpr (!(EVAC_ABLATE & 1)) {
-                constexpr int B = kRows == 2 ? 8 : 4;                              // peers per LDS round trip (register budget)
-                for (; j + B <= jend; j += B) {
-                    f4 t[B];
+                // R row slices per lane (slots beyond n_rows hold stale positions: computed, never read)
+                auto sweep = [&](auto r_tag) {
+                    constexpr int R = decltype(r_tag)::value;
+                    float X[R], Y[R], ax[R], ay[R];
 #pragma unroll
-                    for (int k = 0; k < B; ++k) t[k] = tile[j + k];
-#pragma unroll
-                    for (int k = 0; k < B; ++k) {
-#pragma unroll
-                        for (int r = 0; r < kRows; ++r) pair_accumulate(X[r], Y[r], t[k], r2b, ax[r], ay[r]);
+                    for (int r = 0; r < R; ++r) {
+                        const float2 rp = sm.rowpos[par][c.slot][gbase + r * kWave];
+                        X[r] = rp.x; Y[r] = rp.y;
+                        ax[r] = 0.0f; ay[r] = 0.0f;
                     }
-                }
-                if constexpr (B == 8) {
-                    if (j < jend) {
-                        f4 t[4];
+                    constexpr int B = R <= 2 ? 8 : 4;                              // peers per LDS round trip (register budget)
+                    int j = jbeg;
+                    for (; j + B <= jend; j += B) {
+                        f4 t[B];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+                        for (int k = 0; k < B; ++k) t[k] = tile[j + k];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
+                        for (int k = 0; k < B; ++k) {
 #pragma unroll
-                            for (int r = 0; r < kRows; ++r) pair_accumulate(X[r], Y[r], t[k], r2b, ax[r], ay[r]);
+                            for (int r = 0; r < R; ++r) pair_accumulate(X[r], Y[r], t[k], r2b, ax[r], ay[r]);
                         }
                     }
+                    if constexpr (B == 8) {
+                        if (j < jend) {
+                            f4 t[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                                for (int r = 0; r < R; ++r) pair_accumulate(X[r], Y[r], t[k], r2b, ax[r], ay[r]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) sm.part[share][c.slot][gbase + r * kWave] = make_float2(ax[r], ay[r]);
+                };
+                if (slices == 1) sweep(std::integral_constant<int, 1>{});
+                else if (slices == 2) sweep(std::integral_constant<int, 2>{});
+                else if constexpr (kRows == 4) {
+                    if (slices == 3) sweep(std::integral_constant<int, 3>{});
+                    else if (slices == 4) sweep(std::integral_constant<int, 4>{});
                 }
             }
-#pragma unroll
-            for (int r = 0; r < kRows; ++r) sm.part[share][c.slot][gbase + r * kWave] = make_float2(ax[r], ay[r]);
             __syncthreads();
-            const int tid = c.wave_in_env * kWave + c.lane;
+            if (fv) {
 #pragma unroll
-            for (int r = 0; r < kRows; ++r) {      // fixed order: deterministic
-                const float2 pr = sm.part[r][c.slot][tid];
-                sx += pr.x;
-                sy += pr.y;
+                for (int r = 0; r < kRows; ++r) {      // fixed order: deterministic
+                    const float2 pr = sm.part[r][c.slot][row_rank];
+                    sx += pr.x;
+                    sy += pr.y;
+                }
             }
+            if (poisoned) sx = sy = __builtin_nanf("");
         }
     }
 };

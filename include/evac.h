@@ -182,7 +182,7 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions_or_null,
  * rpo_agent.py:123-126).  `workspace`: evac_workspace_bytes(h) bytes on the device, 256-byte aligned, ZERO-INITIALISED by the
  * caller, alive and used on one stream at a time like the state buffers.  It holds
  *   - the rollout schedule of large batches of one-wave envs (>= 16 envs per CU): moving[E] | perm[E] int32 -- every launch
- *     leaves the pedestrians still moving of each env in moving[] and, every 50 env steps, the envs are re-dealt to the
+ *     leaves the pedestrians still moving of each env in moving[] and, every 50 to 200 env steps, the envs are re-dealt to the
  *     SIMDs by that load;
  *   - the exchange areas of the team kernels (513..1024 pedestrians, few envs: 2 / 4 / 8 workgroups per env).
  * Performance devices only: results are bit-identical with and without the workspace.  NULL unbinds.
