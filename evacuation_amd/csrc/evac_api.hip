@@ -252,6 +252,13 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         const int wpe = waves_per_env(cfg->number_of_pedestrians);
         const long long waves = h->sub_lanes ? ((long long)num_envs * h->sub_lanes + 63) / 64 : (long long)num_envs * wpe;
         h->p.fair = waves <= 2ll * 16 * cus ? 1 : 0;
+        // Packed rollouts (evac_packed.h) are opt-in (EVAC_PACK=1): they halve the instructions of a late-episode env but also
+        // the waves in flight, and a launch of ONE round (4096 envs) is bound by the latency of a wave's step, not by issue
+        // slots -- 1.65e9 against 1.63e9 env-steps/s with 100-step launches, 1.01e9 against 1.07e9 with 20-step launches (the
+        // pairing costs two barriers per launch); launches many rounds deep gain: 65 536 envs 2.08e9 against 1.87e9.  Whether
+        // an env is packed changes the rounding of its summed observations, so the switch is global, not per batch size.
+        const char* pk = std::getenv("EVAC_PACK");
+        h->p.pack = (one_wave && cfg->positions == EVAC_POS_GRAV && pk && pk[0] == '1') ? 1 : 0;
         h->sched = nullptr;
         h->sched_age = -1;
         // teams: as many CUs per env as the batch leaves free -- all members must be resident together (one 1024-thread
@@ -319,7 +326,7 @@ int evac_bind_state(evac_handle_t h, float* ped, uint8_t* status, float* agent, 
 
 namespace {
 struct WorkspaceLayout {
-    size_t sched, team_err, team_ctr, team_cnt, team_rec, team_tile, total;
+    size_t sched, stats, team_err, team_ctr, team_cnt, team_rec, team_tile, total;
 };
 WorkspaceLayout workspace_layout(const evac_handle* h) {
     const size_t E = (size_t)h->p.n_envs;
@@ -327,6 +334,7 @@ WorkspaceLayout workspace_layout(const evac_handle* h) {
     WorkspaceLayout w{};
     size_t o = 0;
     w.sched = o; o = up(o + 2 * E * sizeof(int32_t));
+    w.stats = o; o = up(o + 64);
     if (h->team_k) {
         w.team_err = o; o = up(o + 128);
         w.team_ctr = o; o = up(o + E * 128);
@@ -346,12 +354,14 @@ int evac_bind_workspace(evac_handle_t h, void* workspace, int64_t bytes) {
     h->sched = nullptr;
     h->sched_age = -1;
     h->team_bound = false;
+    h->p.pack_stats = nullptr;
     if (!workspace) return EVAC_OK;
     const WorkspaceLayout w = workspace_layout(h);
     if (bytes < (int64_t)w.total) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_bind_workspace: workspace smaller than evac_workspace_bytes()");
     if ((uintptr_t)workspace & 255u) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_bind_workspace: workspace must be 256-byte aligned");
     char* base = (char*)workspace;
     h->sched = (int32_t*)(base + w.sched);
+    h->p.pack_stats = (unsigned*)(base + w.stats);
     if (h->team_k) {
         h->p.team_err = (unsigned*)(base + w.team_err);
         h->p.team_ctr = (unsigned*)(base + w.team_ctr);

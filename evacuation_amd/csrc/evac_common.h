@@ -87,6 +87,7 @@ struct Params {
     int32_t grav_pow_int;                           // alpha+2 if it is an integer in [1,63], else 0
     int32_t small_noise;                            // sin/cos regime: 2 short Taylor, 1 long Taylor, 0 ocml sincosf (noise_sincos)
     uint32_t seed_lo, seed_hi, env_id_offset;
+    int32_t pack;                                   // rollouts pack two late-episode one-wave envs into a wave (evac_packed.h)
     int32_t fair;                                   // rollouts rotate the wave priorities (launches of one or two rounds: evac_create)
     // cell list (Cells family): cell = (int)((x + cell_ox) * cell_inv_hx) clamped to [0, 15], same in y;
     // head_scale = min(2^23 - 1, (2^31 - 1) / N): unit headings are summed as integers (exact, order-independent)
@@ -101,6 +102,7 @@ struct Params {
     // cnt [2][E][8] x 8 B, rec [2][E][32] x 16 B, ctr [E][32] x 4 B (zeroed by the host before every launch), err [32] x 4 B
     void *team_tile, *team_cnt, *team_rec;
     unsigned *team_ctr, *team_err;
+    unsigned* pack_stats;                           // workspace: [0] env-launches that ran packed so far (cumulative), or NULL
 };
 
 // ------------------------------------------------------------------------------------------------

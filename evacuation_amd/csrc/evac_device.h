@@ -190,7 +190,7 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
         out.gy = s.f2;
     }
     EVAC_T(c, 5);   // classify + reductions
-    out.n_escaped = s.i[2];
+    out.n_escaped = s.i[2] + F::escaped_elsewhere(c);
     out.n_follower = s.i[4];
     out.n_exiting = out.n_viscek = 0;   // filled by finish_counts() when the episode ends
 
@@ -212,12 +212,55 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     }
     const float intrinsic = 0.0f - s.f0 * p.inv_n;                          // reward.py:19-21
     out.reward = r_agent + r_ped + p.intrinsic_coef * intrinsic;           // env.py:158
-    out.terminated = term_agent || (s.i[2] == p.n_ped);                     // area.py:175-178, env.py:171
+    out.terminated = term_agent || (s.i[2] + F::escaped_elsewhere(c) == p.n_ped);   // area.py:175-178, env.py:171
     e.acc_ret += out.reward;                                                // env.py:168-170
     e.acc_intr += intrinsic;
     e.acc_stat += r_agent + r_ped;
     EVAC_T(c, 6);   // rewards, flags
 }
+
+// ------------------------------------------------------------------------------------------------
+// Even progress of the waves that share a SIMD.  With equal priorities the SIMD's issue arbiter serves its OLDEST wave
+// first: of the four one-wave envs of a SIMD the first runs at the speed of a lone wave and leaves early, the last ends
+// the launch alone on a mostly idle SIMD (wave lifetimes of one launch spread 1 : 4).  s_setprio outranks age, so:
+//   * kernels whose SIMD-mates sit in other workgroups rotate the priorities by the step counter, offset by the wave's
+//     slot in its SIMD (HW_ID): over four steps every wave has held every priority once (C2: 3.02 -> 2.74 us per step);
+//     the workgroup-per-env kernels use the env's load as its priority instead (see rollout_body);
+//   * the CU-wide workgroup (Wave<1, 1024>) knows its SIMD-mates (waves w, w+4, w+8, w+12): every wave publishes its step
+//     counter in LDS and takes as priority the number of mates that are ahead of it.
+// A hint only: results do not depend on it.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void set_wave_priority(int k) {   // k in 0..3, wave-uniform
+    switch (k & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+__device__ __forceinline__ int simd_wave_slot() {   // slot of this wave among the waves of its SIMD (HW_ID bits 3:0)
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    return (int)(hw & 3u);
+}
+#ifndef EVAC_PRIO
+#define EVAC_PRIO 1     // 0: leave the arbitration to wave age (A/B builds)
+#endif
+
+// Pace keeping of the CU-wide workgroups: wave `slot` publishes its step counter and takes as priority the number of its
+// SIMD-mates (waves slot % 4 + 4 k) that are ahead of it.
+template <class Smem>
+__device__ __forceinline__ void pace_step(Smem& sm, int slot, int lane, int t) {
+    int* mine = &sm.progress[(slot & 3) * 4];
+    if (lane == 0) mine[slot >> 2] = t;
+    const i4 pr = *(const i4*)mine;     // the mates' counters may be a step old: good enough
+    const int ahead = (pr.x > t ? 1 : 0) + (pr.y > t ? 1 : 0) + (pr.z > t ? 1 : 0) + (pr.w > t ? 1 : 0);
+    set_wave_priority(__builtin_amdgcn_readfirstlane(ahead));
+}
+
+}  // namespace evac
+#include "evac_packed.h"
+namespace evac {
 
 // ------------------------------------------------------------------------------------------------
 // Kernels of the Wave / Cells families.  __launch_bounds__(block, 4): at least 4 waves per SIMD, i.e. at most
@@ -342,34 +385,6 @@ EVAC_STEP_KERNEL(k_step_raw, false)
 EVAC_STEP_KERNEL(k_step_norm, true)
 #undef EVAC_STEP_KERNEL
 
-// ------------------------------------------------------------------------------------------------
-// Even progress of the waves that share a SIMD.  With equal priorities the SIMD's issue arbiter serves its OLDEST wave
-// first: of the four one-wave envs of a SIMD the first runs at the speed of a lone wave and leaves early, the last ends
-// the launch alone on a mostly idle SIMD (wave lifetimes of one launch spread 1 : 4).  s_setprio outranks age, so:
-//   * kernels whose SIMD-mates sit in other workgroups rotate the priorities by the step counter, offset by the wave's
-//     slot in its SIMD (HW_ID): over four steps every wave has held every priority once (C2: 3.02 -> 2.74 us per step);
-//     the workgroup-per-env kernels use the env's load as its priority instead (see rollout_body);
-//   * the CU-wide workgroup (Wave<1, 1024>) knows its SIMD-mates (waves w, w+4, w+8, w+12): every wave publishes its step
-//     counter in LDS and takes as priority the number of mates that are ahead of it.
-// A hint only: results do not depend on it.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void set_wave_priority(int k) {   // k in 0..3, wave-uniform
-    switch (k & 3) {
-        case 0: __builtin_amdgcn_s_setprio(0); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
-    }
-}
-__device__ __forceinline__ int simd_wave_slot() {   // slot of this wave among the waves of its SIMD (HW_ID bits 3:0)
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    return (int)(hw & 3u);
-}
-#ifndef EVAC_PRIO
-#define EVAC_PRIO 1     // 0: leave the arbitration to wave age (A/B builds)
-#endif
-
 // T steps per launch, state in registers (rpo_agent.py:180-203 rollout loop, RandomAgent or given actions).
 // Output: ONE packed f32 slab [T][E][D+3] = [obs(D) | reward | terminated | truncated] -- a single message
 // for the all-gather and a single coalesced store stream for the kernel.  GRAV kernels stage the 9 words
@@ -406,12 +421,16 @@ __device__ __forceinline__ void rollout_body(
     // Retire the state loads HERE, or their first use inside the loop puts `s_waitcnt vmcnt(0)` -- which
     // also waits for the previous step's stores -- into every iteration.
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
-    constexpr bool kRotate = EVAC_PRIO && !F::kPace && std::is_same<F, Wave<F::WPE>>::value && F::WPE < 16;
-    int prio_slot = 0;
-    if constexpr (kRotate) prio_slot = simd_wave_slot();
     if constexpr (EVAC_PRIO && F::kPace) {
         if (w.lane == 0) sm.progress[(w.slot & 3) * 4 + (w.slot >> 2)] = 0;
     }
+    // late in an episode two one-wave envs with at most 32 moving pedestrians each share a wave (evac_packed.h)
+    if constexpr (GRAV && !DIAG && std::is_same<F, Wave<1, F::kBlock>>::value) {
+        if (p.pack && try_pack<F, GRAV>(sm, p, w, q, e, active, n_steps, actions, slab_out, moving_out)) return;
+    }
+    constexpr bool kRotate = EVAC_PRIO && !F::kPace && std::is_same<F, Wave<F::WPE>>::value && F::WPE < 16;
+    int prio_slot = 0;
+    if constexpr (kRotate) prio_slot = simd_wave_slot();
 #ifdef EVAC_STAMP
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w.stamp.last)::"memory");
     unsigned long long rt0_;   // constant 100 MHz counter next to the shader-clock one: their ratio is the clock the kernel ran at
@@ -432,13 +451,7 @@ __device__ __forceinline__ void rollout_body(
                 }
             }
         }
-        if constexpr (EVAC_PRIO && F::kPace) {
-            int* mine = &sm.progress[(w.slot & 3) * 4];
-            if (w.lane == 0) mine[w.slot >> 2] = t;
-            const i4 pr = *(const i4*)mine;     // the mates' counters may be a step old: good enough
-            const int ahead = (pr.x > t ? 1 : 0) + (pr.y > t ? 1 : 0) + (pr.z > t ? 1 : 0) + (pr.w > t ? 1 : 0);
-            set_wave_priority(__builtin_amdgcn_readfirstlane(ahead));
-        }
+        if constexpr (EVAC_PRIO && F::kPace) pace_step(sm, w.slot, w.lane, t);
         const int slot64 = t & 63;
         if (slot64 == 0) {
             if (actions) {

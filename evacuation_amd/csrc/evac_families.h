@@ -67,6 +67,14 @@ struct Wave {
         // rollout outputs of up to kStageSteps steps, flushed with ONE 64-lane store (GRAV kernels)
         alignas(16) float stage[kEnvsPerBlock][kStageSteps][12];   // rows written as two 16-byte vectors + 1 word
         alignas(16) int progress[kPace ? 16 : 4];                  // kPace: step counter of every wave, [SIMD][wave of the SIMD]
+        // WPE == 1: packing of two late-episode envs into one wave (evac_packed.h): eligibility per wave; per pair of waves the
+        // 2 x 32 compacted pedestrians (x, y, dx, dy | status, id) and the two envs' scalars
+        static constexpr int kPairs = WPE == 1 ? kEnvsPerBlock / 2 : 1;
+        int pk_elig[WPE == 1 ? kEnvsPerBlock : 1];
+        alignas(16) f4 pk_ped[kPairs][kWave];
+        i2 pk_tag[kPairs][kWave];
+        alignas(16) f4 pk_env[kPairs][2][3];
+        int pk_slot[kPairs][2];                                    // the two waves of a pair (their staging rows)
     };
 
     struct Ctx {
@@ -108,6 +116,8 @@ struct Wave {
         }
     }
 
+    template <class C>
+    static __device__ __forceinline__ int escaped_elsewhere(const C&) { return 0; }
     static __device__ __forceinline__ void init(Ctx& c) {
         if constexpr (WPE > 1) {
             if (c.wave_in_env == 0 && c.lane < 2) c.sm.poison[c.lane][c.slot] = 0;
@@ -435,6 +445,8 @@ struct Cells {
     };
 
     static __device__ __forceinline__ void sync() { __syncthreads(); }
+    template <class C>
+    static __device__ __forceinline__ int escaped_elsewhere(const C&) { return 0; }
 
     static __device__ __forceinline__ void invalidate(Ctx&) {}
     // Once per kernel, before the first step: the counters start at zero (afterwards the prefix wave clears them).
@@ -555,14 +567,18 @@ struct Cells {
 //   * values that Wave<1> fetches with v_readlane come through ds_bpermute from a per-group source lane.
 // There is no workgroup barrier anywhere (a wave is in lock-step).
 // ------------------------------------------------------------------------------------------------
-template <int G_>
+// BLOCK_ = 1024: the PACKED use of Sub<32> inside the CU-wide rollout workgroups (evac_packed.h): late in an episode two
+// envs with at most 32 moving pedestrians each share a wave.  A lane then carries an arbitrary pedestrian id (Ctx::i; `li`
+// is its position in the group) and the env's escaped pedestrians, which are not in any lane, enter the termination test
+// through Ctx::esc_base.
+template <int G_, int BLOCK_ = 256>
 struct Sub {
     static constexpr int G = G_;
     static_assert(G == 16 || G == 32, "sub-wave groups are 16 or 32 lanes");
     static constexpr bool kEnvUniform = false, kHelpers = false, kExitLane = true, kPipelined = false;
     static constexpr int kThreadsPerEnv = G;
     static constexpr int kEnvsPerWave = kWave / G;
-    static constexpr int kBlock = 256;
+    static constexpr int kBlock = BLOCK_;
     static constexpr int kEnvsPerBlock = (kBlock / kWave) * kEnvsPerWave;
     static constexpr unsigned long long kGroupBits = G == 32 ? 0xffffffffull : 0xffffull;
     static constexpr const char* kName = G == 16 ? "4 envs/wave, all pairs" : "2 envs/wave, all pairs";
@@ -573,7 +589,8 @@ struct Sub {
 
     struct Ctx {
         Smem& sm;
-        int env, slot, lane, sub, i;
+        int env, slot, lane, sub, i, li;
+        int esc_base = 0;           // escaped pedestrians of the env that no lane carries (packed rollouts only)
         unsigned long long gmask;   // this group's lanes in a 64-bit ballot
         bool owner;                 // the group's last lane: the DPP sums are valid there
 #ifdef EVAC_STAMP
@@ -583,13 +600,15 @@ struct Sub {
             const int t = threadIdx.x;
             lane = t & (kWave - 1);
             sub = lane / G;
-            i = lane - sub * G;
+            li = i = lane - sub * G;
             slot = (t / kWave) * kEnvsPerWave + sub;
             env = blockIdx.x * kEnvsPerBlock + slot;
             gmask = kGroupBits << (sub * G);
-            owner = i == G - 1;
+            owner = li == G - 1;
         }
     };
+    template <class C>
+    static __device__ __forceinline__ int escaped_elsewhere(const C& c) { return c.esc_base; }
 
     static __device__ __forceinline__ void sync() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -636,7 +655,7 @@ struct Sub {
         const int n_cols = count(m_efv, c.gmask);
         {
             const int before = rank(m_efv, c.gmask);
-            const int idx = efv ? before : n_cols + (c.i - before);     // a bijection onto the group's G slots
+            const int idx = efv ? before : n_cols + (c.li - before);    // a bijection onto the group's G slots
             sm.tile[c.slot][idx] = f4{efv ? q.x * kTileScale : __builtin_inff(), q.y * kTileScale, efv ? ux : 0.0f, efv ? uy : 0.0f};
         }
         sync();

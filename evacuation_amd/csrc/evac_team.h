@@ -92,6 +92,8 @@ struct Team {
     };
 
     static __device__ __forceinline__ void sync() { __syncthreads(); }
+    template <class C>
+    static __device__ __forceinline__ int escaped_elsewhere(const C&) { return 0; }
     static __device__ __forceinline__ void invalidate(Ctx& c) { c.tile_valid = false; }   // the state changed outside step_env (autoreset)
     static __device__ __forceinline__ void init(Ctx& c) {
         if (threadIdx.x == 0) c.sm.abort = 0;

@@ -165,12 +165,15 @@ class BatchedEvacuationEnv:
         # for A/B runs)
         self.workspace = None
         self.schedule = None
+        self.pack_stats = None
         if os.environ.get("EVAC_WORKSPACE", "1") != "0":
             nbytes = int(self.lib.evac_workspace_bytes(self._h))
             self.workspace = torch.zeros((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=dev)
             assert self.workspace.data_ptr() % 256 == 0
             _lib.check(self.lib.evac_bind_workspace(self._h, _ptr(self.workspace), C.c_int64(nbytes)), self._h)
             self.schedule = self.workspace[:8 * E].view(torch.int32).view(2, E)     # moving[E] | perm[E]
+            off = (8 * E + 255) // 256 * 256
+            self.pack_stats = self.workspace[off:off + 4].view(torch.int32)        # env-launches that ran packed (cumulative)
         # step outputs (reused every step; callers that keep them must clone, like the reference's
         # live-reference observations, env.py:98-104)
         self.obs = torch.zeros((E, self.obs_dim), dtype=torch.float32, device=dev)

@@ -21,7 +21,9 @@
  * kernels on (for every N > 64) / off (default: N > 512; the all-pairs kernels give the same neighbour sets); EVAC_CU_WIDE=1 / 0
  * forces / forbids the CU-wide rollout workgroups of one-wave envs (default: batches of >= 16 envs per CU); EVAC_TEAM=0 / 2 / 4 / 8
  * forbids / forces the team rollout kernels of rooms of more than 512 pedestrians (default: as many CUs per env as the batch leaves
- * free; not under EVAC_CELLS); all of them give bit-identical results.  The Python host honours EVAC_WORKSPACE=0 (no workspace) and
+ * free; not under EVAC_CELLS); all of them give bit-identical results.  EVAC_PACK=1 lets rollouts of one-wave envs with a
+ * gravity observation run two late-episode envs (<= 32 moving pedestrians each, no episode end possible inside the launch) in
+ * one wave: trajectories, flags and rewards stay bit-identical, the summed observations agree to f32 rounding (default off).  The Python host honours EVAC_WORKSPACE=0 (no workspace) and
  * EVAC_LIB=<path> to load a profiling build of this library instead of evacuation_amd/libevac.so.
  *
  * Device layouts (row-major, E = num_envs, N = n_ped)
