@@ -91,3 +91,34 @@ def test_team_nan_poisoning_reaches_every_member(ea):
                            sb[key].view(torch.uint8) if sb[key].dtype == torch.uint8 else sb[key].view(torch.int32)), key
     assert torch.equal(a["obs"].view(torch.int32), b["obs"].view(torch.int32))
     ref.close(); tm.close()
+
+
+def test_workspace_binding_errors_and_sizes(ea):
+    """evac_workspace_bytes / evac_bind_workspace through the C ABI: too small or misaligned workspaces are refused, NULL
+    unbinds (rollouts then run the one-workgroup kernels), and the handle reports which kernels it will launch."""
+    import ctypes as C
+    import torch
+    from evacuation_amd import _lib
+    lib = _lib.load()
+    cfg = ea.EnvConfig(number_of_pedestrians=1024, max_timesteps=50)
+    env = _make(ea, cfg, ea.EnvWrappersConfig(positions="rel", statuses="ohe", type="Box"), 8, 1, team=8)
+    need = int(lib.evac_workspace_bytes(env._h))
+    assert need >= 2 * 8 * 4 + 2 * 8 * 1024 * 16                         # schedule + at least the teams' double-buffered tile
+    buf = torch.zeros(need + 512, dtype=torch.uint8, device=env.device)
+    base = buf.data_ptr()
+    aligned = (base + 255) // 256 * 256
+    assert lib.evac_bind_workspace(env._h, C.c_void_p(aligned), C.c_int64(need - 1)) == _lib.ERR_INVALID_ARGUMENT
+    assert lib.evac_bind_workspace(env._h, C.c_void_p(aligned + 8), C.c_int64(need)) == _lib.ERR_INVALID_ARGUMENT
+    assert lib.evac_bind_workspace(env._h, None, C.c_int64(0)) == _lib.EVAC_OK          # unbound: plain kernels
+    env.reset()
+    a = env.rollout(5)["obs"].clone()
+    assert lib.evac_bind_workspace(env._h, C.c_void_p(aligned), C.c_int64(need)) == _lib.EVAC_OK
+    ref = _make(ea, cfg, ea.EnvWrappersConfig(positions="rel", statuses="ohe", type="Box"), 8, 1, team=0)
+    ref.reset()
+    b = ref.rollout(5)["obs"]
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    c2 = env.rollout(5)["obs"]; d2 = ref.rollout(5)["obs"]                   # now through the teams
+    torch.cuda.synchronize()
+    assert env.team_error() == 0 and torch.equal(c2.view(torch.int32), d2.view(torch.int32))
+    env.close(); ref.close()
