@@ -65,6 +65,7 @@ struct evac_handle {
     int sub_lanes;      // 0: one wave (or more) per env; 16 / 32: sub-wave kernels (evac_subwave.h)
     bool cells;         // workgroup-per-env kernels with the cell list (N > 64) instead of all pairs
     bool cu_wide;       // rollouts of one-wave envs in CU-wide workgroups (the batch fills every CU with 16 envs)
+    bool cu_wide4;      // the same for four-wave envs (4 envs per CU-wide workgroup)
     int team_k;         // rollouts of 513..1024-pedestrian envs by teams of 2 / 4 / 8 workgroups per env (0: one workgroup per env)
     int32_t* sched;     // inside the caller's workspace (evac_bind_workspace): moving[E] | perm[E], or NULL
     int sched_age;      // env steps rolled out since the schedule was last rebuilt (< 0: never built)
@@ -257,6 +258,9 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         // slots -- 1.65e9 against 1.63e9 env-steps/s with 100-step launches, 1.01e9 against 1.07e9 with 20-step launches (the
         // pairing costs two barriers per launch); launches many rounds deep gain: 65 536 envs 2.08e9 against 1.87e9.  Whether
         // an env is packed changes the rounding of its summed observations, so the switch is global, not per batch size.
+        // four-wave envs (N = 129..256, all pairs): 4 envs per CU-wide workgroup with per-env LDS barriers, pace and schedule
+        h->cu_wide4 = h->sub_lanes == 0 && wpe == 4 && !h->cells &&
+                      (cw && cw[0] == '1' ? true : (cw && cw[0] == '0' ? false : (num_envs >= 4 * cus && num_envs <= 16 * cus)));
         const char* pk = std::getenv("EVAC_PACK");
         h->p.pack = (one_wave && cfg->positions == EVAC_POS_GRAV && pk && pk[0] == '1') ? 1 : 0;
         h->sched = nullptr;
@@ -286,6 +290,7 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
                                    : (wpe == 2 ? evac::Wave<2>::kName : wpe == 4 ? evac::Wave<4>::kName : wpe == 8 ? evac::Wave<8>::kName : evac::Wave<16>::kName);
         h->variant[0] = "k_step<" + fam + (grav ? ", grav obs>" : ", generic obs>");
         if (h->cu_wide) fam = evac::Wave<1, 1024>::kName;
+        if (h->cu_wide4) fam = evac::Wave<4, 1024>::kName;
         if (h->team_k) fam = h->team_k == 8 ? evac::Team<8>::kName : (h->team_k == 4 ? evac::Team<4>::kName : evac::Team<2>::kName);
         h->variant[1] = "k_rollout<" + fam + (grav ? ", grav obs>" : ", generic obs>");
     }
@@ -461,21 +466,33 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
         else if (K == 4) EVAC_LAUNCH_TEAM(4);
         else EVAC_LAUNCH_TEAM(2);
 #undef EVAC_LAUNCH_TEAM
-    } else if (h->cu_wide) {
+    } else if (h->cu_wide || h->cu_wide4) {
         // one-wave envs, batch >= 16 envs per CU: CU-wide workgroups, envs dealt to the SIMDs by load when a schedule scratch
         // is bound (rebuilt every 50..200 env steps: the loads drift slowly)
         // (short launches re-sort less often: the sort is a launch of its own, ~4 us next to a 20-step launch of ~55 us)
         const int kScheduleEvery = n_steps >= 50 ? 50 : (8 * n_steps < 200 ? (8 * n_steps > 50 ? 8 * n_steps : 50) : 200);
         using FW = evac::Wave<1, 1024>;
+        using FW4 = evac::Wave<4, 1024>;
         hipStream_t s_ = (hipStream_t)stream;
         const int E = h->p.n_envs;
         int32_t* moving = h->sched;
         const int32_t* perm = h->sched ? h->sched + E : nullptr;
         if (h->sched && (h->sched_age < 0 || h->sched_age >= kScheduleEvery)) {
-            hipLaunchKernelGGL(evac::k_schedule, dim3(1), dim3(1024), 0, s_, E, (const int*)moving, h->sched + E);
+            hipLaunchKernelGGL(evac::k_schedule, dim3(1), dim3(1024), 0, s_, E, (const int*)moving, h->sched + E,
+                               h->cu_wide4 ? 4 : 16, h->cu_wide4 ? 4 : 1);
             h->sched_age = 0;
         }
         if (h->sched) h->sched_age += n_steps;
+        if (h->cu_wide4) {
+            const dim3 grid4((unsigned)((E + FW4::kEnvsPerBlock - 1) / FW4::kEnvsPerBlock));
+            if (h->p.obs_pos == EVAC_POS_GRAV)
+                hipLaunchKernelGGL((evac::k_rollout<FW4, true>), grid4, dim3(FW4::kBlock), 0, s_, h->p, (int)n_steps, (const float2*)actions,
+                                   slab_out, final_stats, (const int*)perm, (int*)moving);
+            else
+                hipLaunchKernelGGL((evac::k_rollout<FW4, false>), grid4, dim3(FW4::kBlock), 0, s_, h->p, (int)n_steps, (const float2*)actions,
+                                   slab_out, final_stats, (const int*)perm, (int*)moving);
+            return check_launch(h, "evac_rollout");
+        }
         const dim3 grid((unsigned)((E + FW::kEnvsPerBlock - 1) / FW::kEnvsPerBlock));
         if (h->p.obs_pos == EVAC_POS_GRAV)
             hipLaunchKernelGGL((evac::k_rollout<FW, true>), grid, dim3(FW::kBlock), 0, s_, h->p, (int)n_steps, (const float2*)actions,

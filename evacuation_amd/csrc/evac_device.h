@@ -247,12 +247,12 @@ __device__ __forceinline__ int simd_wave_slot() {   // slot of this wave among t
 #define EVAC_PRIO 1     // 0: leave the arbitration to wave age (A/B builds)
 #endif
 
-// Pace keeping of the CU-wide workgroups: wave `slot` publishes its step counter and takes as priority the number of its
-// SIMD-mates (waves slot % 4 + 4 k) that are ahead of it.
+// Pace keeping of the CU-wide workgroups: a wave publishes its step counter and takes as priority the number of its
+// SIMD-mates that are ahead of it (one-wave envs: wave w runs on SIMD w % 4; four-wave envs: wave k of every env on SIMD k).
 template <class Smem>
-__device__ __forceinline__ void pace_step(Smem& sm, int slot, int lane, int t) {
-    int* mine = &sm.progress[(slot & 3) * 4];
-    if (lane == 0) mine[slot >> 2] = t;
+__device__ __forceinline__ void pace_step(Smem& sm, int simd, int k, int lane, int t) {   // this wave: the SIMD's k-th
+    int* mine = &sm.progress[simd * 4];
+    if (lane == 0) mine[k] = t;
     const i4 pr = *(const i4*)mine;     // the mates' counters may be a step old: good enough
     const int ahead = (pr.x > t ? 1 : 0) + (pr.y > t ? 1 : 0) + (pr.z > t ? 1 : 0) + (pr.w > t ? 1 : 0);
     set_wave_priority(__builtin_amdgcn_readfirstlane(ahead));
@@ -421,8 +421,11 @@ __device__ __forceinline__ void rollout_body(
     // Retire the state loads HERE, or their first use inside the loop puts `s_waitcnt vmcnt(0)` -- which
     // also waits for the previous step's stores -- into every iteration.
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
+    int pace_simd = 0, pace_k = 0;
     if constexpr (EVAC_PRIO && F::kPace) {
-        if (w.lane == 0) sm.progress[(w.slot & 3) * 4 + (w.slot >> 2)] = 0;
+        pace_simd = F::WPE == 1 ? (w.slot & 3) : (w.wave_in_env & 3);
+        pace_k = F::WPE == 1 ? (w.slot >> 2) : w.slot;
+        if (w.lane == 0) sm.progress[pace_simd * 4 + pace_k] = 0;
     }
     // late in an episode two one-wave envs with at most 32 moving pedestrians each share a wave (evac_packed.h)
     if constexpr (GRAV && !DIAG && std::is_same<F, Wave<1, F::kBlock>>::value) {
@@ -451,7 +454,7 @@ __device__ __forceinline__ void rollout_body(
                 }
             }
         }
-        if constexpr (EVAC_PRIO && F::kPace) pace_step(sm, w.slot, w.lane, t);
+        if constexpr (EVAC_PRIO && F::kPace) pace_step(sm, pace_simd, pace_k, w.lane, t);
         const int slot64 = t & 63;
         if (slot64 == 0) {
             if (actions) {
@@ -557,6 +560,9 @@ __device__ __forceinline__ void rollout_body(
         atomicMax(&g_stamps[11], ~0ull - (rt1_ - rt0_));
     }
 #endif
+    if constexpr (F::kEnvBarrier) {               // (multi-wave envs: the load is the column count the last reduction delivered)
+        if (moving_out && w.owner) moving_out[w.env] = w.have_next ? w.next_cols : p.n_ped;
+    }
     if constexpr (F::kThreadsPerEnv == kWave) {   // what k_schedule sorts the envs of the next launches by
         if (moving_out) {   // the length of the env's pair loop: its moving pedestrians, or 0 if no row needs evaluating
             const int nm = ballot(needs_row(p, q.st)) != 0ull ? wave_count((unsigned)(q.st - kViscek) < 3u) : 0;
@@ -580,12 +586,15 @@ __global__ __launch_bounds__(F::kBlock, 4) void k_rollout(
 // random placement that is 1.25-1.35x the mean load for most of an episode (tools/moving_distribution.py).
 // One workgroup; perm[slot] = env, slot = workgroup * 16 + wave.  Ties are placed in arrival order (LDS atomics): the
 // permutation may differ from run to run, the results cannot.
-__global__ __launch_bounds__(1024) void k_schedule(int n_envs, const int* __restrict__ moving, int* __restrict__ perm) {
+// per_wg = 16: one-wave envs (slot = workgroup * 16 + wave, SIMD = wave % 4); per_wg = 4: four-wave envs (slot = workgroup * 4 +
+// env of the workgroup; every SIMD runs one wave of each of the four) -- one env of each load quartile per workgroup.  Loads
+// are binned in 65 steps of `unit` pedestrians.
+__global__ __launch_bounds__(1024) void k_schedule(int n_envs, const int* __restrict__ moving, int* __restrict__ perm, int per_wg, int unit) {
     __shared__ int hist[kWave + 2];
     const int tid = threadIdx.x;
     if (tid < kWave + 2) hist[tid] = 0;
     __syncthreads();
-    for (int e = tid; e < n_envs; e += 1024) atomicAdd(&hist[min(max(moving[e], 0), kWave)], 1);
+    for (int e = tid; e < n_envs; e += 1024) atomicAdd(&hist[min(max(moving[e] / unit, 0), kWave)], 1);
     __syncthreads();
     if (tid < kWave) {                       // exclusive prefix over the 65 bins (bin 64 = everything at or above 64)
         const int v = hist[tid];
@@ -595,14 +604,15 @@ __global__ __launch_bounds__(1024) void k_schedule(int n_envs, const int* __rest
         if (tid == kWave - 1) hist[kWave] = incl;
     }
     __syncthreads();
-    const int e16 = n_envs & ~15, G = e16 >> 2;      // groups of four (one SIMD each) among the full workgroups
+    const int e16 = n_envs & ~(per_wg - 1), G = e16 >> 2;      // groups of four (one SIMD / one workgroup each) among the full workgroups
     for (int e = tid; e < n_envs; e += 1024) {
-        const int r = atomicAdd(&hist[min(max(moving[e], 0), kWave)], 1);   // rank by load, ascending
+        const int r = atomicAdd(&hist[min(max(moving[e] / unit, 0), kWave)], 1);   // rank by load, ascending
         int slot = r;
         if (r < e16) {
             const int k = r / G, j = r - k * G;
             const int g = (k & 1) ? G - 1 - j : j;   // snake: quarters 0 and 2 ascending, 1 and 3 descending
-            slot = (g >> 2) * 16 + k * 4 + (g & 3);  // workgroup g / 4, SIMD g % 4, the SIMD's k-th wave
+            slot = per_wg == 16 ? (g >> 2) * 16 + k * 4 + (g & 3)   // workgroup g / 4, SIMD g % 4, the SIMD's k-th wave
+                                : g * 4 + k;                        // workgroup g, its k-th env
         }
         perm[slot] = e;
     }

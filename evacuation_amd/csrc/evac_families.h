@@ -39,11 +39,14 @@ struct Wave {
     static constexpr int kThreadsPerEnv = WPE * kWave;
     // WPE == 1: several one-wave envs share a workgroup (no workgroup barrier is ever used there);
     // WPE >= 2: exactly one env per workgroup, so that __syncthreads() is a per-env barrier
-    static constexpr int kBlock = WPE == 1 ? BLOCK1_ : kThreadsPerEnv;
+    //           -- except in the CU-wide form (BLOCK1 = 1024: 16 / WPE envs per workgroup), where the waves of ONE env meet
+    //           at a barrier of their own in LDS (sync())
+    static constexpr int kBlock = (WPE == 1 || BLOCK1_ == 1024) ? (BLOCK1_ > kThreadsPerEnv ? BLOCK1_ : kThreadsPerEnv) : kThreadsPerEnv;
     static constexpr int kEnvsPerBlock = kBlock / kThreadsPerEnv;
-    static constexpr bool kPace = WPE == 1 && kBlock == 1024;
+    static constexpr bool kPace = kBlock == 1024 && kEnvsPerBlock > 1;      // CU-wide: the SIMD-mates are known, the waves keep pace (rollout_body)
+    static constexpr bool kEnvBarrier = WPE > 1 && kEnvsPerBlock > 1;
     static constexpr bool kHelpers = false, kExitLane = true, kPipelined = false;
-    static constexpr const char* kName = WPE == 1 ? (kPace ? "1 wave/env, all pairs, CU-wide workgroups" : "1 wave/env, all pairs") : (WPE == 2 ? "2 waves/env, all pairs" : (WPE == 4 ? "4 waves/env, all pairs" : (WPE == 8 ? "8 waves/env, all pairs" : "16 waves/env, all pairs")));
+    static constexpr const char* kName = WPE == 1 ? (kPace ? "1 wave/env, all pairs, CU-wide workgroups" : "1 wave/env, all pairs") : (WPE == 2 ? "2 waves/env, all pairs" : (WPE == 4 ? (kPace ? "4 waves/env, all pairs, CU-wide workgroups" : "4 waves/env, all pairs") : (WPE == 8 ? "8 waves/env, all pairs" : "16 waves/env, all pairs")));
 
     // WPE > 1: two tiles used alternately, so that writing step t+1's tile needs no barrier against the waves still
     // reading step t's (the two barriers of step t+1 lie between a tile's last read and its next write)
@@ -64,6 +67,7 @@ struct Wave {
         int cols[kEnvsPerBlock][WPE];              // moving pedestrians per wave (tile compaction)
         float exitg[kEnvsPerBlock][2];            // gravity exit term from the lane that computed it (WPE > 1)
         int poison[2][kEnvsPerBlock];             // WPE > 1: a moving pedestrian has a NaN heading (by step parity)
+        int bar[kEnvsPerBlock];                   // kEnvBarrier: arrivals at the env's own barrier (WPE per generation)
         // rollout outputs of up to kStageSteps steps, flushed with ONE 64-lane store (GRAV kernels)
         alignas(16) float stage[kEnvsPerBlock][kStageSteps][12];   // rows written as two 16-byte vectors + 1 word
         alignas(16) int progress[kPace ? 16 : 4];                  // kPace: step counter of every wave, [SIMD][wave of the SIMD]
@@ -108,11 +112,32 @@ struct Wave {
     // Sync the WPE waves of one env.  WPE == 1: a wave is in lock-step; only keep the compiler from
     // moving LDS accesses across the point.  WPE > 1: one env per workgroup, so a workgroup barrier.
     static __device__ __forceinline__ void sync() {
+        static_assert(!kEnvBarrier, "several multi-wave envs per workgroup: use sync(ctx)");
         if constexpr (WPE == 1) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         } else {
             __syncthreads();
+        }
+    }
+    // The barrier of ONE env.  One env per workgroup: the workgroup barrier.  CU-wide form: an arrival counter per env in
+    // LDS -- a wave's LDS operations execute in order, so its earlier writes are visible to whoever sees its arrival; the
+    // waves of the other envs of the workgroup are not held up.
+    template <class C>
+    static __device__ __forceinline__ void sync(C& c) {
+        if constexpr (!kEnvBarrier) {
+            sync();
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (c.lane == 0) {
+                int* ctr = &c.sm.bar[c.slot];
+                const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int target = (old / WPE + 1) * WPE;
+                int spins = 0;       // (bounded: a lost sibling must not hang the GPU; it cannot happen -- the env's waves run one code path)
+                while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 
@@ -121,7 +146,8 @@ struct Wave {
     static __device__ __forceinline__ void init(Ctx& c) {
         if constexpr (WPE > 1) {
             if (c.wave_in_env == 0 && c.lane < 2) c.sm.poison[c.lane][c.slot] = 0;
-            __syncthreads();
+            if (c.wave_in_env == 0 && c.lane == 2) c.sm.bar[c.slot] = 0;
+            __syncthreads();   // (the one workgroup-wide barrier of the CU-wide form: once per kernel, every live wave passes it)
         }
     }
     // the statuses changed outside step_env (autoreset): the counts carried over from the last reduction are void
@@ -139,12 +165,12 @@ struct Wave {
         for (int k = 0; k < 8; ++k) s.i[k] = mask_count(pred[k]);
         if constexpr (WPE > 1) {
             auto& sm = c.sm;
-            if constexpr (GUARD) __syncthreads();   // previous users of the records are done
+            if constexpr (GUARD) C::Family::sync(c);   // previous users of the records are done
             if (c.lane == 0) {
                 sm.redf[c.slot][c.wave_in_env] = f4{s.f0, s.f1, s.f2, 0.0f};
                 sm.redi[c.slot][c.wave_in_env] = i4{s.i[0] | (s.i[1] << 16), s.i[2] | (s.i[3] << 16), s.i[4] | (s.i[5] << 16), s.i[6] | (s.i[7] << 16)};
             }
-            __syncthreads();
+            C::Family::sync(c);
             const int w = c.lane < WPE ? c.lane : WPE - 1;
             f4 rf = sm.redf[c.slot][w];
             i4 ri = sm.redi[c.slot][w];
@@ -210,7 +236,7 @@ struct Wave {
         auto& sm = c.sm;
         int par = 0;
         if constexpr (WPE == 1) {
-            sync();   // tile readers of the previous step are done (a fence: the wave is in lock-step)
+            sync(c);   // tile readers of the previous step are done (a fence: the wave is in lock-step)
         } else {
             par = c.par;
             c.par = par ^ 1;
@@ -238,7 +264,7 @@ struct Wave {
                     row_rank += c.next_rbase;
                 } else {                    // first step of a launch, or right after an autoreset
                     if (c.lane == 0) sm.cols[c.slot][c.wave_in_env] = n_cols | (n_rows << 16);
-                    __syncthreads();
+                    sync(c);
                     int tot = 0, base = 0;
 #pragma unroll
                     for (int w2 = 0; w2 < WPE; ++w2) {
@@ -262,7 +288,7 @@ struct Wave {
             // evaluated rows through w * NaN; the followers whose rows are skipped get it through this flag.
             if (ballot(efv && (ux != ux || uy != uy)) != 0ull && c.lane == 0) sm.poison[par][c.slot] = 1;
         }
-        sync();   // tile complete
+        sync(c);   // tile complete
         bool poisoned = false;
         if constexpr (WPE > 1) {
             poisoned = sm.poison[par][c.slot] != 0;
@@ -355,7 +381,7 @@ struct Wave {
                     else if (slices == 4) sweep(std::integral_constant<int, 4>{});
                 }
             }
-            __syncthreads();
+            sync(c);
             if (fv) {
 #pragma unroll
                 for (int r = 0; r < kRows; ++r) {      // fixed order: deterministic
@@ -401,7 +427,7 @@ struct Cells {
     static constexpr int kThreadsPerEnv = WPE * kWave;
     static constexpr int kBlock = kThreadsPerEnv;
     static constexpr int kEnvsPerBlock = 1;
-    static constexpr bool kPace = false, kHelpers = false, kExitLane = true, kPipelined = false;
+    static constexpr bool kPace = false, kHelpers = false, kExitLane = true, kPipelined = false, kEnvBarrier = false;
     static constexpr int kPad = 8;   // +inf entries behind the last moving pedestrian (>= entries per batch)
 #ifndef EVAC_ROW_BATCH
 #define EVAC_ROW_BATCH 8
@@ -445,6 +471,8 @@ struct Cells {
     };
 
     static __device__ __forceinline__ void sync() { __syncthreads(); }
+    template <class C>
+    static __device__ __forceinline__ void sync(C&) { __syncthreads(); }
     template <class C>
     static __device__ __forceinline__ int escaped_elsewhere(const C&) { return 0; }
 
@@ -575,7 +603,7 @@ template <int G_, int BLOCK_ = 256>
 struct Sub {
     static constexpr int G = G_;
     static_assert(G == 16 || G == 32, "sub-wave groups are 16 or 32 lanes");
-    static constexpr bool kEnvUniform = false, kHelpers = false, kExitLane = true, kPipelined = false;
+    static constexpr bool kEnvUniform = false, kHelpers = false, kExitLane = true, kPipelined = false, kEnvBarrier = false;
     static constexpr int kThreadsPerEnv = G;
     static constexpr int kEnvsPerWave = kWave / G;
     static constexpr int kBlock = BLOCK_;

@@ -127,7 +127,7 @@ __device__ __forceinline__ bool try_pack(typename FW::Smem& sm, const Params& p,
     int prio_slot = 0;
     if constexpr (EVAC_PRIO && !FW::kPace) prio_slot = simd_wave_slot();
     for (int t = 0; t < n_steps; ++t) {
-        if constexpr (EVAC_PRIO && FW::kPace) pace_step(sm, w.slot, w.lane, t);
+        if constexpr (EVAC_PRIO && FW::kPace) pace_step(sm, w.slot & 3, w.slot >> 2, w.lane, t);
         else if constexpr (EVAC_PRIO != 0) {
             if (p.fair) set_wave_priority(t + prio_slot);
         }

@@ -42,7 +42,7 @@ struct Team {
     static constexpr int K = K_;
     static_assert(K == 2 || K == 4 || K == 8, "a team has 2, 4 or 8 members");
     static constexpr int WPE = 16;                       // waves per workgroup = ped waves per team
-    static constexpr bool kEnvUniform = true, kPace = false, kHelpers = true, kExitLane = false, kPipelined = true;
+    static constexpr bool kEnvUniform = true, kPace = false, kHelpers = true, kExitLane = false, kPipelined = true, kEnvBarrier = false;
     static constexpr int kBlock = 1024, kThreadsPerEnv = 1024, kEnvsPerBlock = 1;
     static constexpr int P = 1024 / K;                   // pedestrians per member
     static constexpr int PW = P / kWave;                 // ped waves per member

@@ -36,6 +36,8 @@ def _make(ea, cfg, wrap, E, seed, cu_wide, schedule):
     (60, 512, dict(positions="rel", statuses="ohe", type="Box")),
     (33, 77, dict(positions="grav", alpha=2)),
     (64, 160, dict(positions="abs", statuses="cat", type="Dict")),        # the env fills its wave
+    (200, 53, dict(positions="grav", alpha=3)),                           # four-wave envs: 4 per CU-wide workgroup, barriers per env in LDS
+    (256, 40, dict(positions="rel", statuses="ohe", type="Box")),
 ])
 def test_cu_wide_scheduled_rollout_is_bit_identical(ea, n, E, wrap_kw):
     import torch
