@@ -1,0 +1,91 @@
+"""Randomised sweep: every scheduling / decomposition device switched on (CU-wide workgroups, load schedule, teams, packed
+rollouts) against the plain kernels (everything off), over random room sizes, batch sizes, observation modes, enslaving
+degrees, launch lengths, with and without caller-provided actions.  States, flags and episode records must be bit-identical;
+observations and rewards too, except that packed envs may round their summed observations differently."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SWITCHES = ("EVAC_CU_WIDE", "EVAC_TEAM", "EVAC_PACK", "EVAC_WORKSPACE")
+
+
+@pytest.fixture(scope="module")
+def ea():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import evacuation_amd
+    return evacuation_amd
+
+
+def _make(ea, cfg, wrap, E, seed, **env):
+    old = {k: os.environ.get(k) for k in SWITCHES}
+    try:
+        for k in SWITCHES:
+            os.environ.pop(k, None)
+        os.environ.update({k: str(v) for k, v in env.items()})
+        return ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+CASES = []
+_rng = np.random.default_rng(20261003)
+for _ in range(14):
+    n = int(_rng.choice([33, 48, 60, 64, 130, 200, 256, 600, 777, 1024]))
+    E = int(_rng.integers(3, 70)) if n > 64 else int(_rng.integers(20, 300))
+    if n > 512:
+        E = int(_rng.integers(2, 40))
+    mode = _rng.choice(["grav", "grav", "relbox", "absdict"])
+    ens = float(_rng.choice([1.0, 1.0, 0.5, 0.1]))
+    CASES.append((n, E, str(mode), ens, int(_rng.integers(0, 1 << 30))))
+
+
+@pytest.mark.parametrize("n,E,mode,ens,seed", CASES)
+def test_all_devices_on_equals_all_off(ea, n, E, mode, ens, seed):
+    import torch
+    wrap_kw = {"grav": dict(positions="grav", alpha=3), "relbox": dict(positions="rel", statuses="ohe", type="Box"),
+               "absdict": dict(positions="abs", statuses="cat", type="Dict")}[mode]
+    rng = np.random.default_rng(seed)
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=int(rng.integers(40, 400)), is_new_exiting_reward=True,
+                       is_new_followers_reward=bool(rng.integers(0, 2)), enslaving_degree=ens, noise_coef=float(rng.choice([0.2, 0.5])))
+    wrap = ea.EnvWrappersConfig(**wrap_kw)
+    off = _make(ea, cfg, wrap, E, seed % 1000, EVAC_CU_WIDE=0, EVAC_TEAM=0, EVAC_PACK=0, EVAC_WORKSPACE=0)
+    on = _make(ea, cfg, wrap, E, seed % 1000, EVAC_CU_WIDE=1, EVAC_PACK=1)             # teams by default where they apply
+    packed_possible = mode == "grav" and n <= 64
+    off.reset(); on.reset()
+    # start some envs late in their episode so that packing and the viscek-only rows come into play
+    st = off.get_state()
+    status = st["status"].clone()
+    esc = torch.from_numpy(rng.random((E, n)) < rng.uniform(0.0, 0.9)).to(status.device)
+    status[esc] = 4
+    for env in (off, on):
+        env.set_state(status=status)
+    for T in [int(x) for x in rng.integers(1, 60, size=4)]:
+        acts = None
+        if rng.integers(0, 2):
+            acts = torch.from_numpy(rng.uniform(-1, 1, (T, E, 2)).astype(np.float32)).to(off.device)
+        a = off.rollout(T, actions=acts)
+        b = on.rollout(T, actions=acts)
+        torch.cuda.synchronize()
+        assert on.team_error() == 0
+        assert torch.equal(a["terminated"], b["terminated"]) and torch.equal(a["truncated"], b["truncated"])
+        if packed_possible:
+            torch.testing.assert_close(a["obs"], b["obs"], rtol=3e-6, atol=3e-6 * max(1.0, float(a["obs"].abs().max())))
+            torch.testing.assert_close(a["reward"], b["reward"], rtol=1e-6, atol=1e-6)
+        else:
+            assert torch.equal(a["obs"].view(torch.int32), b["obs"].view(torch.int32))
+            assert torch.equal(a["reward"].view(torch.int32), b["reward"].view(torch.int32))
+            assert torch.equal(a["episode_stats"].view(torch.int32), b["episode_stats"].view(torch.int32))
+        sa, sb = off.get_state(), on.get_state()
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), (T, k)
+        assert torch.equal(off.clock, on.clock)
+    off.close(); on.close()
