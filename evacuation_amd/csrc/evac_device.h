@@ -421,11 +421,11 @@ __device__ __forceinline__ void rollout_body(
     // Retire the state loads HERE, or their first use inside the loop puts `s_waitcnt vmcnt(0)` -- which
     // also waits for the previous step's stores -- into every iteration.
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
-    int pace_simd = 0, pace_k = 0;
+    // (the wave's place among its SIMD-mates: recomputed where it is used rather than held in two more scalar registers)
+#define EVAC_PACE_SIMD (F::WPE == 1 ? (w.slot & 3) : (w.wave_in_env & 3))
+#define EVAC_PACE_K (F::WPE == 1 ? (w.slot >> 2) : w.slot)
     if constexpr (EVAC_PRIO && F::kPace) {
-        pace_simd = F::WPE == 1 ? (w.slot & 3) : (w.wave_in_env & 3);
-        pace_k = F::WPE == 1 ? (w.slot >> 2) : w.slot;
-        if (w.lane == 0) sm.progress[pace_simd * 4 + pace_k] = 0;
+        if (w.lane == 0) sm.progress[EVAC_PACE_SIMD * 4 + EVAC_PACE_K] = 0;
     }
     // late in an episode two one-wave envs with at most 32 moving pedestrians each share a wave (evac_packed.h)
     if constexpr (GRAV && !DIAG && std::is_same<F, Wave<1, F::kBlock>>::value) {
@@ -454,7 +454,9 @@ __device__ __forceinline__ void rollout_body(
                 }
             }
         }
-        if constexpr (EVAC_PRIO && F::kPace) pace_step(sm, pace_simd, pace_k, w.lane, t);
+        if constexpr (EVAC_PRIO && F::kPace) pace_step(sm, EVAC_PACE_SIMD, EVAC_PACE_K, w.lane, t);
+#undef EVAC_PACE_SIMD
+#undef EVAC_PACE_K
         const int slot64 = t & 63;
         if (slot64 == 0) {
             if (actions) {

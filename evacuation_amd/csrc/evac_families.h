@@ -347,7 +347,7 @@ struct Wave {
                         X[r] = rp.x; Y[r] = rp.y;
                         ax[r] = 0.0f; ay[r] = 0.0f;
                     }
-                    constexpr int B = R <= 2 ? 8 : 4;                              // peers per LDS round trip (register budget)
+                    constexpr int B = (R <= 2 && !(kEnvBarrier && R == 2)) ? 8 : 4;   // peers per LDS round trip (register budget)
                     int j = jbeg;
                     for (; j + B <= jend; j += B) {
                         f4 t[B];

@@ -158,9 +158,13 @@ def test_kernel_resource_budgets():
         k = kernels[mangled]
         if any(t in name for t in ("k_step", "k_rollout", "k_reset", "k_observe")):
             assert k["vgpr_count"] <= 128, (name, k)
-        # the default faces of the production families: one wave per env, sub-wave, cell list
+        # the default faces of the production families: one wave per env (4- and 16-wave workgroups), sub-wave, cell list, teams
         headline = ("k_step" in name or "k_rollout" in name) and "diag" not in name and \
-                   ("Wave<1>" in name or "_sub<" in name or "Cells<" in name)
+                   ("Wave<1," in name or "_sub<" in name or "Cells<" in name or "Team<" in name)
         if headline:
             assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (name, k)
+        if "Wave<4, 1024>" in name:        # the CU-wide form of the four-wave envs: a few spilled scalars at most
+            assert k["private_segment_fixed_size"] <= 16, (name, k)
     assert sum("Cells<" in n and "k_rollout<" in n for n in names) == 8      # 4 sizes x 2 observation faces
+    assert sum("Team<" in n and "k_rollout<" in n for n in names) == 6       # 3 team sizes x 2 observation faces
+    assert sum("Wave<1, 1024>" in n for n in names) == 2 and sum("Wave<4, 1024>" in n for n in names) == 2
