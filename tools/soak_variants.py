@@ -1,0 +1,51 @@
+"""Long-run equality of the scheduling / decomposition devices against the plain kernels: many episodes, rewards, flags and
+final state compared bit for bit (any race in the team exchange or the per-env LDS barriers would show here).
+Run on the GPU box:  python tools/soak_variants.py [steps]"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import evacuation_amd as ea
+
+STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
+SW = ("EVAC_CU_WIDE", "EVAC_TEAM", "EVAC_PACK", "EVAC_WORKSPACE")
+
+
+def make(cfg, wrap, E, **env):
+    old = {k: os.environ.get(k) for k in SW}
+    for k in SW:
+        os.environ.pop(k, None)
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=123)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+
+ok = True
+for name, n, E, wrap_kw, T in (("C5 teams of 8 CUs", 1024, 32, dict(positions="rel", statuses="ohe", type="Box"), 100),
+                               ("C5 teams of 4 CUs", 1024, 64, dict(positions="grav", alpha=3), 50),
+                               ("C3 CU-wide", 256, 1024, dict(positions="grav", alpha=3), 100),
+                               ("C2 CU-wide + schedule", 60, 4096, dict(positions="grav", alpha=3), 100),
+                               ("C2 CU-wide, 20-step launches", 60, 4096, dict(positions="grav", alpha=3), 20)):
+    cfg = ea.EnvConfig(number_of_pedestrians=n, is_new_exiting_reward=True, is_new_followers_reward=True, max_timesteps=700)
+    wrap = ea.EnvWrappersConfig(**wrap_kw)
+    a = make(cfg, wrap, E, EVAC_CU_WIDE=0, EVAC_TEAM=0, EVAC_PACK=0, EVAC_WORKSPACE=0)
+    b = make(cfg, wrap, E)
+    a.reset(); b.reset()
+    t0 = time.time()
+    bad = 0
+    for k in range(STEPS // T):
+        ra, rb = a.rollout(T), b.rollout(T)
+        same = torch.equal(ra["slab"].view(torch.int32), rb["slab"].view(torch.int32)) and \
+            torch.equal(ra["episode_stats"].view(torch.int32), rb["episode_stats"].view(torch.int32))
+        bad += 0 if same else 1
+    torch.cuda.synchronize()
+    sa, sb = a.get_state(), b.get_state()
+    state_ok = all(torch.equal(sa[k], sb[k]) for k in sa) and torch.equal(a.acc, b.acc)
+    err = b.team_error()
+    print(f"{name:32s} {b.kernel_variant():70s} {STEPS} steps in {time.time() - t0:5.1f} s: launches that differ {bad}, final state equal {state_ok}, team_error {err}")
+    ok = ok and bad == 0 and state_ok and err == 0
+    a.close(); b.close()
+print("SOAK", "OK" if ok else "FAILED")
+sys.exit(0 if ok else 1)
