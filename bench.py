@@ -411,6 +411,8 @@ def main(argv=None):
     dense_l = [a.elapsed_time(b) * 1e-3 for a, b, t in block_events[dense_b] if t == inner]
     kernel_dense_s = (sorted(dense_l)[len(dense_l) // 2] - event_overhead_s) if dense_l else kernel_s
     full = per_launch
+    if loc.team_error():                                      # a team barrier timed out somewhere above: the numbers are void
+        raise SystemExit("bench.py: evac_team_error is set (a team rollout lost a member); results discarded")
     bytes_per_env_step = loc.algorithmic_bytes_per_env_step
     bytes_per_launch = bytes_per_env_step * E * inner
     achieved = bytes_per_launch / kernel_s / 1e9
