@@ -62,6 +62,13 @@ int main(int argc, char** argv) {
     hipStream_t stream;
     HIP_OK(hipStreamCreate(&stream));
     EVAC_OK_(evac_bind_state(h, ped, status, agent, clock, acc), h);
+    // optional workspace (load schedule of large batches, exchange areas of the team kernels): zero-initialised, 256-byte
+    // aligned (hipMalloc aligns to 256 B); results are bit-identical with and without it
+    void* workspace = nullptr;
+    const int64_t ws_bytes = evac_workspace_bytes(h);
+    HIP_OK(hipMalloc(&workspace, (size_t)ws_bytes));
+    HIP_OK(hipMemset(workspace, 0, (size_t)ws_bytes));
+    EVAC_OK_(evac_bind_workspace(h, workspace, ws_bytes), h);
     EVAC_OK_(evac_reset(h, nullptr, nullptr, obs, stream), h);
     EVAC_OK_(evac_rollout(h, T, nullptr, nullptr, slab, nullptr, 0, nullptr, nullptr, stream), h);      // the checked launch
     HIP_OK(hipStreamSynchronize(stream));
@@ -80,7 +87,7 @@ int main(int argc, char** argv) {
                 "\"env_steps_per_s\": %.4e, \"slab_fnv1a\": \"%016llx\"}\n",
                 E, N, T, (long long)D, (double)E * T * reps / dt, (unsigned long long)fnv);
     evac_destroy(h);
-    void* bufs[] = {ped, status, agent, clock, acc, obs, slab};
+    void* bufs[] = {ped, status, agent, clock, acc, obs, slab, workspace};
     for (void* b : bufs) (void)hipFree(b);
     return 0;
 }
