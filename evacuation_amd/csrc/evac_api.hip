@@ -66,6 +66,7 @@ struct evac_handle {
     bool cells;         // workgroup-per-env kernels with the cell list (N > 64) instead of all pairs
     bool cu_wide;       // rollouts of one-wave envs in CU-wide workgroups (the batch fills every CU with 16 envs)
     bool cu_wide4;      // the same for four-wave envs (4 envs per CU-wide workgroup)
+    bool default_cfg;   // the configuration the specialised rollout kernels assume (k_rollout_default_config)
     int team_k;         // rollouts of 513..1024-pedestrian envs by teams of 2 / 4 / 8 workgroups per env (0: one workgroup per env)
     int32_t* sched;     // inside the caller's workspace (evac_bind_workspace): moving[E] | perm[E], or NULL
     int sched_age;      // env steps rolled out since the schedule was last rebuilt (< 0: never built)
@@ -262,7 +263,14 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         h->cu_wide4 = h->sub_lanes == 0 && wpe == 4 && !h->cells &&
                       (cw && cw[0] == '1' ? true : (cw && cw[0] == '0' ? false : (num_envs >= 4 * cus && num_envs <= 16 * cus)));
         const char* pk = std::getenv("EVAC_PACK");
+        const char* sp = std::getenv("EVAC_SPECIALIZE");     // EVAC_SPECIALIZE=0: always the generic kernels (A/B runs)
+        h->default_cfg = !(sp && sp[0] == '0');              // (completed below, once Params is filled)
         h->p.pack = (one_wave && cfg->positions == EVAC_POS_GRAV && pk && pk[0] == '1') ? 1 : 0;
+        const bool obs_default = cfg->positions == EVAC_POS_GRAV
+                                     ? p.grav_pow_int == 5
+                                     : (cfg->positions == EVAC_POS_REL && cfg->statuses == EVAC_STAT_OHE && cfg->type == EVAC_TYPE_BOX);
+        h->default_cfg = h->default_cfg && obs_default && !h->p.pack && p.small_noise == 2 && p.ens == 1.0f &&
+                         p.one_minus_ens == 0.0f && p.flags == (evac::kFlagNewExitingReward | evac::kFlagNewFollowersReward);
         h->sched = nullptr;
         h->sched_age = -1;
         // teams: as many CUs per env as the batch leaves free -- all members must be resident together (one 1024-thread
@@ -455,17 +463,23 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
         if (hipMemsetAsync(h->p.team_ctr, 0, (size_t)E * 128, s_) != hipSuccess) return fail(h, EVAC_ERR_HIP, "evac_rollout: hipMemsetAsync failed");
         const dim3 grid((unsigned)((E + 7) / 8 * 8 * K)), block(1024);
         const bool grav = h->p.obs_pos == EVAC_POS_GRAV;
-#define EVAC_LAUNCH_TEAM(K_)                                                                                              \
+#define EVAC_LAUNCH_TEAM_K(KERNEL, K_)                                                                                    \
     do {                                                                                                                  \
-        if (grav) hipLaunchKernelGGL((evac::k_rollout<evac::Team<K_>, true>), grid, block, 0, s_, h->p, (int)n_steps,      \
+        if (grav) hipLaunchKernelGGL((evac::KERNEL<evac::Team<K_>, true>), grid, block, 0, s_, h->p, (int)n_steps,         \
                                      (const float2*)actions, slab_out, final_stats, (const int*)nullptr, (int*)nullptr);   \
-        else hipLaunchKernelGGL((evac::k_rollout<evac::Team<K_>, false>), grid, block, 0, s_, h->p, (int)n_steps,          \
+        else hipLaunchKernelGGL((evac::KERNEL<evac::Team<K_>, false>), grid, block, 0, s_, h->p, (int)n_steps,             \
                                 (const float2*)actions, slab_out, final_stats, (const int*)nullptr, (int*)nullptr);        \
+    } while (0)
+#define EVAC_LAUNCH_TEAM(K_)                                                               \
+    do {                                                                                   \
+        if (h->default_cfg) EVAC_LAUNCH_TEAM_K(k_rollout_default_config, K_);              \
+        else EVAC_LAUNCH_TEAM_K(k_rollout, K_);                                            \
     } while (0)
         if (K == 8) EVAC_LAUNCH_TEAM(8);
         else if (K == 4) EVAC_LAUNCH_TEAM(4);
         else EVAC_LAUNCH_TEAM(2);
 #undef EVAC_LAUNCH_TEAM
+#undef EVAC_LAUNCH_TEAM_K
     } else if (h->cu_wide || h->cu_wide4) {
         // one-wave envs, batch >= 16 envs per CU: CU-wide workgroups, envs dealt to the SIMDs by load when a schedule scratch
         // is bound (rebuilt every 50..200 env steps: the loads drift slowly)
@@ -485,7 +499,13 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
         if (h->sched) h->sched_age += n_steps;
         if (h->cu_wide4) {
             const dim3 grid4((unsigned)((E + FW4::kEnvsPerBlock - 1) / FW4::kEnvsPerBlock));
-            if (h->p.obs_pos == EVAC_POS_GRAV)
+            if (h->default_cfg && h->p.obs_pos == EVAC_POS_GRAV)
+                hipLaunchKernelGGL((evac::k_rollout_default_config<FW4, true>), grid4, dim3(FW4::kBlock), 0, s_, h->p, (int)n_steps,
+                                   (const float2*)actions, slab_out, final_stats, (const int*)perm, (int*)moving);
+            else if (h->default_cfg)
+                hipLaunchKernelGGL((evac::k_rollout_default_config<FW4, false>), grid4, dim3(FW4::kBlock), 0, s_, h->p, (int)n_steps,
+                                   (const float2*)actions, slab_out, final_stats, (const int*)perm, (int*)moving);
+            else if (h->p.obs_pos == EVAC_POS_GRAV)
                 hipLaunchKernelGGL((evac::k_rollout<FW4, true>), grid4, dim3(FW4::kBlock), 0, s_, h->p, (int)n_steps, (const float2*)actions,
                                    slab_out, final_stats, (const int*)perm, (int*)moving);
             else
@@ -494,13 +514,22 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
             return check_launch(h, "evac_rollout");
         }
         const dim3 grid((unsigned)((E + FW::kEnvsPerBlock - 1) / FW::kEnvsPerBlock));
-        if (h->p.obs_pos == EVAC_POS_GRAV)
+        if (h->default_cfg && h->p.obs_pos == EVAC_POS_GRAV)
+            hipLaunchKernelGGL((evac::k_rollout_default_config<FW, true>), grid, dim3(FW::kBlock), 0, s_, h->p, (int)n_steps,
+                               (const float2*)actions, slab_out, final_stats, (const int*)perm, (int*)moving);
+        else if (h->default_cfg)
+            hipLaunchKernelGGL((evac::k_rollout_default_config<FW, false>), grid, dim3(FW::kBlock), 0, s_, h->p, (int)n_steps,
+                               (const float2*)actions, slab_out, final_stats, (const int*)perm, (int*)moving);
+        else if (h->p.obs_pos == EVAC_POS_GRAV)
             hipLaunchKernelGGL((evac::k_rollout<FW, true>), grid, dim3(FW::kBlock), 0, s_, h->p, (int)n_steps, (const float2*)actions,
                                slab_out, final_stats, (const int*)perm, (int*)moving);
         else
             hipLaunchKernelGGL((evac::k_rollout<FW, false>), grid, dim3(FW::kBlock), 0, s_, h->p, (int)n_steps, (const float2*)actions,
                                slab_out, final_stats, (const int*)perm, (int*)moving);
-    } else
+    } else if (h->default_cfg)
+        EVAC_DISPATCH(h, k_rollout_default_config, stream, h->p, (int)n_steps, (const float2*)actions, slab_out, final_stats,
+                      (const int*)nullptr, (int*)nullptr);
+    else
         EVAC_DISPATCH(h, k_rollout, stream, h->p, (int)n_steps, (const float2*)actions, slab_out, final_stats, (const int*)nullptr,
                       (int*)nullptr);
     return check_launch(h, "evac_rollout");

@@ -249,13 +249,19 @@ __device__ __forceinline__ int simd_wave_slot() {   // slot of this wave among t
 
 // Pace keeping of the CU-wide workgroups: a wave publishes its step counter and takes as priority the number of its
 // SIMD-mates that are ahead of it (one-wave envs: wave w runs on SIMD w % 4; four-wave envs: wave k of every env on SIMD k).
+// Cost per step: one LDS write, one LDS read whose result is used a whole step later (`seen`: a hint may be a step old, and
+// the wave never waits for the round trip), one compare + popcount, and the s_setprio switch only when the rank changes.
 template <class Smem>
-__device__ __forceinline__ void pace_step(Smem& sm, int simd, int k, int lane, int t) {   // this wave: the SIMD's k-th
+__device__ __forceinline__ void pace_step(Smem& sm, int simd, int k, int lane, int t, int& seen, int& prio) {   // this wave: the SIMD's k-th
     int* mine = &sm.progress[simd * 4];
     if (lane == 0) mine[k] = t;
-    const i4 pr = *(const i4*)mine;     // the mates' counters may be a step old: good enough
-    const int ahead = (pr.x > t ? 1 : 0) + (pr.y > t ? 1 : 0) + (pr.z > t ? 1 : 0) + (pr.w > t ? 1 : 0);
-    set_wave_priority(__builtin_amdgcn_readfirstlane(ahead));
+    const unsigned ahead_mask = (unsigned)ballot(seen >= t) & 0xfu;   // lanes 0..3 hold the four counters as read one step ago
+    seen = mine[lane & 3];
+    const int ahead = __popc(ahead_mask) & 3;                          // (t = 0: the zero-initialised `seen` counts all four: & 3)
+    if (ahead != prio) {
+        prio = ahead;
+        set_wave_priority(ahead);
+    }
 }
 
 }  // namespace evac
@@ -440,6 +446,8 @@ __device__ __forceinline__ void rollout_body(
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0_)::"memory");
     const unsigned long long ck0_ = w.stamp.last;
 #endif
+    int pace_seen = 0, pace_prio = 0;
+    int staged = 0;                       // t % kStageSteps: the slot of the step in the staging block
     for (int t = 0; t < n_steps; ++t) {
         if constexpr (kRotate) {
             if (p.fair) {
@@ -454,7 +462,7 @@ __device__ __forceinline__ void rollout_body(
                 }
             }
         }
-        if constexpr (EVAC_PRIO && F::kPace) pace_step(sm, EVAC_PACE_SIMD, EVAC_PACE_K, w.lane, t);
+        if constexpr (EVAC_PRIO && F::kPace) pace_step(sm, EVAC_PACE_SIMD, EVAC_PACE_K, w.lane, t, pace_seen, pace_prio);
 #undef EVAC_PACE_SIMD
 #undef EVAC_PACE_K
         const int slot64 = t & 63;
@@ -482,9 +490,14 @@ __device__ __forceinline__ void rollout_body(
         if constexpr (F::kHelpers) draws = !w.helper;
         if (draws && (!have || sel == 0u) && !(EVAC_ABLATE & 4)) {
             nzr = philox4x32_10(make_uint4(gid, (uint32_t)w.i, e.total >> 2, kStreamNoise), p.seed_lo, p.seed_hi);
+            // word `total & 3` of the call is this step's draw: the words are ROTATED so that it always sits in .x (a uniform
+            // four-way select costs ~10 scalar instructions and three branches per step); a launch that starts inside a
+            // group of four steps rotates to its word first
+            for (uint32_t k = 0; k < sel; ++k) nzr = make_uint4(nzr.y, nzr.z, nzr.w, nzr.x);
             have = true;
         }
-        const uint32_t wsel = sel == 0 ? nzr.x : (sel == 1 ? nzr.y : (sel == 2 ? nzr.z : nzr.w));
+        const uint32_t wsel = nzr.x;
+        nzr = make_uint4(nzr.y, nzr.z, nzr.w, nzr.x);
         float nz = (u01(wsel) - 0.5f) * p.noise_coef;
         if constexpr (DIAG) {
             if (noise_in) nz = active ? noise_in[((size_t)t * E + w.env) * p.n_ped + w.i] : 0.0f;   // injection mode
@@ -521,7 +534,6 @@ __device__ __forceinline__ void rollout_body(
         const float f_term = o.terminated ? 1.0f : 0.0f, f_trunc = o.truncated ? 1.0f : 0.0f;
         if constexpr (GRAV) {
             if constexpr (!(EVAC_ABLATE & 16)) {
-                const int staged = t % kStageSteps;                 // slot of this step in the staging block (scalar)
                 if (w.owner) {
                     float* st = sm.stage[w.slot][staged];
                     *(f4*)(st + 0) = f4{o6[0], o6[1], o6[2], o6[3]};
@@ -537,6 +549,7 @@ __device__ __forceinline__ void rollout_body(
                         }
                     }
                 }
+                staged = staged == kStageSteps - 1 ? 0 : staged + 1;
             }
         } else {
             if constexpr (!(EVAC_ABLATE & 2)) write_obs_generic(p, w.i, active, q, e, StorePlain{rowp});
@@ -580,6 +593,37 @@ __global__ __launch_bounds__(F::kBlock, 4) void k_rollout(
     evac_episode_stats_t* __restrict__ final_stats, const int* __restrict__ perm, int* __restrict__ moving_out) {
     __shared__ typename F::Smem sm;
     rollout_body<F, GRAV, false>(sm, p, n_steps, actions, nullptr, slab_out, final_stats, 0, nullptr, nullptr, perm, moving_out);
+}
+
+// The same kernel specialised for the reference's default configuration (what its training scripts and the benchmark run):
+// |noise| <= 0.2, enslaving_degree 1, both status rewards on, no wall termination, no NaN guard, no action clipping, no
+// packing; and either the gravity observation with alpha = 3 or the Box observation of relative positions + one-hot statuses.  The options are wave-uniform branches in the generic kernel -- a compare, a
+// branch and often a taken jump each, ~50 scalar instructions of a step whose cost for a lone wave is its instruction count
+// times ~8 cycles; here they are constants the compiler folds.  Same arithmetic on the path taken: bit-identical results
+// (tests/test_gpu_schedule.py runs both).  The host picks it when the handle's configuration matches (evac_create).
+template <bool GRAV>
+__device__ __forceinline__ Params default_config_constants(Params p) {
+    p.flags = kFlagNewExitingReward | kFlagNewFollowersReward;
+    p.small_noise = 2;
+    p.ens = 1.0f;
+    p.one_minus_ens = 0.0f;
+    p.pack = 0;
+    if constexpr (GRAV) {
+        p.grav_pow_int = 5;                       // gravity observation with alpha = 3 (wrappers/config.py default)
+    } else {
+        p.obs_pos = EVAC_POS_REL;                 // the Box observation of BASELINE config 5: relative positions + one-hot statuses
+        p.obs_stat = EVAC_STAT_OHE;
+        p.obs_box = 1;
+    }
+    return p;
+}
+template <class F, bool GRAV>
+__global__ __launch_bounds__(F::kBlock, 4) void k_rollout_default_config(
+    Params p, int n_steps, const float2* __restrict__ actions, float* __restrict__ slab_out,
+    evac_episode_stats_t* __restrict__ final_stats, const int* __restrict__ perm, int* __restrict__ moving_out) {
+    __shared__ typename F::Smem sm;
+    const Params q = default_config_constants<GRAV>(p);
+    rollout_body<F, GRAV, false>(sm, q, n_steps, actions, nullptr, slab_out, final_stats, 0, nullptr, nullptr, perm, moving_out);
 }
 
 // The schedule of the CU-wide rollout workgroups: envs sorted by the pedestrians still moving (the length of their pair

@@ -126,8 +126,9 @@ __device__ __forceinline__ bool try_pack(typename FW::Smem& sm, const Params& p,
     const int fl_s = c.lane / kGravRow, fl_k = c.lane - fl_s * kGravRow;
     int prio_slot = 0;
     if constexpr (EVAC_PRIO && !FW::kPace) prio_slot = simd_wave_slot();
+    int pace_seen = 0, pace_prio = 0;
     for (int t = 0; t < n_steps; ++t) {
-        if constexpr (EVAC_PRIO && FW::kPace) pace_step(sm, w.slot & 3, w.slot >> 2, w.lane, t);
+        if constexpr (EVAC_PRIO && FW::kPace) pace_step(sm, w.slot & 3, w.slot >> 2, w.lane, t, pace_seen, pace_prio);
         else if constexpr (EVAC_PRIO != 0) {
             if (p.fair) set_wave_priority(t + prio_slot);
         }

@@ -104,3 +104,36 @@ def test_schedule_balances_simd_groups(ea):
         lo, hi = q[k * E // 4], q[(k + 1) * E // 4 - 1]
         assert ((slot_load[:, k, :] >= lo) & (slot_load[:, k, :] <= hi)).all()
     env.close()
+
+
+@pytest.mark.parametrize("n,E,cu_wide,box", [(60, 333, False, False), (60, 333, True, False), (10, 500, False, False), (30, 200, False, True),
+                                              (256, 37, False, False), (256, 37, True, False), (100, 50, False, True),
+                                              (1024, 8, False, True), (1024, 40, False, True), (700, 12, False, False)])
+def test_default_config_kernel_is_bit_identical(ea, n, E, cu_wide, box):
+    """The rollout kernels specialised for the reference's default configuration (k_rollout_default_config: gravity
+    observation with alpha = 3, or the Box of relative positions + one-hot statuses) against the generic ones
+    (EVAC_SPECIALIZE=0), for every kernel family: sub-wave, one wave, multi-wave, CU-wide, teams, cell list."""
+    import torch
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=90, is_new_exiting_reward=True, is_new_followers_reward=True)
+    wrap = ea.EnvWrappersConfig(positions="rel", statuses="ohe", type="Box") if box else ea.EnvWrappersConfig(positions="grav", alpha=3)
+    envs = []
+    for spec in ("0", "1"):
+        old = {k: os.environ.get(k) for k in ("EVAC_SPECIALIZE", "EVAC_CU_WIDE")}
+        try:
+            os.environ["EVAC_SPECIALIZE"] = spec
+            os.environ["EVAC_CU_WIDE"] = "1" if cu_wide else "0"
+            envs.append(ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=21))
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    gen, spec = envs
+    gen.reset(); spec.reset()
+    for T in (40, 100, 3, 64):
+        a, b = gen.rollout(T), spec.rollout(T)
+        torch.cuda.synchronize()
+        assert spec.team_error() == 0
+        assert torch.equal(a["slab"].view(torch.int32), b["slab"].view(torch.int32))
+        assert torch.equal(a["episode_stats"].view(torch.int32), b["episode_stats"].view(torch.int32))
+    sa, sb = gen.get_state(), spec.get_state()
+    assert all(torch.equal(sa[k], sb[k]) for k in sa) and torch.equal(gen.acc, spec.acc) and torch.equal(gen.clock, spec.clock)
+    gen.close(); spec.close()
