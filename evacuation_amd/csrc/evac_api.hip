@@ -270,7 +270,8 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
                                      ? p.grav_pow_int == 5
                                      : (cfg->positions == EVAC_POS_REL && cfg->statuses == EVAC_STAT_OHE && cfg->type == EVAC_TYPE_BOX);
         h->default_cfg = h->default_cfg && obs_default && !h->p.pack && p.small_noise == 2 && p.ens == 1.0f &&
-                         p.one_minus_ens == 0.0f && p.flags == (evac::kFlagNewExitingReward | evac::kFlagNewFollowersReward);
+                         p.one_minus_ens == 0.0f &&
+                         (p.flags & (evac::kFlagTermOnWall | evac::kFlagNanGuard)) == 0;
         h->sched = nullptr;
         h->sched_age = -1;
         // teams: as many CUs per env as the batch leaves free -- all members must be resident together (one 1024-thread
@@ -418,7 +419,9 @@ static int step_common(evac_handle_t h, const char* name, const float* actions, 
         return fail(h, EVAC_ERR_INVALID_ARGUMENT, std::string(name) + ": actions/obs/reward/terminated/truncated must be non-NULL");
     if ((uintptr_t)actions & 7u) return fail(h, EVAC_ERR_INVALID_ARGUMENT, std::string(name) + ": actions must be 8-byte aligned");
     DeviceGuard g(h->device);
-    if (na.state) EVAC_DISPATCH(h, k_step_norm, stream, EVAC_STEP_ARGS);
+    if (na.state && h->default_cfg) EVAC_DISPATCH(h, k_step_norm_default_config, stream, EVAC_STEP_ARGS);
+    else if (na.state) EVAC_DISPATCH(h, k_step_norm, stream, EVAC_STEP_ARGS);
+    else if (h->default_cfg) EVAC_DISPATCH(h, k_step_default_config, stream, EVAC_STEP_ARGS);
     else EVAC_DISPATCH(h, k_step_raw, stream, EVAC_STEP_ARGS);
     return check_launch(h, name);
 }

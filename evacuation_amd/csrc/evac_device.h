@@ -376,6 +376,25 @@ __device__ __forceinline__ void step_kernel_body(
                                 final_stats, na);
     store_env(p, w.env, w.i, active, w.owner, q, e);
 }
+// The reference's default configuration as compile-time constants (see k_rollout_default_config below).
+template <bool GRAV>
+__device__ __forceinline__ Params default_config_constants(Params p) {
+    // no wall termination, no NaN guard; the two status rewards and ClipAction stay run-time options (the reference's scripts
+    // differ in them: run_scripts/*.sh; the trainer clips)
+    p.flags = p.flags & (kFlagClipAction | kFlagNewExitingReward | kFlagNewFollowersReward);
+    p.small_noise = 2;
+    p.ens = 1.0f;
+    p.one_minus_ens = 0.0f;
+    p.pack = 0;
+    if constexpr (GRAV) {
+        p.grav_pow_int = 5;                       // gravity observation with alpha = 3 (wrappers/config.py default)
+    } else {
+        p.obs_pos = EVAC_POS_REL;                 // the Box observation of BASELINE config 5: relative positions + one-hot statuses
+        p.obs_stat = EVAC_STAT_OHE;
+        p.obs_box = 1;
+    }
+    return p;
+}
 // evac_step / evac_step_normalized
 #define EVAC_STEP_KERNEL(NAME, NORM_)                                                                                          \
     template <class F, bool GRAV>                                                                                              \
@@ -390,6 +409,20 @@ __device__ __forceinline__ void step_kernel_body(
 EVAC_STEP_KERNEL(k_step_raw, false)
 EVAC_STEP_KERNEL(k_step_norm, true)
 #undef EVAC_STEP_KERNEL
+#define EVAC_STEP_KERNEL_DEFAULT(NAME, NORM_)                                                                                  \
+    template <class F, bool GRAV>                                                                                              \
+    __global__ __launch_bounds__(F::kBlock, 4) void NAME(                                                                       \
+        Params p, const float2* __restrict__ actions, const float* __restrict__ noise_in, float* __restrict__ obs_out,          \
+        float* __restrict__ reward_out, uint8_t* __restrict__ term_out, uint8_t* __restrict__ trunc_out, int autoreset,         \
+        float* __restrict__ final_obs, evac_episode_stats_t* __restrict__ final_stats, NormArgs na) {                           \
+        __shared__ typename F::Smem sm;                                                                                         \
+        const Params q = default_config_constants<GRAV>(p);                                                                     \
+        step_kernel_body<F, GRAV, NORM_>(sm, q, actions, noise_in, obs_out, reward_out, term_out, trunc_out, autoreset, final_obs, \
+                                         final_stats, na);                                                                      \
+    }
+EVAC_STEP_KERNEL_DEFAULT(k_step_default_config, false)
+EVAC_STEP_KERNEL_DEFAULT(k_step_norm_default_config, true)
+#undef EVAC_STEP_KERNEL_DEFAULT
 
 // T steps per launch, state in registers (rpo_agent.py:180-203 rollout loop, RandomAgent or given actions).
 // Output: ONE packed f32 slab [T][E][D+3] = [obs(D) | reward | terminated | truncated] -- a single message
@@ -596,27 +629,11 @@ __global__ __launch_bounds__(F::kBlock, 4) void k_rollout(
 }
 
 // The same kernel specialised for the reference's default configuration (what its training scripts and the benchmark run):
-// |noise| <= 0.2, enslaving_degree 1, both status rewards on, no wall termination, no NaN guard, no action clipping, no
-// packing; and either the gravity observation with alpha = 3 or the Box observation of relative positions + one-hot statuses.  The options are wave-uniform branches in the generic kernel -- a compare, a
+// |noise| <= 0.2, enslaving_degree 1, no wall termination, no NaN guard, no packing; and either the gravity observation
+// with alpha = 3 or the Box observation of relative positions + one-hot statuses.  The options are wave-uniform branches in the generic kernel -- a compare, a
 // branch and often a taken jump each, ~50 scalar instructions of a step whose cost for a lone wave is its instruction count
 // times ~8 cycles; here they are constants the compiler folds.  Same arithmetic on the path taken: bit-identical results
 // (tests/test_gpu_schedule.py runs both).  The host picks it when the handle's configuration matches (evac_create).
-template <bool GRAV>
-__device__ __forceinline__ Params default_config_constants(Params p) {
-    p.flags = kFlagNewExitingReward | kFlagNewFollowersReward;
-    p.small_noise = 2;
-    p.ens = 1.0f;
-    p.one_minus_ens = 0.0f;
-    p.pack = 0;
-    if constexpr (GRAV) {
-        p.grav_pow_int = 5;                       // gravity observation with alpha = 3 (wrappers/config.py default)
-    } else {
-        p.obs_pos = EVAC_POS_REL;                 // the Box observation of BASELINE config 5: relative positions + one-hot statuses
-        p.obs_stat = EVAC_STAT_OHE;
-        p.obs_box = 1;
-    }
-    return p;
-}
 template <class F, bool GRAV>
 __global__ __launch_bounds__(F::kBlock, 4) void k_rollout_default_config(
     Params p, int n_steps, const float2* __restrict__ actions, float* __restrict__ slab_out,

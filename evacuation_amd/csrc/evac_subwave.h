@@ -117,6 +117,20 @@ __device__ __forceinline__ void step_kernel_body_sub(
 EVAC_STEP_KERNEL_SUB(k_step_raw_sub, false)
 EVAC_STEP_KERNEL_SUB(k_step_norm_sub, true)
 #undef EVAC_STEP_KERNEL_SUB
+#define EVAC_STEP_KERNEL_SUB_DEFAULT(NAME, NORM_)                                                                               \
+    template <int G, bool GRAV>                                                                                                \
+    __global__ __launch_bounds__(256) void NAME(                                                                                \
+        Params p, const float2* __restrict__ actions, const float* __restrict__ noise_in, float* __restrict__ obs_out,          \
+        float* __restrict__ reward_out, uint8_t* __restrict__ term_out, uint8_t* __restrict__ trunc_out, int autoreset,         \
+        float* __restrict__ final_obs, evac_episode_stats_t* __restrict__ final_stats, NormArgs na) {                           \
+        __shared__ typename Sub<G>::Smem sm;                                                                                    \
+        const Params q = default_config_constants<GRAV>(p);                                                                     \
+        step_kernel_body_sub<G, GRAV, NORM_>(sm, q, actions, noise_in, obs_out, reward_out, term_out, trunc_out, autoreset,      \
+                                             final_obs, final_stats, na);                                                       \
+    }
+EVAC_STEP_KERNEL_SUB_DEFAULT(k_step_default_config_sub, false)
+EVAC_STEP_KERNEL_SUB_DEFAULT(k_step_norm_default_config_sub, true)
+#undef EVAC_STEP_KERNEL_SUB_DEFAULT
 
 template <int G, bool GRAV, bool DIAG>
 __device__ __forceinline__ void rollout_body_sub(typename Sub<G>::Smem& sm, const Params& p, int n_steps,

@@ -114,7 +114,9 @@ def test_default_config_kernel_is_bit_identical(ea, n, E, cu_wide, box):
     observation with alpha = 3, or the Box of relative positions + one-hot statuses) against the generic ones
     (EVAC_SPECIALIZE=0), for every kernel family: sub-wave, one wave, multi-wave, CU-wide, teams, cell list."""
     import torch
-    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=90, is_new_exiting_reward=True, is_new_followers_reward=True)
+    # (the status rewards and ClipAction stay run-time options of the specialised kernels: vary them with the case)
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=90, is_new_exiting_reward=bool(E % 2), is_new_followers_reward=bool(n % 3),
+                       clip_action=bool(E % 3 == 0))
     wrap = ea.EnvWrappersConfig(positions="rel", statuses="ohe", type="Box") if box else ea.EnvWrappersConfig(positions="grav", alpha=3)
     envs = []
     for spec in ("0", "1"):
@@ -134,6 +136,12 @@ def test_default_config_kernel_is_bit_identical(ea, n, E, cu_wide, box):
         assert spec.team_error() == 0
         assert torch.equal(a["slab"].view(torch.int32), b["slab"].view(torch.int32))
         assert torch.equal(a["episode_stats"].view(torch.int32), b["episode_stats"].view(torch.int32))
+    for _ in range(5):                                                     # and the step API (k_step_default_config)
+        act = torch.rand((E, 2), device=gen.device) * 2 - 1
+        o1, r1, t1, u1, _ = gen.step(act)
+        o2, r2, t2, u2, _ = spec.step(act)
+        assert torch.equal(o1.view(torch.int32), o2.view(torch.int32)) and torch.equal(r1.view(torch.int32), r2.view(torch.int32))
+        assert torch.equal(t1, t2) and torch.equal(u1, u2)
     sa, sb = gen.get_state(), spec.get_state()
     assert all(torch.equal(sa[k], sb[k]) for k in sa) and torch.equal(gen.acc, spec.acc) and torch.equal(gen.clock, spec.clock)
     gen.close(); spec.close()
