@@ -297,11 +297,12 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
                           wpe == 1 ? evac::Wave<1>::kName :
                           h->cells ? (wpe == 2 ? evac::Cells<2>::kName : wpe == 4 ? evac::Cells<4>::kName : wpe == 8 ? evac::Cells<8>::kName : evac::Cells<16>::kName)
                                    : (wpe == 2 ? evac::Wave<2>::kName : wpe == 4 ? evac::Wave<4>::kName : wpe == 8 ? evac::Wave<8>::kName : evac::Wave<16>::kName);
-        h->variant[0] = "k_step<" + fam + (grav ? ", grav obs>" : ", generic obs>");
+        const char* kind = h->default_cfg ? "_default_config<" : "<";     // (the names rocprofv3 shows)
+        h->variant[0] = std::string("k_step") + kind + fam + (grav ? ", grav obs>" : ", generic obs>");
         if (h->cu_wide) fam = evac::Wave<1, 1024>::kName;
         if (h->cu_wide4) fam = evac::Wave<4, 1024>::kName;
         if (h->team_k) fam = h->team_k == 8 ? evac::Team<8>::kName : (h->team_k == 4 ? evac::Team<4>::kName : evac::Team<2>::kName);
-        h->variant[1] = "k_rollout<" + fam + (grav ? ", grav obs>" : ", generic obs>");
+        h->variant[1] = std::string("k_rollout") + kind + fam + (grav ? ", grav obs>" : ", generic obs>");
     }
     *out = h;
     return EVAC_OK;

@@ -23,7 +23,11 @@
  * forbids / forces the team rollout kernels of rooms of more than 512 pedestrians (default: as many CUs per env as the batch leaves
  * free; not under EVAC_CELLS); all of them give bit-identical results.  EVAC_PACK=1 lets rollouts of one-wave envs with a
  * gravity observation run two late-episode envs (<= 32 moving pedestrians each, no episode end possible inside the launch) in
- * one wave: trajectories, flags and rewards stay bit-identical, the summed observations agree to f32 rounding (default off).  The Python host honours EVAC_WORKSPACE=0 (no workspace) and
+ * one wave: trajectories, flags and rewards stay bit-identical, the summed observations agree to f32 rounding (default off).
+ * EVAC_SPECIALIZE=0 keeps handles of the reference's default configuration (enslaving_degree 1, |noise_coef| <= 0.4, alpha 3 gravity
+ * observation or rel + ohe Box, no wall termination) on the generic kernels instead of the k_*_default_config instantiations in
+ * which those uniform parameters are compile-time constants (bit-identical, tests/test_gpu_schedule.py).
+ * The Python host honours EVAC_WORKSPACE=0 (no workspace) and
  * EVAC_LIB=<path> to load a profiling build of this library instead of evacuation_amd/libevac.so.
  *
  * Device layouts (row-major, E = num_envs, N = n_ped)

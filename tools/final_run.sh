@@ -13,6 +13,8 @@ python ../../bench.py --workload big --mode step --steps 100 --warmup 20 --block
 python ../../bench.py --workload c2 --envs 65536 --no-cpu-baseline --no-step-api > bench_c2_65536.json 2>/dev/null
 EVAC_CU_WIDE=0 python ../../bench.py --no-cpu-baseline --no-step-api > bench_c2_256thread_workgroups.json 2>/dev/null
 EVAC_WORKSPACE=0 python ../../bench.py --no-cpu-baseline --no-step-api > bench_c2_no_schedule.json 2>/dev/null
+EVAC_SPECIALIZE=0 python ../../bench.py --no-cpu-baseline > bench_c2_generic_kernel.json 2>/dev/null
+EVAC_SPECIALIZE=0 python ../../bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-step-api > bench_c2_driver_generic_kernel.json 2>/dev/null
 python ../../tools/subwave_bench.py > subwave.txt 2>&1
 python ../../examples/rollout_with_policy.py > policy_example.txt 2>&1
 python ../../tools/moving_distribution.py > moving_distribution.txt 2>&1
