@@ -132,7 +132,7 @@ struct Wave {
             if (c.lane == 0) {
                 int* ctr = &c.sm.bar[c.slot];
                 const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int target = (old / WPE + 1) * WPE;
+                const int target = (old & ~(WPE - 1)) + WPE;      // (WPE is a power of two, the counter only grows)
                 int spins = 0;       // (bounded: a lost sibling must not hang the GPU; it cannot happen -- the env's waves run one code path)
                 while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(0);
             }
@@ -189,11 +189,12 @@ struct Wave {
             if constexpr (!GUARD && std::is_same<typename C::Family, Wave>::value) {
                 // the step's own reduction: count 3 is "moves at the next step"; after the DPP steps lane w holds the sum
                 // over waves 0..w, i.e. the tile offsets of the next step's compaction -- no exchange, no barrier then
-                const int before = c.wave_in_env == 0 ? 0 : __builtin_amdgcn_readlane(ri.y, c.wave_in_env - 1);
+                const int wi = __builtin_amdgcn_readfirstlane(c.wave_in_env);      // (uniform: keeps the selects scalar)
+                const int before = wi == 0 ? 0 : __builtin_amdgcn_readlane(ri.y, max(wi - 1, 0));
                 c.next_base = before >> 16;
                 c.next_cols = __builtin_amdgcn_readlane(ri.y, WPE - 1) >> 16;
                 // count 5 is "needs its row at the next step": the offsets of the next step's ROW compaction, likewise
-                const int rbefore = c.wave_in_env == 0 ? 0 : __builtin_amdgcn_readlane(ri.z, c.wave_in_env - 1);
+                const int rbefore = wi == 0 ? 0 : __builtin_amdgcn_readlane(ri.z, max(wi - 1, 0));
                 c.next_rbase = rbefore >> 16;
                 c.next_rows = __builtin_amdgcn_readlane(ri.z, WPE - 1) >> 16;
                 c.have_next = true;
@@ -330,12 +331,16 @@ struct Wave {
             }
         } else {
             // this wave: up to kRows row slices (64 compacted rows each) of its group of kRows waves, column share `share`
-            const int share = c.wave_in_env % kRows, gbase = (c.wave_in_env - share) * kWave + c.lane;
-            const int slices = __builtin_amdgcn_readfirstlane(min(max((n_rows - (c.wave_in_env - share) * kWave + kWave - 1) / kWave, 0), kRows));
-            const int groups = (n_cols + 3) >> 2;                                  // peers in groups of 4 (padding weighs 0)
-            const int per = (groups + kRows - 1) / kRows;
-            const int jbeg = __builtin_amdgcn_readfirstlane(share * per * 4);
-            const int jend = __builtin_amdgcn_readfirstlane(min((share + 1) * per, groups) * 4);
+            // (all of this is wave-uniform: kept in scalar registers, unsigned so that the divisions are shifts)
+            const unsigned wu = (unsigned)__builtin_amdgcn_readfirstlane(c.wave_in_env);
+            const unsigned nc = (unsigned)__builtin_amdgcn_readfirstlane(n_cols), nr = (unsigned)__builtin_amdgcn_readfirstlane(n_rows);
+            const unsigned share_u = wu % (unsigned)kRows, first_row = (wu - share_u) * (unsigned)kWave;
+            const int share = (int)share_u, gbase = (int)first_row + c.lane;
+            const int slices = nr > first_row ? (int)min((nr - first_row + (unsigned)kWave - 1u) / (unsigned)kWave, (unsigned)kRows) : 0;
+            const unsigned groups = (nc + 3u) >> 2;                                // peers in groups of 4 (padding weighs 0)
+            const unsigned per = (groups + (unsigned)kRows - 1u) / (unsigned)kRows;
+            const int jbeg = (int)(share_u * per * 4u);
+            const int jend = (int)(min((share_u + 1u) * per, groups) * 4u);
             if constexpr (!(EVAC_ABLATE & 1)) {
                 // R row slices per lane (slots beyond n_rows hold stale positions: computed, never read)
                 auto sweep = [&](auto r_tag) {
