@@ -130,7 +130,10 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1
 // 24-bit uniform in [0,1): exact in f32
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * 0x1.0p-24f; }
 // U[-1,1): exact in f32 (pedestrians.py:17-18 draws U(-1,1); random_agent.py:8-9 samples Box(-1,1))
-__device__ __forceinline__ float usym(uint32_t x) { return 2.0f * u01(x) - 1.0f; }
+// (k * 2^-23 is exact, so the fused form rounds once like 2 * u01 - 1 does: same bits, one instruction less)
+__device__ __forceinline__ float usym(uint32_t x) { return __builtin_fmaf((float)(x >> 8), 0x1.0p-23f, -1.0f); }
+// u01 - 0.5, likewise
+__device__ __forceinline__ float u01_centred(uint32_t x) { return __builtin_fmaf((float)(x >> 8), 0x1.0p-24f, -0.5f); }
 
 // ------------------------------------------------------------------------------------------------
 // wave-level helpers
@@ -192,6 +195,15 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
 // Lane mask of a predicate.  HIP's __ballot(int) first materialises the bool as 0/1 in a VGPR and compares it with 0
 // again (v_cndmask + v_cmp per call); the builtin takes the condition's mask as it is.
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// Lanes whose value equals K, as ONE v_cmp into a scalar register pair.  ballot(v == K) is that too when the comparison is
+// its only user; when the compiler has the same comparison at hand as a lane bool (a select elsewhere) it turns the bool
+// into the mask with v_cndmask + v_cmp instead.
+template <int K>
+__device__ __forceinline__ unsigned long long mask_eq(int v) {
+    unsigned long long m;
+    asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(m) : "n"(K), "v"(v));
+    return m;
+}
 // Set bits of a ballot as a 32-bit value the compiler knows nothing else about: otherwise (float)count is expanded as a
 // 64-bit integer conversion (s_lshl_b64 / s_min / s_or / v_cvt / v_ldexp) because ctpop's operand is 64 bits wide.
 __device__ __forceinline__ int mask_count(unsigned long long m) {
@@ -540,7 +552,7 @@ __device__ __forceinline__ float philox_noise(const Params& p, uint32_t env_gid,
     const uint4 r = philox4x32_10(make_uint4(env_gid, (uint32_t)i, total >> 2, kStreamNoise), p.seed_lo, p.seed_hi);
     const uint32_t sel = total & 3u;
     const uint32_t w = sel == 0 ? r.x : (sel == 1 ? r.y : (sel == 2 ? r.z : r.w));
-    return (u01(w) - 0.5f) * p.noise_coef;                             // area.py:124: U(-c/2, c/2)
+    return u01_centred(w) * p.noise_coef;                              // area.py:124: U(-c/2, c/2)
 }
 __device__ __forceinline__ float2 philox_action(const Params& p, uint32_t env_gid, uint32_t total) {
     const uint4 r = philox4x32_10(make_uint4(env_gid, 0u, total, kStreamAction), p.seed_lo, p.seed_hi);

@@ -126,8 +126,15 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
         const float ndy = (cy * cs + cx * sn) * p.step_size;
         q.dx = fv ? ndx : q.dx;                                             // area.py:136
         q.dy = fv ? ndy : q.dy;
-        const float bdx = p.ens * e.adx + p.one_minus_ens * q.dx;           // area.py:139-142
-        const float bdy = p.ens * e.ady + p.one_minus_ens * q.dy;
+        float bdx, bdy;                                                     // area.py:139-142
+        if (__builtin_constant_p(p.one_minus_ens) && p.one_minus_ens == 0.0f) {
+            // (the default-configuration kernels: 0 * heading is exact, so the fused form has the same bits -- NaN * 0 included)
+            bdx = __builtin_fmaf(0.0f, q.dx, p.ens * e.adx);
+            bdy = __builtin_fmaf(0.0f, q.dy, p.ens * e.ady);
+        } else {
+            bdx = p.ens * e.adx + p.one_minus_ens * q.dx;
+            bdy = p.ens * e.ady + p.one_minus_ens * q.dy;
+        }
         q.dx = fol ? bdx : q.dx;
         q.dy = fol ? bdy : q.dy;
         q.x += efv ? q.dx : 0.0f;                                           // area.py:145
@@ -166,11 +173,14 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     }
     // per-step counts: the two reward transitions, escaped (termination) and followers (gravity exit term);
     // exiting / viscek counts are only part of the episode record and are taken at episode end.
-    pred[0] = ballot((old_st == kViscek || old_st == kFollower) && new_st == kExiting);    // reward.py:35-39
-    pred[1] = ballot(old_st == kViscek && new_st == kFollower);                             // reward.py:43-46
-    pred[2] = ballot(new_st == kEscaped);
+    // (conjunctions are taken on the MASKS: the ballot of a plain comparison is the comparison's own result register,
+    // the ballot of `a && b` costs a select and a second comparison)
+    const unsigned long long now_follower = ballot(new_st == kFollower);
+    pred[0] = ballot((unsigned)(old_st - kViscek) < 2u) & ballot(new_st == kExiting);      // reward.py:35-39
+    pred[1] = mask_eq<kViscek>(old_st) & now_follower;                                      // reward.py:43-46
+    pred[2] = mask_eq<kEscaped>(new_st);
     pred[3] = ballot((unsigned)(new_st - kViscek) < 3u);      // moves at the next step (only the multi-wave all-pairs family uses it)
-    pred[4] = ballot(new_st == kFollower);
+    pred[4] = now_follower;
     pred[5] = ballot(needs_row(p, new_st));                   // its row is needed at the next step (multi-wave all-pairs family)
     }   // work
     if constexpr (GRAV) F::exit_publish(c, exit_lane, gx, gy);
@@ -531,7 +541,7 @@ __device__ __forceinline__ void rollout_body(
         }
         const uint32_t wsel = nzr.x;
         nzr = make_uint4(nzr.y, nzr.z, nzr.w, nzr.x);
-        float nz = (u01(wsel) - 0.5f) * p.noise_coef;
+        float nz = u01_centred(wsel) * p.noise_coef;
         if constexpr (DIAG) {
             if (noise_in) nz = active ? noise_in[((size_t)t * E + w.env) * p.n_ped + w.i] : 0.0f;   // injection mode
         }
