@@ -181,6 +181,23 @@ __device__ __forceinline__ void wave_sum3(float& a, float& b, float& c) {
     b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 63));
     c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), 63));
 }
+// Two integer sums over the 64 lanes, the totals in LANE 63 (the row_shr / row_bcast scheme of wave_sum3, two chains
+// interleaved; the s_nop between the bcast steps is the DPP read-after-VALU-write wait state the third chain covers there).
+__device__ __forceinline__ void wave_sum2_int_lane63(int& a, int& b) {
+    a = dpp_addi<0x111, 0xf>(a); b = dpp_addi<0x111, 0xf>(b);
+    a = dpp_addi<0x112, 0xf>(a); b = dpp_addi<0x112, 0xf>(b);
+    a = dpp_addi<0x114, 0xf>(a); b = dpp_addi<0x114, 0xf>(b);
+    a = dpp_addi<0x118, 0xf>(a); b = dpp_addi<0x118, 0xf>(b);
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_u32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_u32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(a), "+v"(b));
+}
 // Inclusive prefix sum over the 64 lanes (Hillis-Steele inside each 16-lane row with row_shr 1/2/4/8, then the
 // row totals carried across with row_bcast:15 / row_bcast:31).
 __device__ __forceinline__ int wave_inclusive_scan(int v) {

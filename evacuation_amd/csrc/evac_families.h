@@ -248,8 +248,9 @@ struct Wave {
         // RandomAgent most pedestrians have escaped by mid-episode, so the all-pairs loop shrinks from N to
         // n_efv iterations.
         int n_cols, n_rows = 0, row_rank = 0;
+        unsigned long long moving_mask;
         {
-            const unsigned long long m = ballot(efv);
+            const unsigned long long m = moving_mask = ballot(efv);
             int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
             n_cols = __popcll(m);
             if constexpr (WPE > 1) {
@@ -287,7 +288,7 @@ struct Wave {
             if (fv) sm.rowpos[par][c.slot][row_rank] = make_float2(q.x * kTileScale, q.y * kTileScale);
             // The reference's NaN poisoning (a NaN heading makes every FOLLOWER / VISCEK row NaN, area.py:118-119) reaches the
             // evaluated rows through w * NaN; the followers whose rows are skipped get it through this flag.
-            if (ballot(efv && (ux != ux || uy != uy)) != 0ull && c.lane == 0) sm.poison[par][c.slot] = 1;
+            if ((ballot(ux != ux || uy != uy) & moving_mask) != 0ull && c.lane == 0) sm.poison[par][c.slot] = 1;   // (conjunction on the masks)
         }
         sync(c);   // tile complete
         bool poisoned = false;
@@ -305,7 +306,7 @@ struct Wave {
             // needed (step_env: needs_row).  No row at all -> no loop; then the reference's NaN poisoning, which the loop's
             // w * NaN carries otherwise, is applied by hand (it reaches the followers whose rows are not evaluated).
             const bool any_fv = ballot(fv) != 0ull;
-            if (!any_fv && ballot(efv && (ux != ux || uy != uy)) != 0ull) sx = sy = __builtin_nanf("");
+            if (!any_fv && (ballot(ux != ux || uy != uy) & moving_mask) != 0ull) sx = sy = __builtin_nanf("");
             // Branch-free batches: the B wave-uniform ds_read_b128 broadcasts are issued back to
             // back (LDS latency paid once per batch, no VALU slot), then 6 full-rate VALU ops per pair.
             const int n8 = __builtin_amdgcn_readfirstlane(any_fv ? ((n_cols + 3) & ~3) : 0);   // no rows -> no loop
@@ -705,7 +706,7 @@ struct Sub {
         const bool any_row = ballot(fv) != 0ull;
         const int n4 = any_row ? ((nmax + 3) & ~3) : 0;
         if (!any_row) {   // no loop: the NaN poisoning it would carry (area.py:118-119), per group
-            const unsigned long long m_nan = ballot(efv && (ux != ux || uy != uy));
+            const unsigned long long m_nan = ballot(ux != ux || uy != uy) & m_efv;
             if ((m_nan & c.gmask) != 0ull) sx = sy = __builtin_nanf("");
         }
         const f4* __restrict__ tile = sm.tile[c.slot];           // per lane: its group's tile

@@ -35,7 +35,46 @@ namespace evac {
 
 __device__ __forceinline__ void store_dev(void* ptr, f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
 __device__ __forceinline__ void store_dev_i32(void* ptr, int v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_add(int* ptr, int v) { (void)__hip_atomic_fetch_add(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Arrive at a device-scope counter and spin (ONE lane) until it has reached `target`: the arrival is a returning atomic -- its
+// result is the first sample, the last member to arrive never polls -- and the polls that follow keep TWO loads in flight
+// half a round trip apart, so that a waiting member notices the last arrival after half a load latency on average instead
+// of a whole one.  Returning atomics and loads return in issue order (vmcnt).  Bounded (2^20 rounds of two loads, a fraction of
+// a second); returns false on a timeout.  No other vector-memory operation may be outstanding on entry.
+__device__ __forceinline__ bool arrive_and_spin(unsigned* ctr, unsigned target) {
+    unsigned a, b;
+    int n;
+    asm volatile(
+        "s_mov_b32 %2, 0\n\t"
+        "global_atomic_add %0, %3, %5, off sc0\n\t"
+        "s_sleep 5\n\t"
+        "global_load_dword %1, %3, off sc1\n\t"
+        "s_waitcnt vmcnt(1)\n\t"
+        "v_add_u32 %0, 1, %0\n\t"
+        "s_branch 3f\n"
+        "1:\n\t"
+        "s_waitcnt vmcnt(1)\n"
+        "3:\n\t"
+        "v_sub_u32 %0, %0, %4\n\t"
+        "v_cmp_gt_i32 vcc, 0, %0\n\t"
+        "s_cbranch_vccz 2f\n\t"
+        "global_load_dword %0, %3, off sc1\n\t"
+        "s_waitcnt vmcnt(1)\n\t"
+        "v_sub_u32 %1, %1, %4\n\t"
+        "v_cmp_gt_i32 vcc, 0, %1\n\t"
+        "s_cbranch_vccz 2f\n\t"
+        "global_load_dword %1, %3, off sc1\n\t"
+        "s_add_u32 %2, %2, 1\n\t"
+        "s_cmp_lt_u32 %2, 0x100000\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(a), "=&v"(b), "=&s"(n)
+        : "v"(ctr), "v"(target), "v"(1u)
+        : "vcc", "scc", "memory");
+    return n < 0x100000;
+}
 
 template <int K_>
 struct Team {
@@ -47,15 +86,16 @@ struct Team {
     static constexpr int P = 1024 / K;                   // pedestrians per member
     static constexpr int PW = P / kWave;                 // ped waves per member
     static constexpr int kPad = 8;
+    static constexpr int kFewRows = 64;                  // needed rows of a member up to which the transposed sweep is used (neighbour_sum)
     static constexpr const char* kName = K == 8 ? "8 CUs/env, all pairs over the team's tile" : (K == 4 ? "4 CUs/env, all pairs over the team's tile" : "2 CUs/env, all pairs over the team's tile");
 
     struct Smem {
         f4 tile[1024 + kPad];                 // the team's moving pedestrians: (X, Y, heading x, heading y as integers)
         float2 rowpos[PW][kWave];             // this member's needed rows, compacted per ped wave
-        i2 part[WPE][PW][kWave];              // partial heading sums [column share][ped wave][row slot]
+        alignas(8) int acc[PW][kWave][2];                  // heading sums of the needed rows [ped wave][row slot]: integer LDS atomics of all 16 waves, cleared by their reader
         int rows[PW];                         // needed rows per ped wave
         int abort;                            // sticky: a barrier timed out
-        alignas(16) f4 red_f;                 // the folded records (wave 0 -> everybody)
+        alignas(16) f4 red_f;                 // the folded records (three helper waves -> everybody)
         alignas(16) i4 red_i;
         i2 seg[WPE];                          // where segment w of the exchange area lands in the tile: (offset, entries)
         i2 totals;                            // entries of the tile, NaN headings among them
@@ -97,6 +137,7 @@ struct Team {
     static __device__ __forceinline__ void invalidate(Ctx& c) { c.tile_valid = false; }   // the state changed outside step_env (autoreset)
     static __device__ __forceinline__ void init(Ctx& c) {
         if (threadIdx.x == 0) c.sm.abort = 0;
+        if (threadIdx.x < PW * kWave) *(i2*)c.sm.acc[threadIdx.x / kWave][threadIdx.x % kWave] = i2{0, 0};
         __syncthreads();
     }
 
@@ -108,16 +149,11 @@ struct Team {
         c.round += 1u;
         if (threadIdx.x == 0) {
             unsigned* ctr = p.team_ctr + (size_t)c.env * 32;
-            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!c.sm.abort) {
-                const unsigned target = c.round * (unsigned)K;
-                int spins = 0;
-                while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0 && ++spins < (1 << 21))
-                    __builtin_amdgcn_s_sleep(1);
-                if (spins >= (1 << 21)) {
-                    c.sm.abort = 1;
-                    __hip_atomic_store(p.team_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            if (c.sm.abort) {        // a lost team: keep counting, wait for nobody
+                __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (!arrive_and_spin(ctr, c.round * (unsigned)K)) {
+                c.sm.abort = 1;
+                __hip_atomic_store(p.team_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         __syncthreads();
@@ -139,7 +175,7 @@ struct Team {
             const int hx = (int)__builtin_rintf(ux * hs), hy = (int)__builtin_rintf(uy * hs);
             store_dev(gtile + c.wave_in_env * kWave + col_rank, f4{X, Y, __builtin_bit_cast(float, hx), __builtin_bit_cast(float, hy)});
         }
-        const int n_nan = __popcll(ballot(efv && (ux != ux || uy != uy)));
+        const int n_nan = __popcll(ballot(ux != ux || uy != uy) & m_col);   // (conjunction on the masks)
         if (c.lane == 0) {
             store_dev_i32(gcnt + c.wave_in_env, __popcll(m_col) | (n_nan << 16));
             sm.rows[c.wave] = __popcll(m_row);
@@ -210,33 +246,47 @@ struct Team {
         EVAC_T(c, 12);   // (sub-phase: per-pedestrian work of the ped waves / waiting for them, record stores)
         team_round(p, c);
         EVAC_T(c, 13);   // (sub-phase: the team barrier)
-        // ONE load phase.  Wave 0 reads the 16 records (lane w: record w) and the 16 segment counts, folds the records and
-        // leaves the result in LDS for the other waves (every wave reading them itself costs 7 device-scope loads of the
-        // same three cache lines by 128 waves of a team: 5000 cycles of the step); every wave reads entry `lane` of the
-        // segment of ped wave `c.wave` (wave w of every member gathers segment w; which of its 64 entries are real is known
-        // from the counts, so that load need not wait for them).
+        // ONE load phase.  Every wave reads entry `lane` of the segment of ped wave `c.wave` (wave w of every member gathers
+        // segment w; which of its 64 entries are real is known from the counts, so that load need not wait for them).  Three
+        // HELPER waves read, in the same statement, the 16 records (lane w: record w) resp. the 16 segment counts, fold them
+        // and leave the result in LDS for everybody: the float sums, the packed counts and the prefix of the segment counts are
+        // independent chains, and the ped waves -- the critical path of the step -- only fetch their tile entry.  (Every wave
+        // folding for itself costs 7 device-scope loads of the same three cache lines by 128 waves of a team: 5000 cycles of
+        // the step.)
+        static_assert(PW + 2 < WPE, "three helper waves fold the records");
         const f4* gtile = (const f4*)p.team_tile + ((size_t)c.par_tile * p.n_envs + c.env) * 1024 + c.wave * kWave + c.lane;
+        const int w = c.lane < WPE ? c.lane : WPE - 1;
         f4 ev;
-        if (c.wave == 0) {
-            const int w = c.lane < WPE ? c.lane : WPE - 1;
-            const int* gcnt = (const int*)p.team_cnt + ((size_t)c.par_tile * p.n_envs + c.env) * WPE + w;
-            f4 rf, rb;
-            int cw;
-            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
-                         "global_load_dwordx4 %2, %5, off sc1\n\tglobal_load_dword %3, %6, off sc1\n\ts_waitcnt vmcnt(0)"
-                         : "=&v"(rf), "=&v"(rb), "=&v"(ev), "=&v"(cw) : "v"(rec + 2 * w), "v"(gtile), "v"(gcnt) : "memory");
+        if (c.wave == PW) {                 // the float sums: the fold of Wave<16>::reduce, instruction for instruction (same tree, same rounding)
+            f4 rf;
+            asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(rf), "=&v"(ev) : "v"(rec + 2 * w), "v"(gtile) : "memory");
+#define EVAC_RED_STEP(CTRL) rf.x = dpp_add<CTRL, 0xf>(rf.x); rf.y = dpp_add<CTRL, 0xf>(rf.y); rf.z = dpp_add<CTRL, 0xf>(rf.z);
+            EVAC_RED_STEP(0x111)
+            EVAC_RED_STEP(0x112)
+            EVAC_RED_STEP(0x114)
+            EVAC_RED_STEP(0x118)
+#undef EVAC_RED_STEP
+            if (c.lane == WPE - 1) c.sm.red_f = rf;
+        } else if (c.wave == PW + 1) {      // the packed counts
+            f4 rb;
+            asm volatile("global_load_dwordx4 %0, %2, off offset:16 sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(rb), "=&v"(ev) : "v"(rec + 2 * w), "v"(gtile) : "memory");
             i4 ri = __builtin_bit_cast(i4, rb);
-            // the fold of Wave<16>::reduce, instruction for instruction: same tree, same rounding
-#define EVAC_RED_STEP(CTRL)                                                                                      \
-    rf.x = dpp_add<CTRL, 0xf>(rf.x); rf.y = dpp_add<CTRL, 0xf>(rf.y); rf.z = dpp_add<CTRL, 0xf>(rf.z);           \
-    ri.x = dpp_addi<CTRL, 0xf>(ri.x); ri.y = dpp_addi<CTRL, 0xf>(ri.y); ri.z = dpp_addi<CTRL, 0xf>(ri.z);        \
+#define EVAC_RED_STEP(CTRL)                                                                                       \
+    ri.x = dpp_addi<CTRL, 0xf>(ri.x); ri.y = dpp_addi<CTRL, 0xf>(ri.y); ri.z = dpp_addi<CTRL, 0xf>(ri.z);         \
     ri.w = dpp_addi<CTRL, 0xf>(ri.w);
             EVAC_RED_STEP(0x111)
             EVAC_RED_STEP(0x112)
             EVAC_RED_STEP(0x114)
             EVAC_RED_STEP(0x118)
 #undef EVAC_RED_STEP
-            // where segment w lands in the tile: exclusive prefix of the 16 counts (lanes 0..15, one DPP row)
+            if (c.lane == WPE - 1) c.sm.red_i = ri;
+        } else if (c.wave == PW + 2) {      // where segment w lands in the tile: exclusive prefix of the 16 counts (lanes 0..15, one DPP row)
+            const int* gcnt = (const int*)p.team_cnt + ((size_t)c.par_tile * p.n_envs + c.env) * WPE + w;
+            int cw;
+            asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(cw), "=&v"(ev) : "v"(gcnt), "v"(gtile) : "memory");
             const int cnt = cw & 0xffff;
             int incl = cnt, nans = cw >> 16;
             incl = dpp_addi<0x111, 0xf>(incl); nans = dpp_addi<0x111, 0xf>(nans);
@@ -244,11 +294,7 @@ struct Team {
             incl = dpp_addi<0x114, 0xf>(incl); nans = dpp_addi<0x114, 0xf>(nans);
             incl = dpp_addi<0x118, 0xf>(incl); nans = dpp_addi<0x118, 0xf>(nans);
             if (c.lane < WPE) c.sm.seg[c.lane] = i2{incl - cnt, cnt};
-            if (c.lane == WPE - 1) {
-                c.sm.red_f = rf;
-                c.sm.red_i = ri;
-                c.sm.totals = i2{incl, nans};
-            }
+            if (c.lane == WPE - 1) c.sm.totals = i2{incl, nans};
         } else {
             asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(ev) : "v"(gtile) : "memory");
         }
@@ -292,9 +338,39 @@ struct Team {
         }
         c.tile_valid = false;     // consumed: the step's reduction brings the next one
         EVAC_T(c, 2);   // exchange (only when the tile was not delivered by the previous step)
-        const int n_cols = c.n_cols;
-        // ---- the member's rows against the tile: two ped waves (two rows per lane) per pass, 1/16 of the columns per wave ----
+        const int n_cols = __builtin_amdgcn_readfirstlane(c.n_cols);
+        int n_rows[PW], n_rows_all = 0;
+#pragma unroll
+        for (int pw = 0; pw < PW; ++pw) {
+            n_rows[pw] = __builtin_amdgcn_readfirstlane(sm.rows[pw]);
+            n_rows_all += n_rows[pw];
+        }
         if constexpr (!(EVAC_ABLATE & 1)) {
+          if (n_rows_all <= kFewRows) {
+            // ---- FEW rows (most of an episode: only the VISCEK pedestrians of the member need one under enslaving_degree 1):
+            // the sweep is transposed.  The rows are dealt to the 16 waves round-robin and the LANES hold the columns, 64 per
+            // pass, the row's position uniform: r * ceil(n_cols / 64) passes of 7 instructions in all instead of n_cols * 14 per
+            // sixteenth, whatever r is (6 rows against 200 columns: 24 passes instead of 200 column visits).  The lanes' shares
+            // are folded with DPP and lane 63 adds the total to the row's accumulator (integers: the order does not matter).
+            const f4* __restrict__ tile = sm.tile;
+            int before = 0;                                   // rows of the ped waves before this one: the deal goes on across them
+#pragma unroll
+            for (int pw = 0; pw < PW; ++pw) {
+                for (int r = (c.wave - PW - before) & (WPE - 1); r < n_rows[pw]; r += WPE) {   // (the helper waves first: the ped waves come late)
+                    const float2 rp = sm.rowpos[pw][r];       // (uniform address: a broadcast)
+                    int ax = 0, ay = 0;
+                    for (int j0 = 0; j0 < n_cols; j0 += kWave)
+                        pair_accumulate_int(rp.x, rp.y, tile[min(j0 + c.lane, n_cols)], kRPed2Big, ax, ay);   // entry n_cols: padding, weight 0
+                    wave_sum2_int_lane63(ax, ay);             // (64 lanes adding to ONE LDS word would be serialised: fold in registers first)
+                    if (c.lane == kWave - 1) {
+                        lds_add(&sm.acc[pw][r][0], ax);
+                        lds_add(&sm.acc[pw][r][1], ay);
+                    }
+                }
+                before += n_rows[pw];
+            }
+          } else {
+            // ---- the member's rows against the tile: two ped waves (two rows per lane) per pass, 1/16 of the columns per wave ----
             const int groups = (n_cols + 3) >> 2;
             const int per = (groups + WPE - 1) / WPE;
             const int jbeg = __builtin_amdgcn_readfirstlane(c.wave * per * 4);
@@ -330,20 +406,20 @@ struct Team {
                     ax0 = ax1 = ax;
                     ay0 = ay1 = ay;
                 }
-                sm.part[c.wave][pw][c.lane] = i2{ax0, ay0};
-                sm.part[c.wave][pw + 1][c.lane] = i2{ax1, ay1};
+                // the 16 partial sums of a row meet in its LDS accumulator (integers: any order gives the same bits)
+                if (na != 0) { lds_add(&sm.acc[pw][c.lane][0], ax0); lds_add(&sm.acc[pw][c.lane][1], ay0); }
+                if (nb != 0) { lds_add(&sm.acc[pw + 1][c.lane][0], ax1); lds_add(&sm.acc[pw + 1][c.lane][1], ay1); }
             }
+          }
         }
         __syncthreads();
-        // ---- the 16 partial sums of a row (integers: any order) ----
         int tx = 0, ty = 0;
-        if (row) {
-#pragma unroll
-            for (int w2 = 0; w2 < WPE; ++w2) {
-                const i2 v = sm.part[w2][c.wave][c.row_slot];
-                tx += v.x;
-                ty += v.y;
-            }
+        if (!c.helper) {      // the row's sum; then the wave clears its accumulators for the next step (a wave's LDS operations execute
+                              // in order, and nobody adds again before the next step's barriers)
+            const i2 v = *(const i2*)sm.acc[c.wave][c.row_slot];
+            tx = v.x;
+            ty = v.y;
+            *(i2*)sm.acc[c.wave][c.lane] = i2{0, 0};
         }
         sx = row ? (float)tx : 0.0f;
         sy = row ? (float)ty : 0.0f;

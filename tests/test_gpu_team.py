@@ -65,6 +65,32 @@ def test_team_rollout_equals_one_workgroup_per_env(ea, n, E, team, wrap_kw, ens)
     ref.close(); tm.close()
 
 
+@pytest.mark.parametrize("n,E,team,ens", [(1024, 8, 8, 1.0), (1024, 8, 2, 1.0), (900, 8, 4, 1.0), (1024, 4, 8, 0.9)])
+def test_team_rollout_late_in_an_episode(ea, n, E, team, ens):
+    """Late in an episode a member has few rows to evaluate (only its VISCEK pedestrians under enslaving_degree 1) and the
+    pair sweep runs transposed -- rows dealt to the waves, lanes over the columns (Team::neighbour_sum); with
+    enslaving_degree < 1 the followers keep their rows and both forms alternate.  Same bits as the cell-list kernels all the
+    way through an episode."""
+    import torch
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=1500, is_new_exiting_reward=True, enslaving_degree=ens)
+    wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
+    ref = _make(ea, cfg, wrap, E, 5, team=0)
+    tm = _make(ea, cfg, wrap, E, 5, team=team)
+    ref.reset(); tm.reset()
+    for chunk in (300, 300, 300, 300, 301, 100):          # the truncation at 1500 and the reset fall inside the fifth launch
+        a = ref.rollout(chunk)
+        b = tm.rollout(chunk)
+        torch.cuda.synchronize()
+        assert tm.team_error() == 0
+        for key in ("obs", "reward", "terminated", "truncated"):
+            assert torch.equal(a[key].view(torch.int32), b[key].view(torch.int32)), (chunk, key)
+    sa, sb = ref.get_state(), tm.get_state()
+    for key in sa:
+        assert torch.equal(sa[key], sb[key]), key
+    st = sa["status"] if "status" in sa else None
+    ref.close(); tm.close()
+
+
 def test_team_nan_poisoning_reaches_every_member(ea):
     """A zero direction (0/0 heading, area.py:101) poisons every FOLLOWER / VISCEK pedestrian of the env in the reference
     (area.py:118-119): the flag has to cross the team."""
