@@ -186,7 +186,8 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     if constexpr (GRAV) F::exit_publish(c, exit_lane, gx, gy);
     if constexpr (F::kPipelined) F::stage_next(p, c, q, work);   // team kernels: the next step's tile entry travels with this reduction
     if constexpr (!(EVAC_ABLATE & 8)) F::template reduce<false>(p, c, s, pred);
-    if constexpr (GRAV) {
+    out.reward = out.gx = out.gy = out.ex = out.ey = 0.0f;
+    if (GRAV && work) {                       // (helper waves store no observation)
         float ex = 0.0f, ey = 0.0f;
         if (F::kExitLane && p.n_ped < F::kThreadsPerEnv) {    // uniform: the env leaves a lane idle
             F::exit_fetch(c, gx, gy, p.n_ped, ex, ey);
@@ -204,6 +205,8 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     out.n_follower = s.i[4];
     out.n_exiting = out.n_viscek = 0;   // filled by finish_counts() when the episode ends
 
+    out.terminated = term_agent || (s.i[2] + F::escaped_elsewhere(c) == p.n_ped);   // area.py:175-178, env.py:171
+    if (!work) return;                        // helper waves: the flags steer them, rewards and episode sums are the ped waves'
     float r_ped = p.init_reward;
     if constexpr (F::kEnvUniform) {
         // Real uniform branches (the empty asm keeps the compiler from if-converting them into always-executed
@@ -222,7 +225,6 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     }
     const float intrinsic = 0.0f - s.f0 * p.inv_n;                          // reward.py:19-21
     out.reward = r_agent + r_ped + p.intrinsic_coef * intrinsic;           // env.py:158
-    out.terminated = term_agent || (s.i[2] + F::escaped_elsewhere(c) == p.n_ped);   // area.py:175-178, env.py:171
     e.acc_ret += out.reward;                                                // env.py:168-170
     e.acc_intr += intrinsic;
     e.acc_stat += r_agent + r_ped;
@@ -595,7 +597,11 @@ __device__ __forceinline__ void rollout_body(
                 staged = staged == kStageSteps - 1 ? 0 : staged + 1;
             }
         } else {
-            if constexpr (!(EVAC_ABLATE & 2)) write_obs_generic(p, w.i, active, q, e, StorePlain{rowp});
+            if constexpr (!(EVAC_ABLATE & 2)) {
+                bool stores = true;             // (team kernels: waves without pedestrians store no observation)
+                if constexpr (F::kHelpers) stores = !w.helper;
+                if (stores) write_obs_generic(p, w.i, active, q, e, StorePlain{rowp});
+            }
             if (w.owner && !(EVAC_ABLATE & 16)) {
                 rowp[p.obs_dim + 0] = o.reward;
                 rowp[p.obs_dim + 1] = f_term;
