@@ -9,17 +9,21 @@
 // tools/microbench/team_barrier.hip measures 1.5 us per publish -> barrier -> gather round of 16 KiB among 8 CUs).  What
 // travels in that round:
 //   * the step's reduction: every ped wave publishes the same 32-byte record as a wave of Cells<16> leaves in LDS; after the
-//     barrier every wave folds the 16 records with the same DPP tree, so rewards / observations / flags are bit-identical to
-//     the one-workgroup kernels' and every member takes the same decisions (autoreset, termination) without further talk;
+//     barrier three helper waves of every member fold the 16 records with the same DPP tree (float sums, packed counts and
+//     the prefix of the segment counts are independent chains), so rewards / observations / flags are bit-identical to the
+//     one-workgroup kernels' and every member takes the same decisions (autoreset, termination) without further talk;
 //   * the NEXT step's tile: the head of the next step (pre_pair: escaped pin, exiting heading, unit heading) depends on the
 //     pedestrian's own post-step state only, so every ped wave already publishes its moving pedestrians (position x 2^40,
 //     integer heading), compacted inside the wave's 64-entry segment, and their count; after the barrier every member
 //     gathers all 16 segments into its LDS tile -- the columns of the next step's distance matrix.  (The first step of a
 //     launch and the step after an autoreset run the same exchange on their own.)
-// The rows are the member's own pedestrians that need one (step_env: needs_row), compacted per ped wave, two ped waves per
-// pass (two rows per lane); each of the 16 waves takes 1/16 of the columns (wave-uniform ds_read_b128 broadcasts) and the 16
-// partial sums of a row meet in LDS.  Heading sums are INTEGERS (pair_accumulate_int), so the result does not depend on
-// how the pairs were split -- it is bit-identical to the cell-list kernel's (Cells<16>).
+// The rows are the member's own pedestrians that need one (step_env: needs_row), compacted per ped wave.  MANY rows (early in
+// an episode): two ped waves per pass (two rows per lane), each of the 16 waves takes 1/16 of the columns (wave-uniform
+// ds_read_b128 broadcasts).  FEW rows (<= kFewRows: most of an episode under enslaving_degree 1, when only the VISCEK
+// pedestrians need one): the sweep is transposed -- the rows are dealt to the 16 waves, the lanes hold the columns.  Either
+// way the partial sums of a row meet in its LDS accumulator by integer atomics.  Heading sums are INTEGERS
+// (pair_accumulate_int), so the result does not depend on how the pairs were split -- it is bit-identical to the cell-list
+// kernel's (Cells<16>).
 // Everything else is the common step body (step_env) and rollout scaffolding (rollout_body); waves without pedestrians
 // ("helper" waves) skip the per-pedestrian arithmetic.
 //
