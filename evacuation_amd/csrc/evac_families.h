@@ -439,6 +439,10 @@ struct Cells {
 #define EVAC_ROW_BATCH 8
 #endif
     static constexpr int kRowBatch = EVAC_ROW_BATCH;   // tile entries per LDS round trip of a row
+#ifndef EVAC_TRANSPOSED_WORK
+#define EVAC_TRANSPOSED_WORK 1024
+#endif
+    static constexpr int kTransposedWork = EVAC_TRANSPOSED_WORK;   // needed rows x passes of 64 columns up to which the sweep is transposed (step 4')
     static constexpr const char* kName = WPE == 2 ? "2 waves/env, cell list" : (WPE == 4 ? "4 waves/env, cell list" : (WPE == 8 ? "8 waves/env, cell list" : "16 waves/env, cell list"));
 
     struct Smem {
@@ -446,6 +450,7 @@ struct Cells {
         alignas(16) int cnt[kCells + 4];      // tickets per cell; [256] = pedestrians with a NaN heading
         alignas(16) int start[kCells + 4];    // exclusive prefix of cnt; [256] = moving pedestrians, [257] = NaN headings
         int who[kThreadsPerEnv];              // tile slot -> pedestrian | cell << 16
+        int rowlist[kThreadsPerEnv];          // the tile slots whose row is needed, in ticket order (cnt[kCells + 1] of them)
         i2 res[kThreadsPerEnv];               // pedestrian -> integer heading sums of its row
         // 16-wave workgroups: claim more than half of the CU's 160 KiB so that the dispatcher places ONE env per CU
         // (two 1024-thread workgroups on one CU halve each other's speed while other CUs idle: 29.8 vs 16.3 us per step
@@ -533,6 +538,7 @@ struct Cells {
                 sm.start[kCells] = incl;                                           // moving pedestrians
                 sm.start[kCells + 1] = sm.cnt[kCells];
                 sm.cnt[kCells] = 0;
+                sm.cnt[kCells + 1] = 0;                                            // tickets of the needed rows (step 3)
             }
         }
         __syncthreads();
@@ -545,12 +551,34 @@ struct Cells {
             const int hx = (int)__builtin_rintf(ux * hs), hy = (int)__builtin_rintf(uy * hs);
             sm.tile[0][s] = f4{q.x * kTileScale, q.y * kTileScale, __builtin_bit_cast(float, hx), __builtin_bit_cast(float, hy)};
             sm.who[s] = c.i | (fv ? 0x8000 : 0) | (cell << 16);   // bit 15: this pedestrian's row is needed
+            if (fv) sm.rowlist[atomicAdd(&sm.cnt[kCells + 1], 1)] = s;
         }
         if (c.i < kPad) sm.tile[0][n_cols + c.i] = f4{__builtin_inff(), 0.0f, 0.0f, 0.0f};
         __syncthreads();
         EVAC_T(c, 2);   // binning
-        // ---- 4. rows in tile order ----
+        // ---- 4'. FEW needed rows (most of an episode under enslaving_degree 1: only the VISCEK pedestrians have one) against
+        // a tile of any size: one active lane per wave walking its cells is the worst use of the machine.  The needed rows are
+        // dealt to the waves instead (in ticket order: arbitrary, and irrelevant for integer sums) and the LANES hold the
+        // columns, 64 tile entries per pass whatever cell they are in -- all pairs, the same neighbour sets.
+        const int n_need = __builtin_amdgcn_readfirstlane(sm.cnt[kCells + 1]);
+        const int n_cols_u = __builtin_amdgcn_readfirstlane(n_cols);
+        const bool transposed = n_need * ((n_cols_u + kWave - 1) / kWave) <= kTransposedWork;
         if constexpr (!(EVAC_ABLATE & 1)) {
+          if (transposed) {
+            const f4* __restrict__ tile = sm.tile[0];
+            const int wv = __builtin_amdgcn_readfirstlane(c.wave_in_env);
+            for (int k = wv; k < n_need; k += WPE) {
+                const int s = sm.rowlist[k];                  // (uniform addresses: broadcasts)
+                const f4 me = tile[s];
+                const int ped = sm.who[s] & 0x7fff;
+                int ax = 0, ay = 0;
+                for (int j0 = 0; j0 < n_cols_u; j0 += kWave)
+                    pair_accumulate_int(me.x, me.y, tile[min(j0 + c.lane, n_cols_u)], kRPed2Big, ax, ay);   // entry n_cols: padding, weight 0
+                wave_sum2_int_lane63(ax, ay);
+                if (c.lane == kWave - 1) sm.res[ped] = i2{ax, ay};
+            }
+          } else {
+        // ---- 4. rows in tile order ----
             const int s = c.i;
             const int wc = s < n_cols ? sm.who[s] : 0;
             if (wc & 0x8000) {    // a moving pedestrian whose row is needed (a wave whose slots hold followers only does nothing)
@@ -580,6 +608,7 @@ struct Cells {
                 }
                 sm.res[wc & 0x7fff] = i2{ax, ay};
             }
+          }
         }
         __syncthreads();
         // ---- 5. back to the owner of the pedestrian ----
