@@ -232,6 +232,46 @@ def test_random_states_all_sizes(ea, n):
         compare_step(p, wrap, pre, acts, nzs, got, min_checked=E - 2)
 
 
+@pytest.mark.parametrize("n", [60, 256, 512, 600, 1024])
+def test_late_episode_states_with_few_rows(ea, n):
+    """Late in an episode most pedestrians have escaped, the crowd hangs on the leader and, under enslaving_degree 1, only
+    the few VISCEK pedestrians need a row of the distance matrix: the kernels then compact rows and columns (all-pairs
+    families) or deal the rows to the waves and sweep the tile with the lanes (cell-list family, N > 512).  Crafted states of
+    that kind -- 80 % escaped, a flock around the leader, a handful of loners, one dense knot -- one teacher-forced step
+    against the reference-precision oracle."""
+    rng = np.random.default_rng(7000 + n)
+    p = O.OracleParams(number_of_pedestrians=n, is_new_exiting_reward=True, is_new_followers_reward=True, enslaving_degree=1.0)
+    pre, acts, nzs = [], [], []
+    for e in range(4):
+        pos = rng.uniform(-1, 1, (n, 2))
+        d = rng.uniform(-1, 1, (n, 2))
+        agent = rng.uniform(-0.6, 0.6, 2).astype(np.float32)
+        k_esc = int(n * (0.8 if e < 3 else 0.5))
+        esc = rng.permutation(n)[:k_esc]
+        rest = np.setdiff1d(np.arange(n), esc)
+        flock = rest[: max(1, (2 * len(rest)) // 3)]                          # followers: inside the leader's radius
+        pos[flock] = agent + rng.uniform(-0.12, 0.12, (len(flock), 2))
+        knot = rest[len(flock):][: max(0, len(rest) // 6)]                    # loners that see each other
+        pos[knot] = np.array([0.7, 0.6]) + rng.uniform(-0.05, 0.05, (len(knot), 2))
+        pos[esc] = O.EXIT_POSITION
+        d[esc] = 0.0
+        with np.errstate(all="ignore"):
+            st = O.env_reset(p, pos, d)               # (normalises the directions: 0 / 0 for the escaped, overwritten below)
+        st.dir[esc] = 0.0
+        st.agent_pos = agent.copy()
+        st.agent_dir = (rng.uniform(-1, 1, 2) * 0.01).astype(np.float32)
+        st.status = O.classify_statuses(st.pos, st.agent_pos, O.EXIT_POSITION, st.pos.dtype)
+        st.now = 1200 + e
+        assert (st.status == O.ESCAPED).sum() >= k_esc and (st.status == O.VISCEK).sum() <= max(8, n // 4)
+        pre.append(st)
+        acts.append(rng.uniform(-1, 1, 2).astype(np.float32))
+        nzs.append(rng.uniform(-0.1, 0.1, n).astype(np.float32))
+    for w in (dict(positions="grav", alpha=3), dict(positions="rel", statuses="ohe", type="Box")):
+        wrap = ea.EnvWrappersConfig(**w)
+        got = gpu_step_batch(ea, p, wrap, pre, acts, nzs)
+        compare_step(p, wrap, pre, acts, nzs, got, min_checked=2)
+
+
 def test_free_running_50_steps_vs_reference_fixture(ea):
     """Same reset draws, actions and per-pedestrian noise as the reference episode; free-running."""
     d = np.load(os.path.join(H.GOLDEN, "traj_n60_s1_noise05_ens05.npz"))
