@@ -501,7 +501,9 @@ def main(argv=None):
                          "hbm_traffic_frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          "note": "achieved = algorithmic bytes / launch time (task contract): an equivalent-bandwidth figure, the state "
                                  "stays in registers between the steps of a launch; the all-pairs O(N^2) work makes the kernel "
-                                 "VALU-bound (valu_frac: 10*N^2+40*N lane-op model against 78.6e12 lane-ops/s); hbm_traffic_frac "
+                                 "VALU-bound (valu_frac: 10*N^2+40*N lane-op model of SURVEY 8d against 78.6e12 lane-ops/s -- the model counts "
+                                 "every ordered pair, the kernels only the rows that are needed against the pedestrians that still "
+                                 "move, so it can exceed 1; DESIGN.md 5 has the measured instruction counts); hbm_traffic_frac "
                                  "is the counter-measured HBM traffic rate against the same peak"},
             "step_api": step_api,
         }
