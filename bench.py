@@ -16,20 +16,36 @@ update, statuses, rewards, flags, observation, autoreset -- all written to HBM e
 What is timed.  The cost of a step depends on the episode phase (the all-pairs loop runs over the
 pedestrians that still move: all N after a reset, a third of them late in the episode), so a single
 K-step block measures whichever phase it lands on.  The timed region is therefore a sequence of BLOCKS of
-exactly K steps, each bracketed by barrier + torch.cuda.synchronize() on both sides and timed on its own
-(max over ranks); consecutive blocks tile whole episodes (R = 2000/K blocks per sweep, --sweeps sweeps, at
-least 20 blocks).  `ms_per_step` = mean over episode phases of the per-phase median block time / K, i.e. the
-EPISODE-AVERAGE cost; `value` = total envs / that.  `blocks` in the line also gives the median / min / max
-block, the dense block (all N moving, right after the reset) and the mid-episode block.  Steps are issued as
-launches of min(--inner, K) steps (evac_rollout: the state stays in registers between the steps of a launch,
-every step still writes its outputs to HBM).
+exactly K steps.  Every block opens with barrier + torch.cuda.synchronize() (device idle, all ranks present);
+then, per rank, t0 -> the launches of the K steps (and, N > 1, the all-gather of observations, see below) ->
+the rank drains its own streams -> t1.  The barrier that closes a block is the one that opens the next, OUTSIDE
+the timed region (a dist.barrier() is a collective plus a host sync -- tens of microseconds next to a 70 us
+block); the per-block MAX over ranks is taken after the loop.  Consecutive blocks tile whole episodes
+(R = 2000/K blocks per sweep, --sweeps sweeps, at least 20 blocks).  `ms_per_step` = mean over episode phases
+of the per-phase median block time / K, i.e. the EPISODE-AVERAGE cost; `value` = total envs / that.  Steps are
+issued as launches of min(--inner, K) steps (evac_rollout: the state stays in registers between the steps of a
+launch, every step still writes its outputs to HBM).
+
+The gather (N > 1).  The only collective of the path is the all-gather of the returned observation batch.
+`--gather-schedule pipelined` (default): the outputs are double-buffered and the gather of chunk j-1 is issued
+right after the launch of chunk j -- INSIDE the timed block, on a side stream -- so that it runs under that
+chunk's compute; with one launch per block (the driver's --steps 20) block b therefore computes K steps and
+gathers block b-1's observations (the warm-up primes the pipeline, so every timed block carries exactly one
+gather per launch and drains it before t1).  `--gather-schedule split`: a block's K steps go out as two K/2
+launches and each half is gathered as soon as it is computed, all inside the block (the first half's gather
+runs under the second half, the second half's is exposed).  `--gather direct` replaces RCCL's kernel by
+copy-engine peer writes over hipIpc-mapped buffers (no CU is taken from the rollout workgroups that occupy all
+of them; evacuation_amd/distributed.py DirectGather); a collective that fails is a hard error -- an N-GPU
+`value` is never printed without the gather traffic unless --no-gather was given.
 
 `roofline` follows the task contract: ALGORITHMIC bytes per launch (32N + 38 + 4D per
 env-step, times the env-steps of one launch) divided by the mean duration of the timed launches, measured
 with HIP events on the launching stream, against the 8 TB/s HBM peak.  The kernel keeps its state in
-registers, so this is an equivalent-bandwidth figure; the resource that actually binds is the VALU
-(`binding_resource`, `valu_frac`), and `traffic` is the HBM traffic the PMC counters see
-(profiles/traffic.json, bytes per env-step times the env-steps of one launch).
+registers, so this is an equivalent-bandwidth figure (`equivalent_bandwidth`); the resource that actually binds is
+the VALU: `valu_issue_frac` = counter-measured VALU wave-instructions per env-step (SQ_INSTS_VALU,
+profiles/traffic.json) x 64 lanes x env-steps / kernel time against the plain fp32 issue rate of the chip (256 CU
+x 4 SIMD x 16 lanes x 2.4 GHz = 39.3e12 lane-ops/s); `traffic` is the HBM traffic the PMC counters see
+(bytes per env-step times the env-steps of one launch).
 `cpu_baseline` times the NumPy oracle (a port of the reference's step) on the host cores.
 """
 from __future__ import annotations
@@ -48,7 +64,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy peak)
-VALU_LANE_OPS_PEAK = 78.6e12    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+VALU_ISSUE_PEAK = 39.3e12       # lane-ops/s at one wave64 VALU instruction per 4 cycles per SIMD: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
 EPISODE = 2000                  # max_timesteps of the synthetic workload
 
 WORKLOADS = {
@@ -73,15 +89,19 @@ def parse_args(argv=None):
     ap.add_argument("--blocks", type=int, default=0, help="override the number of timed K-step blocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-api", action="store_true", help="skip the one-launch-per-step side measurement")
-    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of the outputs (N>1)")
-    ap.add_argument("--gather", default="obs", choices=["obs", "slab"],
-                    help="what the ranks all-gather per chunk: the observation batch (north_star) or the whole packed record")
+    ap.add_argument("--no-gather", action="store_true", help="skip the all-gather of the outputs (N>1)")
+    ap.add_argument("--gather", default="obs", choices=["obs", "slab", "direct"],
+                    help="what the ranks all-gather per chunk and how: the observation batch (north_star) or the whole packed "
+                         "record through RCCL, or the packed record by copy-engine peer writes (direct: no CU taken)")
+    ap.add_argument("--gather-schedule", default="pipelined", choices=["pipelined", "split"],
+                    help="pipelined: the gather of chunk j-1 runs under the compute of chunk j (double-buffered, across blocks); "
+                         "split: a one-launch block goes out as two K/2 launches, each gathered inside the block")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-procs", type=int, default=-1,
-                    help="worker processes for the many-core CPU figure (-1: all host cores; 0/1: skip)")
+                    help="worker processes for the many-core CPU figure (-1: the cores this process may run on; 0/1: skip)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
     ap.add_argument("--dry-run", action="store_true",
-                    help="launcher / rendezvous / gather control flow only, on CPU tensors over gloo (tests; prints no throughput)")
+                    help="launcher / rendezvous / block and gather control flow only, on CPU tensors over gloo (tests; prints no throughput)")
     return ap.parse_args(argv)
 
 
@@ -140,20 +160,18 @@ def spawn_ranks(args, argv) -> int:
 def cpu_baseline(n_ped: int, seconds: float, procs: int):
     """The NumPy oracle (a port of the reference's EvacuationEnv.step + GravityEncoding) stepped in a
     single-env RandomAgent loop on one host core, as the reference's README loop does; plus, as
-    `many_core`, the same loop in `procs` independent worker processes."""
+    `many_core`, the same loop in one worker process per core THIS process may run on."""
     from oracle import cpu_bench
 
     n, dt = cpu_bench.readme_loop(n_ped, seconds)
+    allowed = cpu_bench.usable_cores()
     out = {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
            "sample": f"{n} single-env steps (n={n_ped}, gravity obs, RandomAgent loop) of the NumPy oracle in {dt:.1f} s "
-                     f"on 1 of {os.cpu_count()} host cores",
+                     f"on 1 core ({allowed} usable of {os.cpu_count()} host cores)",
            "agent_updates_per_s": n * n_ped / dt}
     if procs > 1:
         try:
-            steps, busy, wall = cpu_bench.many_core(n_ped, min(seconds, 6.0), procs)
-            out["many_core"] = {"value": steps / busy, "unit": "env-steps/s", "cores": procs,
-                                "sample": f"{steps} steps by {procs} independent single-env worker processes, {busy:.1f} s each "
-                                          f"(wall {wall:.1f} s incl. process start-up) of {os.cpu_count()} host cores"}
+            out["many_core"] = cpu_bench.many_core_report(n_ped, min(seconds, 6.0), procs, n / dt)
         except Exception as exc:  # noqa: BLE001
             out["many_core"] = {"error": f"{type(exc).__name__}: {exc}"[:160]}
     return out
@@ -172,24 +190,104 @@ def block_plan(K: int, sweeps: int, blocks: int):
 
 
 def summarize_blocks(wall_s, phases, per_sweep, K):
-    """Episode-average of the per-phase medians + descriptive figures.  wall_s[b] = block time (max over ranks)."""
+    """Episode-average of the per-phase medians + descriptive figures.  wall_s[b] = block time (max over ranks),
+    phases[b] = the episode step at which block b started.  Blocks are grouped by their ACTUAL phase: when K divides the
+    episode the sweeps revisit the same phases (a median per phase); when it does not, every block is a phase of its own and
+    the average runs over all of them (still whole sweeps of the episode)."""
     import statistics
     by_phase = {}
-    for b, w in enumerate(wall_s):
-        by_phase.setdefault(b % per_sweep, []).append(w)
-    phase_median = [statistics.median(by_phase[k]) for k in sorted(by_phase)]
-    avg = sum(phase_median) / len(phase_median)
-    first_phase = {k: phases[k] for k in range(min(per_sweep, len(phases)))}
-    dense_k = min(first_phase, key=lambda k: first_phase[k])                      # block that starts closest after a reset
-    mid_k = min(first_phase, key=lambda k: abs(first_phase[k] - EPISODE // 2))
+    for ph, w in zip(phases, wall_s):
+        by_phase.setdefault(ph, []).append(w)
+    keys = sorted(by_phase)
+    phase_median = {k: statistics.median(by_phase[k]) for k in keys}
+    avg = sum(phase_median.values()) / len(phase_median)
+    dense_k = keys[0]                                                           # the block that starts closest after a reset
+    mid_k = min(keys, key=lambda k: abs(k - EPISODE // 2))
     return avg, {
-        "timed_blocks": len(wall_s), "blocks_per_sweep": per_sweep, "steps_per_block": K,
+        "timed_blocks": len(wall_s), "blocks_per_sweep": per_sweep, "steps_per_block": K, "distinct_phases": len(keys),
         "episode_average_ms_per_step": avg / K * 1e3,
         "median_block_ms_per_step": statistics.median(wall_s) / K * 1e3,
         "min_block_ms_per_step": min(wall_s) / K * 1e3, "max_block_ms_per_step": max(wall_s) / K * 1e3,
-        "dense": {"episode_phase": first_phase[dense_k], "ms_per_step": phase_median[dense_k] / K * 1e3},
-        "mid_episode": {"episode_phase": first_phase[mid_k], "ms_per_step": phase_median[mid_k] / K * 1e3},
+        "dense": {"episode_phase": dense_k, "ms_per_step": phase_median[dense_k] / K * 1e3},
+        "mid_episode": {"episode_phase": mid_k, "ms_per_step": phase_median[mid_k] / K * 1e3},
     }
+
+
+def chunk_sizes(K: int, inner: int, schedule: str, gather: bool):
+    """The launches of one K-step block.  `split` turns a one-launch block into two halves so that the first half's gather
+    has compute to hide under."""
+    if gather and schedule == "split" and K <= inner and K >= 2:
+        return [K - K // 2, K // 2]
+    out, done = [], 0
+    while done < K:
+        t = min(inner, K - done)
+        out.append(t)
+        done += t
+    return out
+
+
+class ChunkPipeline:
+    """Issues the launches of the timed blocks and the gathers of their outputs; the ONE implementation of the block
+    structure, used with HIP streams by main() and with CPU stand-ins by dry_run() (tests/test_bench_launcher_cpu.py reads
+    its trace).
+
+    Chunks are numbered across blocks; chunk j computes into buffer j & 1.  lag = 1 (pipelined): after the launch of chunk j
+    the gather of chunk j-1 is issued (it reads buffer (j-1) & 1 while chunk j writes the other).  lag = 0 (split): chunk j's
+    own gather is issued right after its launch.  Before chunk j+1 reuses a buffer the compute stream waits for the gather
+    that read it.  `drain()` = everything issued so far, compute and gathers, has completed on this rank."""
+
+    def __init__(self, launch, gather, wait_gather, drain_compute, drain_gather, lag=1, trace=None):
+        self.launch, self.gather, self.wait_gather = launch, gather, wait_gather
+        self.drain_compute, self.drain_gather = drain_compute, drain_gather
+        self.lag = lag
+        self.trace = trace
+        self.next = 0                   # next chunk number
+        self.sizes = {}                 # chunk -> steps (for its gather)
+        self.ungathered = None          # the chunk whose gather has not been issued yet (lag = 1)
+        self.inflight = {}              # buffer parity -> gather token of the last gather that read it
+
+    def _log(self, *ev):
+        if self.trace is not None:
+            self.trace.append(ev)
+
+    def _issue_gather(self, j):
+        self._log("gather", j)
+        self.inflight[j & 1] = self.gather(j, self.sizes.pop(j))
+
+    def run_block(self, sizes):
+        """Issue one block: exactly sum(sizes) env steps."""
+        for t in sizes:
+            j = self.next
+            self.next += 1
+            tok = self.inflight.pop(j & 1, None)
+            if tok is not None:                       # buffer reuse: the gather that read buffer j & 1 must be finished
+                self._log("wait_gather_of_buffer", j & 1)
+                self.wait_gather(tok)
+            self._log("launch", j)
+            self.launch(j, t)
+            self.sizes[j] = t
+            if self.gather is None:
+                self.sizes.pop(j)
+                continue
+            if self.lag == 0:
+                self._issue_gather(j)
+            else:
+                if self.ungathered is not None:
+                    self._issue_gather(self.ungathered)
+                self.ungathered = j
+
+    def drain(self):
+        self._log("drain")
+        self.drain_compute()
+        if self.gather is not None:
+            self.drain_gather()
+
+    def flush(self):
+        """After the last block: the gather still owed (pipelined), untimed."""
+        if self.gather is not None and self.ungathered is not None:
+            self._issue_gather(self.ungathered)
+            self.ungathered = None
+        self.drain()
 
 
 def main(argv=None):
@@ -210,7 +308,8 @@ def main(argv=None):
     # touched the GPU, and the GPU measurement below runs on an otherwise idle host.
     cpu_base = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline and not args.dry_run:
-        procs = (os.cpu_count() or 1) if args.cpu_procs < 0 else args.cpu_procs
+        from oracle import cpu_bench
+        procs = cpu_bench.usable_cores() if args.cpu_procs < 0 else args.cpu_procs
         cpu_base = cpu_baseline(WORKLOADS[args.workload][0], args.cpu_seconds, procs)
 
     import torch
@@ -245,7 +344,7 @@ def main(argv=None):
             raise SystemExit(f"bench.py: {dist.get_world_size()} ranks joined, --gpus {args.gpus} requested")
 
     import evacuation_amd as ea
-    from evacuation_amd.distributed import ShardedEvacuationEnv, all_gather_envs, pack_outputs
+    from evacuation_amd.distributed import DirectGather, ShardedEvacuationEnv, all_gather_envs, pack_outputs
 
     cfg = ea.EnvConfig(number_of_pedestrians=n_ped, is_new_exiting_reward=True, is_new_followers_reward=True,
                        intrinsic_reward_coef=0.0, max_timesteps=EPISODE)       # SURVEY.md 8(d) synthetic inputs
@@ -256,128 +355,128 @@ def main(argv=None):
     E, D = loc.num_envs, loc.obs_dim
     env.reset()
     do_gather = world > 1 and not args.no_gather
+    gather_rollout = do_gather and args.mode == "rollout"
+    sizes = chunk_sizes(K, inner, args.gather_schedule, gather_rollout)
+    inner = sizes[0]                                           # the launch shape the roofline block describes
+    lag = 0 if (args.gather_schedule == "split") else 1
 
-    # preallocated, reused output chunks (the trainer's rollout buffer, rpo_agent.py:158-163): the kernel
-    # writes one packed slab [T, E, D+3] = [obs | reward | terminated | truncated], which is also the
-    # all-gather message
-    def alloc(T):
-        b = {"slab": torch.empty((T, E, D + 3), dtype=torch.float32, device=device),
-             "episode_stats": torch.zeros((T, E, loc.stats_words), dtype=torch.float32, device=device)}
-        b["launch"] = loc.rollout_launcher(T, b)          # pre-bound ctypes call: no per-launch Python argument work
-        return b
-    bufs = [alloc(inner), alloc(inner)]
-    tails = {}
+    # Preallocated, reused output chunks (the trainer's rollout buffer, rpo_agent.py:158-163): the kernel writes one packed
+    # slab [T, E, D+3] = [obs | reward | terminated | truncated] per launch shape and buffer parity.
     GW = D if args.gather == "obs" else D + 3                 # gathered words per env-step
-    gathered = [torch.empty((world, inner, E, GW), dtype=torch.float32, device=device) for _ in range(2)] if do_gather else None
-    gsrc = [torch.empty((inner, E, GW), dtype=torch.float32, device=device) for _ in range(2)] if (do_gather and args.gather == "obs") else None
+    chunks = {}
 
-    def gather_message(b, k):
-        """The contiguous tensor this rank contributes: the slab itself, or its observation columns copied out
-        (on the stream the caller is in -- the comm stream, off the compute stream's critical path)."""
-        if args.gather == "slab":
-            return b["slab"]
-        gsrc[k & 1].copy_(b["slab"][..., :D])
-        return gsrc[k & 1]
+    def chunk_bufs(t, parity):
+        key = (t, parity)
+        b = chunks.get(key)
+        if b is None:
+            b = {"slab": torch.empty((t, E, D + 3), dtype=torch.float32, device=device),
+                 "episode_stats": torch.zeros((t, E, loc.stats_words), dtype=torch.float32, device=device)}
+            b["launch"] = loc.rollout_launcher(t, b)          # pre-bound ctypes call: no per-launch Python argument work
+            if gather_rollout:
+                b["gathered"] = torch.empty((world, t, E, GW), dtype=torch.float32, device=device)
+                if args.gather == "obs":
+                    b["gsrc"] = torch.empty((t, E, GW), dtype=torch.float32, device=device)
+                if args.gather == "direct":
+                    b["direct"] = DirectGather(b["slab"], b["gathered"])     # peers' `gathered` buffers mapped through hipIpc
+            chunks[key] = b
+        return b
+
     comm = torch.cuda.Stream(device=device) if do_gather else None
     step_actions = torch.rand((E, 2), device=device) * 2 - 1
-    ev_pool = []
 
-    def run(n_steps, events=None):
-        """Issue exactly n_steps env steps; returns the number of kernel launches."""
-        done = 0
-        k = 0
-        pend = [None, None]
-        while done < n_steps:
-            t = min(inner, n_steps - done)
-            b = bufs[k & 1]
-            if pend[k & 1] is not None:                       # buffer reuse: its gather must be finished
-                torch.cuda.current_stream().wait_event(pend[k & 1])
-                pend[k & 1] = None
-            if events is not None:
-                ev0, ev1 = ev_pool.pop() if ev_pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev0.record()
-            if args.mode == "rollout":
-                if t != inner:
-                    b = tails.get(t) or tails.setdefault(t, alloc(t))
-                b["launch"]()
-            else:
-                loc.step(step_actions)
-            if events is not None:
-                ev1.record()
-                events.append((ev0, ev1, t))
-            if do_gather and args.mode == "rollout" and t == inner:
-                ready = torch.cuda.Event(); ready.record()
-                with torch.cuda.stream(comm):
-                    comm.wait_event(ready)
-                    all_gather_envs(gather_message(b, k), out=gathered[k & 1])
-                    fin = torch.cuda.Event(); fin.record(comm)
-                pend[k & 1] = fin
-            elif do_gather:
-                if args.mode == "step":
-                    msg = loc.obs if args.gather == "obs" else pack_outputs(loc.obs, loc.reward, loc.terminated, loc.truncated)
-                else:
-                    msg = b["slab"][..., :D].contiguous() if args.gather == "obs" else b["slab"]
-                all_gather_envs(msg)
-            done += t
-            k += 1
-        for p in pend:
-            if p is not None:
-                torch.cuda.current_stream().wait_event(p)
-        return k
+    def launch(j, t):
+        if args.mode == "rollout":
+            chunk_bufs(t, j & 1)["launch"]()
+        else:
+            loc.step(step_actions)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def gather(j, t):
+        """Issue the gather of chunk j's outputs on the comm stream; returns the event that marks its end."""
+        if args.mode == "step":
+            msg = loc.obs if args.gather == "obs" else pack_outputs(loc.obs, loc.reward, loc.terminated, loc.truncated)
+            all_gather_envs(msg)                              # (per-step API: one small collective per step, on the compute stream)
+            return None
+        b = chunk_bufs(t, j & 1)
+        ready = torch.cuda.Event()
+        ready.record()                                        # chunk j (and everything before it) on the compute stream
+        with torch.cuda.stream(comm):
+            comm.wait_event(ready)
+            if args.gather == "direct":
+                b["direct"].issue(comm)
+            elif args.gather == "slab":
+                all_gather_envs(b["slab"], out=b["gathered"])
+            else:                                             # the observation columns, copied out on the comm stream
+                b["gsrc"].copy_(b["slab"][..., :D])
+                all_gather_envs(b["gsrc"], out=b["gathered"])
+            fin = torch.cuda.Event()
+            fin.record(comm)
+        return fin
 
-    def drain():
-        """Poll the stream until the issued work is done, so that the synchronize() that closes a timed block returns at
-        once: a blocking wait adds the host's sleep / wake-up latency (~10 us) to a block that is itself ~60 us."""
+    def wait_gather(fin):
+        if fin is not None:
+            torch.cuda.current_stream().wait_event(fin)
+
+    def drain_compute():
+        """Poll the stream until the issued work is done: a blocking wait adds the host's sleep / wake-up latency (~10 us)
+        to a block that is itself ~60 us."""
         st = torch.cuda.current_stream()
         while not st.query():
             pass
 
-    # Exercise the collective once before anything is timed.  If RCCL cannot gather on this node the
-    # benchmark degrades to independent shards (and says so) instead of dying without a number.
-    gather_note = None
-    if do_gather:
-        ok = torch.ones(1, device=device)
+    def drain_gather():
+        while not comm.query():
+            pass
+
+    pipe = ChunkPipeline(launch, gather if do_gather else None, wait_gather, drain_compute, drain_gather if do_gather else None, lag=lag)
+
+    def barrier():
+        """Opens a timed block (and, being the next block's opening, closes the previous one outside its timed region)."""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # Exercise the collective once before anything is timed.  A collective that fails is a hard error: an N-GPU value
+    # without the gather traffic is not the benchmark (use --no-gather to measure independent shards on purpose).
+    if gather_rollout:
         try:
-            all_gather_envs(gather_message(bufs[0], 0), out=gathered[0])
+            b0 = chunk_bufs(sizes[0], 0)
+            if args.gather == "direct":
+                b0["direct"].issue(torch.cuda.current_stream())
+                b0["direct"].self_test()
+            else:
+                all_gather_envs(b0["slab"] if args.gather == "slab" else b0["gsrc"], out=b0["gathered"])
             torch.cuda.synchronize()
         except Exception as exc:  # noqa: BLE001
-            ok.zero_()
-            gather_note = f"all-gather disabled: {type(exc).__name__}: {exc}"[:200]
-        try:
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if ok.item() == 0:
-                do_gather = False
-        except Exception as exc:  # noqa: BLE001
-            do_gather = False
-            gather_note = gather_note or f"all-reduce failed: {type(exc).__name__}"
-        if not do_gather and gather_note is None:
-            gather_note = "all-gather disabled: failed on another rank"
+            raise SystemExit(f"bench.py: rank {rank}: the all-gather failed ({type(exc).__name__}: {exc}); no {world}-GPU result "
+                             f"(--no-gather measures independent shards)") from exc
 
-    run(W)                                                    # W untimed warm-up steps
+    # W untimed warm-up steps through the same pipeline (so that, pipelined, the first timed block has a gather to carry)
+    w_done = 0
+    while w_done < W:
+        t = min(inner, W - w_done)
+        pipe.run_block([t])
+        w_done += t
+    pipe.drain()
     barrier()
     state0 = [t.clone() for t in (loc.ped, loc.status, loc.agent, loc.clock, loc.acc)]   # for the kernel-timing replay below
+    ws0 = loc.workspace.clone() if loc.workspace is not None else None
     n_blocks = per_sweep * sweeps
-    wall, phases, block_events = [], [], []
-    launches = 0
-    # one launch per block and nothing to gather: issue it without run()'s bookkeeping (a few us of Python next to a 55 us kernel)
-    one_launch = bufs[0]["launch"] if (args.mode == "rollout" and K == inner and not do_gather) else None
+    wall, phases = [], []
+    # one launch per block and nothing to gather: issue it without the pipeline's bookkeeping (a few us of Python next to a 50 us kernel)
+    one_launch = chunk_bufs(K, 0)["launch"] if (args.mode == "rollout" and sizes == [K] and not do_gather) else None
     for b in range(n_blocks):
         phases.append((W + b * K) % EPISODE)                  # RandomAgent episodes end by truncation at 2000
-        barrier()
+        barrier()                                             # opening bracket: all ranks present, device idle
         t0 = time.perf_counter()
         if one_launch is not None:
             one_launch()                                      # EXACTLY K steps
-            launches = 1
+            drain_compute()
         else:
-            launches = run(K)                                 # EXACTLY K steps (no event markers inside the timed region)
-        drain()
-        barrier()
-        wall.append(time.perf_counter() - t0)
+            pipe.run_block(sizes)                             # EXACTLY K steps (+ one gather per launch)
+            pipe.drain()                                      # this rank's compute AND gathers are done
+        wall.append(time.perf_counter() - t0)                 # local t1; no collective inside the timed region
+    pipe.flush()
+    barrier()
     if world > 1:
         tt = torch.tensor(wall, dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)             # per block: the slowest rank
@@ -386,43 +485,57 @@ def main(argv=None):
 
     # Duration of the dominant kernel's launches, from HIP events on the launching stream.  An event pair around ONE
     # short launch also times the ~7 us between the markers and the kernel (11 % of a 20-step launch), so the average
-    # launch duration is taken over a replay of the first sweep's blocks (state restored) issued back to back between two events
-    # (elapsed / launches: kernel + the ~1.5 us launch boundary) -- this is the figure a
-    # `rocprofv3 --kernel-trace --stats` of this command reproduces; the per-launch pairs of the timed blocks give
-    # the dense (all N moving) launch, corrected by the mean difference between the two measurements.
+    # launch duration is taken over a replay of the first sweep's blocks (state restored, no gathers) issued back to back
+    # between two events (elapsed / launches: kernel + the ~1.5 us launch boundary) -- this is the figure a
+    # `rocprofv3 --kernel-trace --stats` of this command reproduces; the per-launch pairs give the dense (all N moving)
+    # launch, corrected by the mean difference between the two measurements.
     def restore():
         barrier()
         for dst, src in zip((loc.ped, loc.status, loc.agent, loc.clock, loc.acc), state0):   # same phases as the first sweep
             dst.copy_(src)
+        if ws0 is not None:                                   # ... and the same load schedule: loads as they were, re-sorted at the first launch
+            loc.workspace.copy_(ws0)
+            loc.rebind_workspace()
         barrier()
+
+    def replay_launch(t):
+        if args.mode == "rollout":
+            chunk_bufs(t, 0)["launch"]()
+        else:
+            loc.step(step_actions)
+
     restore()
+    per_launch, dense_l = [], []
     for b in range(per_sweep):                                # replay 1: an event pair around every launch
-        events = []
-        run(K, events)
-        block_events.append(events)
+        for t in sizes:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            replay_launch(t)
+            ev1.record()
+            per_launch.append((b, t, ev0, ev1))
     barrier()
-    per_launch = [a.elapsed_time(b) * 1e-3 for evs in block_events for a, b, t in evs if t == inner]
+    dense_b = min(range(min(per_sweep, n_blocks)), key=lambda k: phases[k])
+    full = [a.elapsed_time(z) * 1e-3 for b, t, a, z in per_launch if t == inner]
+    dense_l = [a.elapsed_time(z) * 1e-3 for b, t, a, z in per_launch if t == inner and b == dense_b]
     restore()                                                 # replay 2: back to back between two events
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     back_to_back = 0
+    uniform = all(t == inner for t in sizes)
     e0.record()
     for b in range(per_sweep):
-        back_to_back += run(K)
+        for t in sizes:
+            replay_launch(t)
+            back_to_back += 1
     e1.record()
     barrier()
-    tail_launches = per_sweep * (1 if K % inner else 0)           # launches of a shorter tail shape, if any
-    kernel_s = e0.elapsed_time(e1) * 1e-3 / max(1, back_to_back) if not tail_launches else sum(per_launch) / max(1, len(per_launch))
-    event_overhead_s = max(0.0, sum(per_launch) / max(1, len(per_launch)) - kernel_s) if not tail_launches else 0.0
-    dense_b = min(range(min(per_sweep, n_blocks)), key=lambda k: phases[k])
-    dense_l = [a.elapsed_time(b) * 1e-3 for a, b, t in block_events[dense_b] if t == inner]
+    kernel_s = e0.elapsed_time(e1) * 1e-3 / max(1, back_to_back) if uniform else sum(full) / max(1, len(full))
+    event_overhead_s = max(0.0, sum(full) / max(1, len(full)) - kernel_s) if uniform else 0.0
     kernel_dense_s = (sorted(dense_l)[len(dense_l) // 2] - event_overhead_s) if dense_l else kernel_s
-    full = per_launch
     if loc.team_error():                                      # a team barrier timed out somewhere above: the numbers are void
         raise SystemExit("bench.py: evac_team_error is set (a team rollout lost a member); results discarded")
     bytes_per_env_step = loc.algorithmic_bytes_per_env_step
     bytes_per_launch = bytes_per_env_step * E * inner
     achieved = bytes_per_launch / kernel_s / 1e9
-    lane_ops_per_env_step = 10.0 * n_ped * n_ped + 40.0 * n_ped          # SURVEY.md 8(d) op model
 
     # the per-step API (one evac_step launch per step, actions resident in HBM), for transparency
     step_api = None
@@ -461,16 +574,27 @@ def main(argv=None):
             step_api["hipgraph_error"] = f"{type(exc).__name__}: {exc}"[:160]
 
     if rank == 0:
-        traffic = traffic_src = None
+        traffic = traffic_src = valu_insts = None
         try:
             with open(args.traffic_json) as f:
                 ent = json.load(f).get(f"{args.workload}:{args.mode}")
             if ent:
                 traffic = ent["hbm_bytes_per_env_step"] * E * inner      # measured per env-step, scaled to one launch
                 traffic_src = f'{ent.get("source")} ({ent.get("envs")} envs x {ent.get("steps_per_launch")} steps per launch)'
+                valu_insts = ent.get("valu_wave_insts_per_env_step")
         except Exception:  # noqa: BLE001
             pass
         value = total_envs / (block_s / K)
+        if not do_gather:
+            gather_desc = ""
+        elif args.mode == "step":
+            gather_desc = ", RCCL all-gather of the step outputs after every step"
+        else:
+            what = {"obs": "observation batch (RCCL)", "slab": "[obs|reward|flags] records (RCCL)",
+                    "direct": "[obs|reward|flags] records (copy-engine peer writes over hipIpc, no CU)"}[args.gather]
+            how = ("issued after the NEXT chunk's launch, inside the timed block (double-buffered; block b carries block b-1's gather)"
+                   if lag == 1 else "each chunk gathered as soon as it is computed, inside its block")
+            gather_desc = f", all-gather of the {what} per {inner}-step chunk on a side stream, {how}"
         out = {
             "metric": "env-steps/s (agent-updates/s) at n=60x4096 envs" if args.workload == "c2" else f"env-steps/s ({args.workload})",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -478,33 +602,38 @@ def main(argv=None):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "n_pedestrians": n_ped, "envs_per_gpu": E, "total_envs": total_envs,
                        "obs": wrap_kw, "actions": "RandomAgent U(-1,1)^2 drawn on device (Philox4x32-10)",
-                       "mode": args.mode, "steps_per_launch": inner, "launches_per_block": launches,
-                       "timing": "blocks of exactly K steps, each bracketed by barrier+synchronize, tiling whole episodes; "
+                       "mode": args.mode, "steps_per_launch": inner, "launches_per_block": len(sizes),
+                       "timing": "blocks of exactly K steps tiling whole episodes; per block: barrier + synchronize (all ranks, device "
+                                 "idle) -> t0 -> launches (+ gathers) -> the rank drains its compute and comm streams -> t1; the "
+                                 "closing barrier is the next block's opening, outside the timed region; max over ranks per block; "
                                  "ms_per_step = episode average of the per-phase median block",
+                       "gather_schedule": (args.gather_schedule if gather_rollout else None),
                        "ranks_joined": dist.get_world_size() if world > 1 else 1,
-                       "parallelism": f"env-sharded x{world}" + (f", RCCL all-gather of the {'observation batch' if args.gather == 'obs' else '[obs|reward|flags] records'} per {inner}-step chunk, overlapped on a side stream" if do_gather else ""),
-                       "gather_note": gather_note,
+                       "parallelism": f"env-sharded x{world}" + gather_desc,
                        "max_timesteps": EPISODE, "autoreset": True},
             "agent_updates_per_s": value * n_ped,
             "blocks": blocks_info,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": loc.kernel_variant(args.mode),
-                         "kernel_ms_per_launch": kernel_s * 1e3, "kernel_launches_timed": back_to_back or len(full),
+                         "kernel_ms_per_launch": kernel_s * 1e3, "kernel_launches_timed": back_to_back if uniform else len(full),
                          "kernel_ms_per_launch_event_pairs": sum(full) / max(1, len(full)) * 1e3,
                          "kernel_ms_per_launch_dense": kernel_dense_s * 1e3,
                          "frac_dense": bytes_per_launch / kernel_dense_s / 1e9 / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_env_step": bytes_per_env_step,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "equivalent_bandwidth": True,
                          "binding_resource": "valu",
-                         "valu_frac": lane_ops_per_env_step * E * inner / kernel_s / VALU_LANE_OPS_PEAK,
+                         "valu_issue_frac": (valu_insts * 64.0 * E * inner / kernel_s / VALU_ISSUE_PEAK) if valu_insts else None,
+                         "valu_wave_insts_per_env_step": valu_insts,
+                         "valu_issue_peak_lane_ops_per_s": VALU_ISSUE_PEAK,
                          "hbm_traffic_frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                         "note": "achieved = algorithmic bytes / launch time (task contract): an equivalent-bandwidth figure, the state "
-                                 "stays in registers between the steps of a launch; the all-pairs O(N^2) work makes the kernel "
-                                 "VALU-bound (valu_frac: 10*N^2+40*N lane-op model of SURVEY 8d against 78.6e12 lane-ops/s -- the model counts "
-                                 "every ordered pair, the kernels only the rows that are needed against the pedestrians that still "
-                                 "move, so it can exceed 1; DESIGN.md 5 has the measured instruction counts); hbm_traffic_frac "
-                                 "is the counter-measured HBM traffic rate against the same peak"},
+                         "note": "achieved = algorithmic bytes / launch time (task contract): an EQUIVALENT-bandwidth figure, the state "
+                                 "stays in registers between the steps of a launch and the counter-measured HBM traffic (traffic, "
+                                 "hbm_traffic_frac) is a few per cent of it; the resource that binds is the VALU: valu_issue_frac = "
+                                 "SQ_INSTS_VALU per env-step (rocprofv3 --pmc, profiles/traffic.json) x 64 lanes x env-steps per launch / "
+                                 "kernel time against 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 39.3e12 lane-ops/s (one wave64 VALU "
+                                 "instruction per 4 cycles per SIMD)"},
             "step_api": step_api,
         }
         out["cpu_baseline"] = cpu_base
@@ -517,8 +646,11 @@ def main(argv=None):
 
 
 def dry_run(args, rank, world, total_envs, envs_per_gpu, K, W, inner, per_sweep, sweeps):
-    """The multi-rank control flow without a GPU: rendezvous over gloo, the block/barrier structure and the
-    packed all-gather on CPU tensors.  Used by tests/test_bench_launcher_cpu.py; reports no throughput."""
+    """The multi-rank control flow without a GPU: rendezvous over gloo, the block structure of main() -- the SAME
+    ChunkPipeline, with CPU stand-ins for the launches and the real (gloo) all-gather -- and the packed all-gather in
+    global env order.  Rank 0 prints the trace of its first blocks: tests/test_bench_launcher_cpu.py asserts that no
+    barrier lies inside a timed region and that, pipelined, the gather of chunk j-1 is issued after the launch of chunk j.
+    Reports no throughput."""
     import torch
     import torch.distributed as dist
 
@@ -528,34 +660,62 @@ def dry_run(args, rank, world, total_envs, envs_per_gpu, K, W, inner, per_sweep,
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
         if dist.get_world_size() != args.gpus:
             raise SystemExit(3)
+    do_gather = world > 1 and not args.no_gather
+    if do_gather and os.environ.get("EVAC_BENCH_FAIL_GATHER") == str(rank):     # testing aid: a collective that fails on one rank
+        print(f"bench.py: rank {rank}: the all-gather failed (injected); no {world}-GPU result", file=sys.stderr)
+        raise SystemExit(5)
+    sizes = chunk_sizes(K, inner, args.gather_schedule, do_gather)
+    lag = 0 if args.gather_schedule == "split" else 1
     off, n_local = shard_range(total_envs, rank, world)
     gid = torch.arange(off, off + n_local, dtype=torch.float32)
-    wall, phases = [], []
-    ok = True
-    for b in range(min(per_sweep * sweeps, 4)):
-        phases.append((W + b * K) % EPISODE)
+    bufs = {}
+    trace, state = [], {"ok": True, "gathers": 0}
+
+    def launch(j, t):
+        bufs[j & 1] = gid[None, :, None] + 1000.0 * j + torch.zeros((min(t, 4), n_local, 9))   # chunk j's "outputs"
+
+    def gather(j, t):
+        g, _ = all_gather_envs(bufs[j & 1])
+        full = gathered_view(g)
+        state["ok"] = state["ok"] and bool((full[0, :, 0] == torch.arange(total_envs, dtype=torch.float32) + 1000.0 * j).all())
+        state["gathers"] += 1
+        return j
+
+    pipe = ChunkPipeline(launch, gather if do_gather else None, lambda tok: None, lambda: None, lambda: None, lag=lag, trace=trace)
+    w_done = 0
+    while w_done < W:
+        t = min(sizes[0], W - w_done)
+        pipe.run_block([t])
+        w_done += t
+    pipe.drain()
+    wall = []
+    n_timed = min(per_sweep * sweeps, 4)
+    for b in range(n_timed):
         if world > 1:
             dist.barrier()
+        trace.append(("barrier",))
+        trace.append(("t0", b))
         t0 = time.perf_counter()
-        slab = gid[None, :, None] + torch.zeros((min(inner, 4), n_local, 9))
-        if world > 1:
-            g, _ = all_gather_envs(slab)
-            full = gathered_view(g)
-            ok = ok and bool((full[0, :, 0] == torch.arange(total_envs, dtype=torch.float32)).all())
-            dist.barrier()
+        pipe.run_block(sizes)
+        pipe.drain()
         wall.append(time.perf_counter() - t0)
+        trace.append(("t1", b))
+    pipe.flush()
     if world > 1:
+        dist.barrier()
         tt = torch.tensor(wall, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_joined": dist.get_world_size() if world > 1 else 1,
                           "steps": K, "warmup": W, "total_envs": total_envs, "envs_per_gpu": envs_per_gpu,
-                          "gather_in_global_env_order": ok, "blocks": len(wall), "value": None,
+                          "gather_in_global_env_order": state["ok"], "gathers": state["gathers"], "blocks": len(wall),
+                          "launches_per_block": len(sizes), "chunk_sizes": sizes, "gather_schedule": args.gather_schedule,
+                          "trace": [list(ev) for ev in trace], "value": None,
                           "self_launched": os.environ.get("EVAC_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    return 0 if ok else 4
+    return 0 if state["ok"] else 4
 
 
 if __name__ == "__main__":

@@ -10,12 +10,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVAC_LIB") or os.path.join(HERE, "libevac.so")
 
 EVAC_OK = 0
-ERR_INVALID_ARGUMENT, ERR_NOT_BOUND, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = -1, -2, -3, -4, -5
+ERR_INVALID_ARGUMENT, ERR_NOT_BOUND, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_TEAM_ABORTED = -1, -2, -3, -4, -5, -6
 POS = {"abs": 0, "rel": 1, "grav": 2}
 STAT = {"no": 0, "ohe": 1, "cat": 2}
 TYPE = {"Dict": 0, "Box": 1}
 MAX_PEDESTRIANS = 1024
-VERSION = 120
+VERSION = 130
 EPISODE_STATS_WORDS = 10       # evac_episode_stats_t: 8 floats + 2 int32
 
 
@@ -55,6 +55,7 @@ SIGNATURES = {
     "evac_workspace_bytes": (C.c_int64, [_P]),
     "evac_bind_workspace": (C.c_int, [_P, _P, C.c_int64]),
     "evac_team_error": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "evac_team_clear_error": (C.c_int, [_P]),
     "evac_reset": (C.c_int, [_P, _P, _P, _P, _P]),
     "evac_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     "evac_rollout": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),

@@ -71,8 +71,16 @@ struct evac_handle {
     int32_t* sched;     // inside the caller's workspace (evac_bind_workspace): moving[E] | perm[E], or NULL
     int sched_age;      // env steps rolled out since the schedule was last rebuilt (< 0: never built)
     bool team_bound;    // the workspace holds the teams' exchange areas
+    int team_fit;       // -1: not checked yet; 1 / 0: the team grid fits the device at once (occupancy x CUs >= workgroups) or not
+    bool team_coop;     // team kernels are launched with hipLaunchCooperativeKernel (the device supports it; EVAC_TEAM_COOP=0: plain launches)
+    int cus;            // compute units of the device
+    bool team_fault;    // EVAC_TEAM_FAULT=1 (tests): launch the team grid one workgroup short
+    // The teams' error word: 64 bytes of host-mapped memory owned by the handle.  A team that lost a member raises it from the
+    // kernel (system-scope store); every later evac_* call of the handle reads it on the host, without synchronising.
+    volatile unsigned* team_flag_host;
+    unsigned* team_flag_dev;
     std::string err;
-    std::string variant[2];
+    std::string variant[3];   // evac_step | evac_rollout with one workgroup (or less) per env | evac_rollout by teams
 };
 
 namespace {
@@ -80,6 +88,19 @@ namespace {
 int fail(evac_handle_t h, int code, const std::string& msg) {
     if (h) h->err = msg;
     return code;
+}
+
+// A team rollout of this handle lost a member (evac_team.h): the outputs of that launch are void.  Sticky until
+// evac_team_clear_error; the handle runs the one-workgroup-per-env kernels from then on.
+int team_aborted(evac_handle_t h, const char* what) {
+    if (h->team_flag_host && *h->team_flag_host != 0u) {
+        h->team_k = 0;
+        return fail(h, EVAC_ERR_TEAM_ABORTED,
+                    std::string(what) + ": an earlier team rollout lost a member (the workgroups of a team were not resident together); "
+                    "the outputs of that launch are void and the env it carried kept its pre-launch state -- call "
+                    "evac_team_clear_error(), then reset or restore the batch; the handle uses one workgroup per env from now on");
+    }
+    return EVAC_OK;
 }
 
 int check_launch(evac_handle_t h, const char* what) {
@@ -131,6 +152,34 @@ int waves_per_env(int n_ped) { return n_ped <= 64 ? 1 : (n_ped <= 128 ? 2 : (n_p
         else EVAC_LAUNCH_WPE(h, KERNEL, 16, s_, __VA_ARGS__);                         \
     } while (0)
 
+
+// ---- team rollouts (evac_team.h): which kernel, how many workgroups, and do they all fit the device at once ----
+const void* team_kernel(const evac_handle* h) {
+    const bool grav = h->p.obs_pos == EVAC_POS_GRAV, dflt = h->default_cfg;
+#define EVAC_TEAM_FN(K_)                                                                                                          \
+    (dflt ? (grav ? (const void*)evac::k_rollout_default_config<evac::Team<K_>, true> : (const void*)evac::k_rollout_default_config<evac::Team<K_>, false>) \
+          : (grav ? (const void*)evac::k_rollout<evac::Team<K_>, true> : (const void*)evac::k_rollout<evac::Team<K_>, false>))
+    return h->team_k == 8 ? EVAC_TEAM_FN(8) : (h->team_k == 4 ? EVAC_TEAM_FN(4) : EVAC_TEAM_FN(2));
+#undef EVAC_TEAM_FN
+}
+unsigned team_grid(const evac_handle* h) {
+    // (EVAC_TEAM_FAULT=1, fault injection for tests/test_gpu_team.py: the last workgroup is never launched, so the team it
+    // belongs to loses a member and must time out, flag the error and leave its env's state alone)
+    return (unsigned)((h->p.n_envs + 7) / 8 * 8 * h->team_k) - (h->team_fault ? 1u : 0u);
+}
+// The members of a team wait for each other, so every workgroup of the grid needs a CU of its own at the same time.
+bool team_grid_fits(evac_handle* h) {
+    if (h->team_fit < 0) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, team_kernel(h), 1024, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            per_cu = 0;
+        }
+        h->team_fit = (long long)per_cu * h->cus >= (long long)team_grid(h) ? 1 : 0;
+    }
+    return h->team_fit == 1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -145,6 +194,7 @@ const char* evac_status_string(int s) {
         case EVAC_ERR_UNSUPPORTED: return "unsupported configuration";
         case EVAC_ERR_HIP: return "HIP error";
         case EVAC_ERR_NO_DEVICE: return "no HIP device";
+        case EVAC_ERR_TEAM_ABORTED: return "a team rollout lost a member";
         default: return "unknown status";
     }
 }
@@ -246,6 +296,7 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         // against 1.59e9).  EVAC_CU_WIDE=1 / 0 forces, for tests.
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+        h->cus = cus;
         const char* cw = std::getenv("EVAC_CU_WIDE");
         const bool one_wave = h->sub_lanes == 0 && cfg->number_of_pedestrians <= evac::kWave;
         h->cu_wide = one_wave && (cw && cw[0] == '1' ? true : (cw && cw[0] == '0' ? false : (num_envs >= 16 * cus && num_envs <= 64 * cus)));
@@ -254,22 +305,15 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         const int wpe = waves_per_env(cfg->number_of_pedestrians);
         const long long waves = h->sub_lanes ? ((long long)num_envs * h->sub_lanes + 63) / 64 : (long long)num_envs * wpe;
         h->p.fair = waves <= 2ll * 16 * cus ? 1 : 0;
-        // Packed rollouts (evac_packed.h) are opt-in (EVAC_PACK=1): they halve the instructions of a late-episode env but also
-        // the waves in flight, and a launch of ONE round (4096 envs) is bound by the latency of a wave's step, not by issue
-        // slots -- 1.65e9 against 1.63e9 env-steps/s with 100-step launches, 1.01e9 against 1.07e9 with 20-step launches (the
-        // pairing costs two barriers per launch); launches many rounds deep gain: 65 536 envs 2.08e9 against 1.87e9.  Whether
-        // an env is packed changes the rounding of its summed observations, so the switch is global, not per batch size.
         // four-wave envs (N = 129..256, all pairs): 4 envs per CU-wide workgroup with per-env LDS barriers, pace and schedule
         h->cu_wide4 = h->sub_lanes == 0 && wpe == 4 && !h->cells &&
                       (cw && cw[0] == '1' ? true : (cw && cw[0] == '0' ? false : (num_envs >= 4 * cus && num_envs <= 16 * cus)));
-        const char* pk = std::getenv("EVAC_PACK");
         const char* sp = std::getenv("EVAC_SPECIALIZE");     // EVAC_SPECIALIZE=0: always the generic kernels (A/B runs)
         h->default_cfg = !(sp && sp[0] == '0');              // (completed below, once Params is filled)
-        h->p.pack = (one_wave && cfg->positions == EVAC_POS_GRAV && pk && pk[0] == '1') ? 1 : 0;
         const bool obs_default = cfg->positions == EVAC_POS_GRAV
                                      ? p.grav_pow_int == 5
                                      : (cfg->positions == EVAC_POS_REL && cfg->statuses == EVAC_STAT_OHE && cfg->type == EVAC_TYPE_BOX);
-        h->default_cfg = h->default_cfg && obs_default && !h->p.pack && p.small_noise == 2 && p.ens == 1.0f &&
+        h->default_cfg = h->default_cfg && obs_default && p.small_noise == 2 && p.ens == 1.0f &&
                          p.one_minus_ens == 0.0f &&
                          (p.flags & (evac::kFlagTermOnWall | evac::kFlagNanGuard)) == 0;
         h->sched = nullptr;
@@ -278,6 +322,11 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         // workgroup per CU), teams are laid out in rows of 8 (one per XCD).  EVAC_TEAM=0 disables, 2 / 4 / 8 forces a size.
         h->team_k = 0;
         h->team_bound = false;
+        h->team_fit = -1;
+        h->team_coop = false;
+        h->team_fault = false;
+        h->team_flag_host = nullptr;
+        h->team_flag_dev = nullptr;
         if (cfg->number_of_pedestrians > 512) {
             const char* tm = std::getenv("EVAC_TEAM");
             const int want = tm ? std::atoi(tm) : -1;
@@ -285,6 +334,26 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
             for (int k = 8; k >= 2; k >>= 1)
                 if ((want < 0 || want == k) && rows * k <= cus) { h->team_k = k; break; }
             if (want == 0 || (want < 0 && std::getenv("EVAC_CELLS"))) h->team_k = 0;   // an A/B run of the one-workgroup families
+        }
+        if (h->team_k) {
+            DeviceGuard g(device);
+            void* host = nullptr;
+            void* dev = nullptr;
+            if (hipHostMalloc(&host, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dev, host, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                if (host) (void)hipHostFree(host);
+                h->team_k = 0;                       // no error word, no teams
+            } else {
+                std::memset(host, 0, 64);
+                h->team_flag_host = (volatile unsigned*)host;
+                h->team_flag_dev = (unsigned*)dev;
+                int coop = 0;
+                const char* tc = std::getenv("EVAC_TEAM_COOP");
+                if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) != hipSuccess) coop = 0;
+                h->team_coop = coop != 0 && !(tc && tc[0] == '0');
+                const char* tf = std::getenv("EVAC_TEAM_FAULT");
+                h->team_fault = tf && tf[0] == '1';
+            }
         }
     }
     p.seed_lo = (uint32_t)(seed & 0xffffffffull);
@@ -301,16 +370,26 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         h->variant[0] = std::string("k_step") + kind + fam + (grav ? ", grav obs>" : ", generic obs>");
         if (h->cu_wide) fam = evac::Wave<1, 1024>::kName;
         if (h->cu_wide4) fam = evac::Wave<4, 1024>::kName;
-        if (h->team_k) fam = h->team_k == 8 ? evac::Team<8>::kName : (h->team_k == 4 ? evac::Team<4>::kName : evac::Team<2>::kName);
         h->variant[1] = std::string("k_rollout") + kind + fam + (grav ? ", grav obs>" : ", generic obs>");
+        if (h->team_k) fam = h->team_k == 8 ? evac::Team<8>::kName : (h->team_k == 4 ? evac::Team<4>::kName : evac::Team<2>::kName);
+        h->variant[2] = std::string("k_rollout") + kind + fam + (grav ? ", grav obs>" : ", generic obs>");
     }
     *out = h;
     return EVAC_OK;
 }
 
-const char* evac_kernel_variant(evac_handle_t h, int32_t rollout) { return h ? h->variant[rollout ? 1 : 0].c_str() : ""; }
+const char* evac_kernel_variant(evac_handle_t h, int32_t rollout) {
+    if (!h) return "";
+    if (!rollout) return h->variant[0].c_str();
+    // the path evac_rollout takes right now: teams only with their exchange areas bound and a grid that fits the device
+    return h->variant[(h->team_k && h->team_bound && h->team_fit != 0) ? 2 : 1].c_str();
+}
 
 int evac_destroy(evac_handle_t h) {
+    if (h && h->team_flag_host) {
+        DeviceGuard g(h->device);
+        (void)hipHostFree((void*)h->team_flag_host);
+    }
     delete h;
     return EVAC_OK;
 }
@@ -369,16 +448,14 @@ int evac_bind_workspace(evac_handle_t h, void* workspace, int64_t bytes) {
     h->sched = nullptr;
     h->sched_age = -1;
     h->team_bound = false;
-    h->p.pack_stats = nullptr;
     if (!workspace) return EVAC_OK;
     const WorkspaceLayout w = workspace_layout(h);
     if (bytes < (int64_t)w.total) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_bind_workspace: workspace smaller than evac_workspace_bytes()");
     if ((uintptr_t)workspace & 255u) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_bind_workspace: workspace must be 256-byte aligned");
     char* base = (char*)workspace;
     h->sched = (int32_t*)(base + w.sched);
-    h->p.pack_stats = (unsigned*)(base + w.stats);
     if (h->team_k) {
-        h->p.team_err = (unsigned*)(base + w.team_err);
+        h->p.team_err = h->team_flag_dev;           // (the workspace keeps its 128-byte slot: older layouts stay valid)
         h->p.team_ctr = (unsigned*)(base + w.team_ctr);
         h->p.team_cnt = base + w.team_cnt;
         h->p.team_rec = base + w.team_rec;
@@ -391,17 +468,26 @@ int evac_bind_workspace(evac_handle_t h, void* workspace, int64_t bytes) {
 int evac_team_error(evac_handle_t h, int32_t* out) {
     if (!h || !out) return EVAC_ERR_INVALID_ARGUMENT;
     *out = 0;
-    if (!h->team_bound) return EVAC_OK;
+    if (!h->team_flag_host) return EVAC_OK;
     DeviceGuard g(h->device);
-    unsigned v = 0;
-    if (hipMemcpy(&v, h->p.team_err, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return fail(h, EVAC_ERR_HIP, "evac_team_error: hipMemcpy failed");
-    *out = (int32_t)v;
+    if (hipDeviceSynchronize() != hipSuccess) return fail(h, EVAC_ERR_HIP, "evac_team_error: hipDeviceSynchronize failed");
+    *out = (int32_t)*h->team_flag_host;
+    return EVAC_OK;
+}
+
+int evac_team_clear_error(evac_handle_t h) {
+    if (!h) return EVAC_ERR_INVALID_ARGUMENT;
+    if (h->team_flag_host) {
+        if (*h->team_flag_host != 0u) h->team_k = 0;      // the handle stays on one workgroup per env
+        *h->team_flag_host = 0u;
+    }
     return EVAC_OK;
 }
 
 #define EVAC_REQUIRE_BOUND(h, name)                                               \
     if (!(h)) return EVAC_ERR_INVALID_ARGUMENT;                                  \
-    if (!(h)->bound) return fail((h), EVAC_ERR_NOT_BOUND, name ": call evac_bind_state first")
+    if (!(h)->bound) return fail((h), EVAC_ERR_NOT_BOUND, name ": call evac_bind_state first"); \
+    if (const int ta_ = team_aborted((h), name); ta_ != EVAC_OK) return ta_
 
 int evac_reset(evac_handle_t h, const uint8_t* mask, const float* draws, float* obs_out, void* stream) {
     EVAC_REQUIRE_BOUND(h, "evac_reset");
@@ -459,31 +545,29 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
     if (capture || actions_out || noise)
         EVAC_DISPATCH(h, k_rollout_diag, stream, h->p, (int)n_steps, (const float2*)actions, (float2*)actions_out, slab_out,
                       final_stats, (int)capture_envs, capture, noise);
-    else if (h->team_k && h->team_bound) {
+    else if (h->team_k && h->team_bound && team_grid_fits(h)) {
         // 513..1024 pedestrians, few envs: K workgroups (CUs) per env (evac_team.h).  The teams' barrier counters start
-        // every launch at zero; workgroup b = j * 8 + xcd carries team (j / K) * 8 + xcd.
+        // every launch at zero; workgroup b = j * 8 + xcd carries team (j / K) * 8 + xcd.  All members of a team spin on its
+        // counter, so the whole grid must be resident at once: checked by team_grid_fits (occupancy x CUs >= workgroups; a grid
+        // that does not fit runs the one-workgroup-per-env kernels below) and, where the device supports it, guaranteed by a
+        // cooperative launch even when another stream has kernels in flight.
         hipStream_t s_ = (hipStream_t)stream;
-        const int E = h->p.n_envs, K = h->team_k;
+        const int E = h->p.n_envs;
         if (hipMemsetAsync(h->p.team_ctr, 0, (size_t)E * 128, s_) != hipSuccess) return fail(h, EVAC_ERR_HIP, "evac_rollout: hipMemsetAsync failed");
-        const dim3 grid((unsigned)((E + 7) / 8 * 8 * K)), block(1024);
-        const bool grav = h->p.obs_pos == EVAC_POS_GRAV;
-#define EVAC_LAUNCH_TEAM_K(KERNEL, K_)                                                                                    \
-    do {                                                                                                                  \
-        if (grav) hipLaunchKernelGGL((evac::KERNEL<evac::Team<K_>, true>), grid, block, 0, s_, h->p, (int)n_steps,         \
-                                     (const float2*)actions, slab_out, final_stats, (const int*)nullptr, (int*)nullptr);   \
-        else hipLaunchKernelGGL((evac::KERNEL<evac::Team<K_>, false>), grid, block, 0, s_, h->p, (int)n_steps,             \
-                                (const float2*)actions, slab_out, final_stats, (const int*)nullptr, (int*)nullptr);        \
-    } while (0)
-#define EVAC_LAUNCH_TEAM(K_)                                                               \
-    do {                                                                                   \
-        if (h->default_cfg) EVAC_LAUNCH_TEAM_K(k_rollout_default_config, K_);              \
-        else EVAC_LAUNCH_TEAM_K(k_rollout, K_);                                            \
-    } while (0)
-        if (K == 8) EVAC_LAUNCH_TEAM(8);
-        else if (K == 4) EVAC_LAUNCH_TEAM(4);
-        else EVAC_LAUNCH_TEAM(2);
-#undef EVAC_LAUNCH_TEAM
-#undef EVAC_LAUNCH_TEAM_K
+        const dim3 grid(team_grid(h)), block(1024);
+        int n_steps_ = (int)n_steps;
+        const float2* actions_ = (const float2*)actions;
+        const int* perm_ = nullptr;
+        int* moving_ = nullptr;
+        void* argv[] = {(void*)&h->p, (void*)&n_steps_, (void*)&actions_, (void*)&slab_out, (void*)&final_stats, (void*)&perm_, (void*)&moving_};
+        const void* fn = team_kernel(h);
+        hipError_t le = h->team_coop ? hipLaunchCooperativeKernel(fn, grid, block, argv, 0, s_) : hipLaunchKernel(fn, grid, block, argv, 0, s_);
+        if (le != hipSuccess && h->team_coop) {      // (e.g. under stream capture): the occupancy check still holds for a plain launch
+            (void)hipGetLastError();
+            h->team_coop = false;
+            le = hipLaunchKernel(fn, grid, block, argv, 0, s_);
+        }
+        if (le != hipSuccess) return fail(h, EVAC_ERR_HIP, std::string("evac_rollout (team launch): ") + hipGetErrorString(le));
     } else if (h->cu_wide || h->cu_wide4) {
         // one-wave envs, batch >= 16 envs per CU: CU-wide workgroups, envs dealt to the SIMDs by load when a schedule scratch
         // is bound (rebuilt every 50..200 env steps: the loads drift slowly)
@@ -613,6 +697,10 @@ int evac_norm_step(evac_handle_t h, float* obs, float* final_obs, float* reward,
 }
 
 #ifdef EVAC_STAMP
+int evac_debug_step_times(unsigned long long* out2048) {
+    if (hipMemcpyFromSymbol(out2048, HIP_SYMBOL(g_step_times), 16 * 128 * sizeof(unsigned long long)) != hipSuccess) return EVAC_ERR_HIP;
+    return EVAC_OK;
+}
 // diagnostic build only: read and clear the per-phase cycle sums
 int evac_debug_stamps(unsigned long long* out16) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return EVAC_ERR_HIP;

@@ -28,6 +28,7 @@
 // summed per phase over all waves into g_stamps.  No stamp executes in the shipped library.
 #ifdef EVAC_STAMP
 __device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_step_times[16][128];   // s_memrealtime (100 MHz) at the top of step t of the 16 waves of workgroup 0
 struct StampState {
     unsigned long long acc[16] = {};
     unsigned long long last = 0;
@@ -87,7 +88,6 @@ struct Params {
     int32_t grav_pow_int;                           // alpha+2 if it is an integer in [1,63], else 0
     int32_t small_noise;                            // sin/cos regime: 2 short Taylor, 1 long Taylor, 0 ocml sincosf (noise_sincos)
     uint32_t seed_lo, seed_hi, env_id_offset;
-    int32_t pack;                                   // rollouts pack two late-episode one-wave envs into a wave (evac_packed.h)
     int32_t fair;                                   // rollouts rotate the wave priorities (launches of one or two rounds: evac_create)
     // cell list (Cells family): cell = (int)((x + cell_ox) * cell_inv_hx) clamped to [0, 15], same in y;
     // head_scale = min(2^23 - 1, (2^31 - 1) / N): unit headings are summed as integers (exact, order-independent)
@@ -102,7 +102,6 @@ struct Params {
     // cnt [2][E][8] x 8 B, rec [2][E][32] x 16 B, ctr [E][32] x 4 B (zeroed by the host before every launch), err [32] x 4 B
     void *team_tile, *team_cnt, *team_rec;
     unsigned *team_ctr, *team_err;
-    unsigned* pack_stats;                           // workspace: [0] env-launches that ran packed so far (cumulative), or NULL
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -154,6 +153,10 @@ __device__ __forceinline__ int dpp_addi(int v) {
 // VALU instruction costs wait states (the compiler pads a single chain with s_nop); with three independent
 // chains in lock-step the hazard is covered by real work.
 #define EVAC_DPP3(CTRL, MASK) a = dpp_add<CTRL, MASK>(a); b = dpp_add<CTRL, MASK>(b); c = dpp_add<CTRL, MASK>(c);
+template <int LANE>
+__device__ __forceinline__ float readlane_const(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), LANE));
+}
 // The two row_bcast steps with a partial row mask: written through update_dpp the compiler emits
 // v_mov 0 / v_mov_dpp / v_add for each (the masked-off rows must add 0); as v_add_f32_dpp on the accumulator itself the
 // masked-off rows simply keep their value -- one instruction per step.  The three chains are interleaved so that every
@@ -171,7 +174,36 @@ __device__ __forceinline__ void dpp_bcast_fold3(float& a, float& b, float& c) {
         "s_nop 1"
         : "+v"(a), "+v"(b), "+v"(c));
 }
+#ifndef EVAC_SUM3_PERMLANE
+#define EVAC_SUM3_PERMLANE 1      // 0: the three interleaved DPP chains of rounds 1-2 (A/B builds)
+#endif
 __device__ __forceinline__ void wave_sum3(float& a, float& b, float& c) {
+#if EVAC_SUM3_PERMLANE
+    // gfx950's half / row swaps PACK the three sums into one register before a single DPP chain runs:
+    //   v_permlane32_swap a, b : a' = [a.lo | b.lo], b' = [a.hi | b.hi]  ->  a' + b' = 32-lane partial sums [a | b]
+    //   the same with (c, 0)                                             ->                                  [c | 0]
+    //   v_permlane16_swap of the two (odd rows of the first with even rows of the second), added
+    //                                                                   ->  16-lane partial sums, rows [a, c, b, 0]
+    //   row_shr 1/2/4/8 on that ONE register: the totals land in lanes 15 (a), 31 (c), 47 (b).
+    // 3 swaps + 3 adds + 4 DPP adds + 3 readlanes instead of 18 DPP adds + 3 readlanes (a DPP add occupies the SIMD ~2.5x as
+    // long as a plain one: tools/microbench/valu_rates.hip).  A fixed tree, shared by every kernel family and entry point.
+    // (inline asm: with the __builtin_amdgcn_permlane*_swap builtins hipcc 7.2 lost the second result of a swap inside the
+    // step body -- both adds read the first -- although a small test kernel compiled correctly.  The leading s_nop covers the
+    // "VALU write -> v_permlane read" hazard of gfx950 for whatever instruction precedes.)
+    float z = 0.0f;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c), "+v"(z));
+    float pab = a + b, pcz = c + z;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(pab), "+v"(pcz));
+    float s = pab + pcz;
+    s = dpp_add<0x111, 0xf>(s);
+    s = dpp_add<0x112, 0xf>(s);
+    s = dpp_add<0x114, 0xf>(s);
+    s = dpp_add<0x118, 0xf>(s);
+    a = readlane_const<15>(s);
+    c = readlane_const<31>(s);
+    b = readlane_const<47>(s);
+#else
     EVAC_DPP3(0x111, 0xf)
     EVAC_DPP3(0x112, 0xf)
     EVAC_DPP3(0x114, 0xf)
@@ -180,6 +212,7 @@ __device__ __forceinline__ void wave_sum3(float& a, float& b, float& c) {
     a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
     b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 63));
     c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), 63));
+#endif
 }
 // Two integer sums over the 64 lanes, the totals in LANE 63 (the row_shr / row_bcast scheme of wave_sum3, two chains
 // interleaved; the s_nop between the bcast steps is the DPP read-after-VALU-write wait state the third chain covers there).

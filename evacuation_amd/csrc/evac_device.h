@@ -12,6 +12,22 @@
 #include "evac_common.h"
 #include "evac_families.h"
 
+#ifndef EVAC_LAZY_HEADING
+#define EVAC_LAZY_HEADING 1   // 0: every wave evaluates the heading block and draws its noise every step (A/B builds)
+#endif
+#ifndef EVAC_PRIO_START
+#define EVAC_PRIO_START 1     // 0: every wave starts a launch at priority 0 (A/B builds)
+#endif
+#ifndef EVAC_HEAVY_FIRST
+#define EVAC_HEAVY_FIRST 1    // 0: k_schedule puts the heaviest quartile into the SIMD's youngest wave (the round-2 deal; A/B builds)
+#endif
+#ifndef EVAC_ROT7
+#define EVAC_ROT7 1           // 0: normalise, rotate, scale as three steps (the round-2 form; A/B builds)
+#endif
+#ifndef EVAC_NT_SLAB
+#define EVAC_NT_SLAB 0        // 1: the rollout's slab rows leave with non-temporal stores (A/B builds)
+#endif
+
 namespace evac {
 
 // ------------------------------------------------------------------------------------------------
@@ -116,14 +132,36 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     // ---- new heading = mean heading rotated by the noise: area.py:120-136.
     // cos/sin(arctan2(my,mx)+eta) = rotation of (mx,my)/|m| by eta; arctan2(0,0) = 0.
     {
-        const bool zero_mean = sx == 0.0f && sy == 0.0f;
-        const float il = frsq(sx * sx + sy * sy);
-        const float cx = zero_mean ? 1.0f : sx * il;
-        const float cy = zero_mean ? 0.0f : sy * il;
-        float sn, cs;
-        noise_sincos(noise, p.small_noise, sn, cs);
-        const float ndx = (cx * cs - cy * sn) * p.step_size;
-        const float ndy = (cy * cs + cx * sn) * p.step_size;
+        // Only the lanes whose row was evaluated use the result (a follower's is multiplied by 0 below).  A wave without any
+        // such lane -- late in an episode most waves: tools/moving_distribution.py -- skips the block (and its caller the
+        // noise draw, see rollout_body): the neighbour sum it would normalise is 0 there, or the NaN of a poisoned env, and
+        // 0 * (a finite heading) is the 0 that 0 * 0 is (up to the sign of a zero direction component).
+        float ndx = sx, ndy = sy;
+#if EVAC_LAZY_HEADING
+        if (ballot(row) != 0ull) {
+            asm volatile("");                 // (a real uniform branch: keep the compiler from if-converting 25 instructions)
+#else
+        {
+#endif
+            const bool zero_mean = sx == 0.0f && sy == 0.0f;
+            float sn, cs;
+            noise_sincos(noise, p.small_noise, sn, cs);
+#if EVAC_ROT7
+            // step_size * unit mean heading, then ONE rotation: 7 instructions (scale the normaliser, two products, two
+            // multiply-adds) where normalise / rotate / scale took 10
+            const float ils = frsq(sx * sx + sy * sy) * p.step_size;
+            const float cx = zero_mean ? p.step_size : sx * ils;
+            const float cy = zero_mean ? 0.0f : sy * ils;
+            ndx = __builtin_fmaf(cx, cs, -(cy * sn));
+            ndy = __builtin_fmaf(cy, cs, cx * sn);
+#else
+            const float il = frsq(sx * sx + sy * sy);
+            const float cx = zero_mean ? 1.0f : sx * il;
+            const float cy = zero_mean ? 0.0f : sy * il;
+            ndx = (cx * cs - cy * sn) * p.step_size;
+            ndy = (cy * cs + cx * sn) * p.step_size;
+#endif
+        }
         q.dx = fv ? ndx : q.dx;                                             // area.py:136
         q.dy = fv ? ndy : q.dy;
         float bdx, bdy;                                                     // area.py:139-142
@@ -201,11 +239,11 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
         out.gy = s.f2;
     }
     EVAC_T(c, 5);   // classify + reductions
-    out.n_escaped = s.i[2] + F::escaped_elsewhere(c);
+    out.n_escaped = s.i[2];
     out.n_follower = s.i[4];
     out.n_exiting = out.n_viscek = 0;   // filled by finish_counts() when the episode ends
 
-    out.terminated = term_agent || (s.i[2] + F::escaped_elsewhere(c) == p.n_ped);   // area.py:175-178, env.py:171
+    out.terminated = term_agent || (s.i[2] == p.n_ped);   // area.py:175-178, env.py:171
     if (!work) return;                        // helper waves: the flags steer them, rewards and episode sums are the ped waves'
     float r_ped = p.init_reward;
     if constexpr (F::kEnvUniform) {
@@ -276,9 +314,6 @@ __device__ __forceinline__ void pace_step(Smem& sm, int simd, int k, int lane, i
     }
 }
 
-}  // namespace evac
-#include "evac_packed.h"
-namespace evac {
 
 // ------------------------------------------------------------------------------------------------
 // Kernels of the Wave / Cells families.  __launch_bounds__(block, 4): at least 4 waves per SIMD, i.e. at most
@@ -381,7 +416,11 @@ __device__ __forceinline__ void step_kernel_body(
     const uint32_t gid = p.env_id_offset + (uint32_t)w.env;
     const float2 a = actions[w.env];
     float nz = 0.0f;
-    if (active) nz = noise_in ? noise_in[(size_t)w.env * p.n_ped + w.i] : philox_noise(p, gid, w.i, e.total);
+    if (noise_in) {
+        if (active) nz = noise_in[(size_t)w.env * p.n_ped + w.i];
+    } else if (!EVAC_LAZY_HEADING || ballot(needs_row(p, q.st)) != 0ull) {   // (only a lane whose row is evaluated uses its draw: step_env)
+        nz = philox_noise(p, gid, w.i, e.total);
+    }
     StepOut o;
     step_env<F, GRAV>(p, w, active, q, e, agent_direction(p, a.x, a.y), nz, o);
     step_outputs<F, GRAV, NORM>(p, w, active, q, e, o, gid, autoreset, obs_out, reward_out, term_out, trunc_out, final_obs,
@@ -397,7 +436,6 @@ __device__ __forceinline__ Params default_config_constants(Params p) {
     p.small_noise = 2;
     p.ens = 1.0f;
     p.one_minus_ens = 0.0f;
-    p.pack = 0;
     if constexpr (GRAV) {
         p.grav_pow_int = 5;                       // gravity observation with alpha = 3 (wrappers/config.py default)
     } else {
@@ -461,8 +499,8 @@ __device__ __forceinline__ void rollout_body(
     const uint32_t gid = p.env_id_offset + (uint32_t)w.env;
     const size_t E = (size_t)p.n_envs;
     const int row = p.obs_dim + 3;
-    uint4 nzr = make_uint4(0, 0, 0, 0);
-    bool have = false;
+    uint32_t nzw[4] = {0u, 0u, 0u, 0u};       // the four noise words of Philox block `noise_group` (wave-uniform; -1: none)
+    int noise_group = -1;
     // RandomAgent actions and the leader directions they give (area.py:189-192) are produced 64 steps at a
     // time, one step per LANE (a per-wave scalar Philox would cost ~100 SALU instructions every step),
     // and fetched per step with v_readlane.
@@ -478,10 +516,6 @@ __device__ __forceinline__ void rollout_body(
     if constexpr (EVAC_PRIO && F::kPace) {
         if (w.lane == 0) sm.progress[EVAC_PACE_SIMD * 4 + EVAC_PACE_K] = 0;
     }
-    // late in an episode two one-wave envs with at most 32 moving pedestrians each share a wave (evac_packed.h)
-    if constexpr (GRAV && !DIAG && std::is_same<F, Wave<1, F::kBlock>>::value) {
-        if (p.pack && try_pack<F, GRAV>(sm, p, w, q, e, active, n_steps, actions, slab_out, moving_out)) return;
-    }
     constexpr bool kRotate = EVAC_PRIO && !F::kPace && std::is_same<F, Wave<F::WPE>>::value && F::WPE < 16;
     int prio_slot = 0;
     if constexpr (kRotate) prio_slot = simd_wave_slot();
@@ -491,9 +525,31 @@ __device__ __forceinline__ void rollout_body(
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0_)::"memory");
     const unsigned long long ck0_ = w.stamp.last;
 #endif
+    // Start-of-launch priorities.  With a schedule (k_schedule) the SIMD's k-th wave carries an env of the k-th load quartile
+    // (EVAC_HEAVY_FIRST: the heaviest in the SIMD's OLDEST wave, so that age -- the arbiter's tie-break -- works for it too),
+    // and the heaviest wave of a SIMD ends the launch: it starts with the highest priority instead of earning it over the
+    // first steps (pace_step's information is a step old; with equal priorities the twelve lighter waves of the CU ran their
+    // first steps first and the heavy ones began 3-4 us late: tools/step_times.py).  `pace_seen` is seeded so that step 0
+    // confirms that rank.
     int pace_seen = 0, pace_prio = 0;
+#if EVAC_PRIO_START
+    if constexpr (EVAC_PRIO && F::kPace && F::WPE == 1) {
+        if (perm) {
+            pace_prio = EVAC_HEAVY_FIRST ? 3 - (w.slot >> 2) : (w.slot >> 2);
+            set_wave_priority(pace_prio);
+            pace_seen = (w.lane & 3) < pace_prio ? (1 << 30) : -1;
+        }
+    }
+#endif
     int staged = 0;                       // t % kStageSteps: the slot of the step in the staging block
     for (int t = 0; t < n_steps; ++t) {
+#ifdef EVAC_STAMP
+        if (w.lane == 0 && t < 128 && blockIdx.x == 0 && threadIdx.x < 1024) {
+            unsigned long long now_;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");
+            g_step_times[threadIdx.x >> 6][t] = now_;
+        }
+#endif
         if constexpr (kRotate) {
             if (p.fair) {
                 // workgroup-per-env kernels: longest job first -- the env's load (its moving pedestrians, known from the last
@@ -529,21 +585,29 @@ __device__ __forceinline__ void rollout_body(
         adir.x = readlane_f(lane_adir.x, slot64);
         adir.y = readlane_f(lane_adir.y, slot64);
         if (DIAG && actions_out && w.owner) actions_out[(size_t)t * E + w.env] = a;   // diagnostic face only
-        // one Philox call serves four consecutive steps of this pedestrian
-        const uint32_t sel = e.total & 3u;
+        // One Philox call serves four consecutive steps of this pedestrian: word (total & 3) of the block with counter
+        // total >> 2.  The draw is LAZY: only a lane whose row is evaluated uses its noise (step_env), so a wave without such a
+        // lane -- most waves late in an episode -- neither draws nor, at the next group of four steps, calls Philox at all;
+        // `noise_group` is the block the four words in registers belong to.  The word is picked by the wave-uniform index
+        // (a scalar-indexed register move), not by rotating the four registers every step.
         bool draws = true;                      // (team kernels: waves without pedestrians draw no noise)
         if constexpr (F::kHelpers) draws = !w.helper;
-        if (draws && (!have || sel == 0u) && !(EVAC_ABLATE & 4)) {
-            nzr = philox4x32_10(make_uint4(gid, (uint32_t)w.i, e.total >> 2, kStreamNoise), p.seed_lo, p.seed_hi);
-            // word `total & 3` of the call is this step's draw: the words are ROTATED so that it always sits in .x (a uniform
-            // four-way select costs ~10 scalar instructions and three branches per step); a launch that starts inside a
-            // group of four steps rotates to its word first
-            for (uint32_t k = 0; k < sel; ++k) nzr = make_uint4(nzr.y, nzr.z, nzr.w, nzr.x);
-            have = true;
+        float nz = 0.0f;
+#if EVAC_LAZY_HEADING
+        const bool wants_noise = ballot(needs_row(p, q.st)) != 0ull;
+#else
+        const bool wants_noise = true;
+#endif
+        if (draws && wants_noise && !(EVAC_ABLATE & 4)) {
+            const int group = (int)(e.total >> 2);
+            if (group != noise_group) {
+                asm volatile("");
+                const uint4 r = philox4x32_10(make_uint4(gid, (uint32_t)w.i, e.total >> 2, kStreamNoise), p.seed_lo, p.seed_hi);
+                nzw[0] = r.x; nzw[1] = r.y; nzw[2] = r.z; nzw[3] = r.w;
+                noise_group = group;
+            }
+            nz = u01_centred(nzw[e.total & 3u]) * p.noise_coef;
         }
-        const uint32_t wsel = nzr.x;
-        nzr = make_uint4(nzr.y, nzr.z, nzr.w, nzr.x);
-        float nz = u01_centred(wsel) * p.noise_coef;
         if constexpr (DIAG) {
             if (noise_in) nz = active ? noise_in[((size_t)t * E + w.env) * p.n_ped + w.i] : 0.0f;   // injection mode
         }
@@ -590,7 +654,12 @@ __device__ __forceinline__ void rollout_body(
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         if (fl_s <= staged) {
                             const float v = sm.stage[w.slot][fl_s][fl_k];
-                            slab_out[((size_t)(t - staged + fl_s) * E + w.env) * kGravRow + fl_k] = v;
+                            float* dst = &slab_out[((size_t)(t - staged + fl_s) * E + w.env) * kGravRow + fl_k];
+#if EVAC_NT_SLAB
+                            __builtin_nontemporal_store(v, dst);
+#else
+                            *dst = v;
+#endif
                         }
                     }
                 }
@@ -633,6 +702,9 @@ __device__ __forceinline__ void rollout_body(
             if (w.owner) moving_out[w.env] = nm;
         }
     }
+    if constexpr (F::kHelpers) {
+        if (F::aborted(w)) return;      // a team that lost a member: void results, the env keeps its pre-launch state
+    }
     store_env(p, w.env, w.i, active, w.owner, q, e);
 }
 
@@ -645,7 +717,7 @@ __global__ __launch_bounds__(F::kBlock, 4) void k_rollout(
 }
 
 // The same kernel specialised for the reference's default configuration (what its training scripts and the benchmark run):
-// |noise| <= 0.2, enslaving_degree 1, no wall termination, no NaN guard, no packing; and either the gravity observation
+// |noise| <= 0.2, enslaving_degree 1, no wall termination, no NaN guard; and either the gravity observation
 // with alpha = 3 or the Box observation of relative positions + one-hot statuses.  The options are wave-uniform branches in the generic kernel -- a compare, a
 // branch and often a taken jump each, ~50 scalar instructions of a step whose cost for a lone wave is its instruction count
 // times ~8 cycles; here they are constants the compiler folds.  Same arithmetic on the path taken: bit-identical results
@@ -690,7 +762,9 @@ __global__ __launch_bounds__(1024) void k_schedule(int n_envs, const int* __rest
         if (r < e16) {
             const int k = r / G, j = r - k * G;
             const int g = (k & 1) ? G - 1 - j : j;   // snake: quarters 0 and 2 ascending, 1 and 3 descending
-            slot = per_wg == 16 ? (g >> 2) * 16 + k * 4 + (g & 3)   // workgroup g / 4, SIMD g % 4, the SIMD's k-th wave
+            // (one-wave envs: the heaviest quartile goes to the SIMD's first -- oldest -- wave, see rollout_body)
+            const int kk = (per_wg == 16 && EVAC_HEAVY_FIRST) ? 3 - k : k;
+            slot = per_wg == 16 ? (g >> 2) * 16 + kk * 4 + (g & 3)  // workgroup g / 4, SIMD g % 4, the SIMD's kk-th wave
                                 : g * 4 + k;                        // workgroup g, its k-th env
         }
         perm[slot] = e;

@@ -71,14 +71,6 @@ struct Wave {
         // rollout outputs of up to kStageSteps steps, flushed with ONE 64-lane store (GRAV kernels)
         alignas(16) float stage[kEnvsPerBlock][kStageSteps][12];   // rows written as two 16-byte vectors + 1 word
         alignas(16) int progress[kPace ? 16 : 4];                  // kPace: step counter of every wave, [SIMD][wave of the SIMD]
-        // WPE == 1: packing of two late-episode envs into one wave (evac_packed.h): eligibility per wave; per pair of waves the
-        // 2 x 32 compacted pedestrians (x, y, dx, dy | status, id) and the two envs' scalars
-        static constexpr int kPairs = WPE == 1 ? kEnvsPerBlock / 2 : 1;
-        int pk_elig[WPE == 1 ? kEnvsPerBlock : 1];
-        alignas(16) f4 pk_ped[kPairs][kWave];
-        i2 pk_tag[kPairs][kWave];
-        alignas(16) f4 pk_env[kPairs][2][3];
-        int pk_slot[kPairs][2];                                    // the two waves of a pair (their staging rows)
     };
 
     struct Ctx {
@@ -141,8 +133,6 @@ struct Wave {
         }
     }
 
-    template <class C>
-    static __device__ __forceinline__ int escaped_elsewhere(const C&) { return 0; }
     static __device__ __forceinline__ void init(Ctx& c) {
         if constexpr (WPE > 1) {
             if (c.wave_in_env == 0 && c.lane < 2) c.sm.poison[c.lane][c.slot] = 0;
@@ -152,6 +142,7 @@ struct Wave {
     }
     // the statuses changed outside step_env (autoreset): the counts carried over from the last reduction are void
     static __device__ __forceinline__ void invalidate(Ctx& c) { c.have_next = false; }
+    static __device__ __forceinline__ bool aborted(Ctx&) { return false; }   // (team kernels only: a barrier timed out)
 
     // Reduce 3 floats and up to 8 predicates over all lanes of the env.  Result in every lane.
     // GUARD: a barrier in front, for callers whose previous reduction may still be read by another wave.
@@ -237,6 +228,16 @@ struct Wave {
         auto& sm = c.sm;
         int par = 0;
         if constexpr (WPE == 1) {
+            // ---- one wave per env.  `fv`: this lane's row is needed (step_env: needs_row).  NO row at all (no VISCEK pedestrian left
+            // under enslaving_degree 1: 45 % of the envs at t = 1000, tools/moving_distribution.py): no tile, no loop -- only the
+            // reference's NaN poisoning (area.py:118-119: a NaN heading among the moving pedestrians makes every row NaN), which the
+            // all-pairs loop carries through w * NaN, is applied by hand: it reaches the followers whose rows are not evaluated.
+            sx = 0.0f;
+            sy = 0.0f;
+            if (ballot(fv) == 0ull) {
+                if ((ballot(ux != ux || uy != uy) & ballot(efv)) != 0ull) sx = sy = __builtin_nanf("");
+                return;
+            }
             sync(c);   // tile readers of the previous step are done (a fence: the wave is in lock-step)
         } else {
             par = c.par;
@@ -302,14 +303,10 @@ struct Wave {
         const f4* __restrict__ tile = sm.tile[par][c.slot];
         const float r2b = kRPed2Big;
         if constexpr (WPE == 1) {
-            // rows of the distance matrix exist only for FOLLOWER/VISCEK pedestrians (area.py:104); `fv` = this lane's row is
-            // needed (step_env: needs_row).  No row at all -> no loop; then the reference's NaN poisoning, which the loop's
-            // w * NaN carries otherwise, is applied by hand (it reaches the followers whose rows are not evaluated).
-            const bool any_fv = ballot(fv) != 0ull;
-            if (!any_fv && (ballot(ux != ux || uy != uy) & moving_mask) != 0ull) sx = sy = __builtin_nanf("");
-            // Branch-free batches: the B wave-uniform ds_read_b128 broadcasts are issued back to
-            // back (LDS latency paid once per batch, no VALU slot), then 6 full-rate VALU ops per pair.
-            const int n8 = __builtin_amdgcn_readfirstlane(any_fv ? ((n_cols + 3) & ~3) : 0);   // no rows -> no loop
+            // MANY rows: all pairs, every lane a row (rows exist only for FOLLOWER/VISCEK pedestrians, area.py:104; the lanes
+            // without one compute a sum nobody uses).  Branch-free batches: the B wave-uniform ds_read_b128 broadcasts are issued
+            // back to back (LDS latency paid once per batch, no VALU slot), then 6 full-rate VALU ops per pair.
+            const int n8 = __builtin_amdgcn_readfirstlane((n_cols + 3) & ~3);
             const float XI = q.x * kTileScale, YI = q.y * kTileScale;
             // peers per LDS round trip: 16 (3.31 vs 3.34 us at 8, 3.49 at 4)
             constexpr int B = 16;
@@ -484,10 +481,9 @@ struct Cells {
     static __device__ __forceinline__ void sync() { __syncthreads(); }
     template <class C>
     static __device__ __forceinline__ void sync(C&) { __syncthreads(); }
-    template <class C>
-    static __device__ __forceinline__ int escaped_elsewhere(const C&) { return 0; }
 
     static __device__ __forceinline__ void invalidate(Ctx&) {}
+    static __device__ __forceinline__ bool aborted(Ctx&) { return false; }
     // Once per kernel, before the first step: the counters start at zero (afterwards the prefix wave clears them).
     static __device__ __forceinline__ void init(Ctx& c) {
         for (int k = c.i; k < kCells + 4; k += kThreadsPerEnv) c.sm.cnt[k] = 0;
@@ -630,10 +626,6 @@ struct Cells {
 //   * values that Wave<1> fetches with v_readlane come through ds_bpermute from a per-group source lane.
 // There is no workgroup barrier anywhere (a wave is in lock-step).
 // ------------------------------------------------------------------------------------------------
-// BLOCK_ = 1024: the PACKED use of Sub<32> inside the CU-wide rollout workgroups (evac_packed.h): late in an episode two
-// envs with at most 32 moving pedestrians each share a wave.  A lane then carries an arbitrary pedestrian id (Ctx::i; `li`
-// is its position in the group) and the env's escaped pedestrians, which are not in any lane, enter the termination test
-// through Ctx::esc_base.
 template <int G_, int BLOCK_ = 256>
 struct Sub {
     static constexpr int G = G_;
@@ -653,7 +645,6 @@ struct Sub {
     struct Ctx {
         Smem& sm;
         int env, slot, lane, sub, i, li;
-        int esc_base = 0;           // escaped pedestrians of the env that no lane carries (packed rollouts only)
         unsigned long long gmask;   // this group's lanes in a 64-bit ballot
         bool owner;                 // the group's last lane: the DPP sums are valid there
 #ifdef EVAC_STAMP
@@ -670,8 +661,6 @@ struct Sub {
             owner = li == G - 1;
         }
     };
-    template <class C>
-    static __device__ __forceinline__ int escaped_elsewhere(const C& c) { return c.esc_base; }
 
     static __device__ __forceinline__ void sync() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -688,6 +677,7 @@ struct Sub {
 
     // Sums valid in the group's last lane (three chains interleaved, see wave_sum3); counts in every lane of the group.
     static __device__ __forceinline__ void invalidate(Ctx&) {}
+    static __device__ __forceinline__ bool aborted(Ctx&) { return false; }
     template <bool GUARD, class C>
     static __device__ __forceinline__ void reduce(const Params&, C& c, Sums& s, const unsigned long long (&pred)[8]) {
         float &a = s.f0, &b = s.f1, &cc = s.f2;

@@ -27,10 +27,15 @@
 // Everything else is the common step body (step_env) and rollout scaffolding (rollout_body); waves without pedestrians
 // ("helper" waves) skip the per-pedestrian arithmetic.
 //
-// The members of a team must be resident together (they spin on the team's counter): the host launches the kernel
-// cooperatively, with at most one workgroup per CU, and places a team on ONE XCD (workgroup ids congruent mod 8 share an
-// XCD -- round-robin dispatch; nothing depends on it but the latency).  Spins are bounded: a team that lost a member sets
-// a sticky abort flag and runs to the end without waiting (the results of that launch are void, err[0] tells the host).
+// The members of a team must be resident together (they spin on the team's counter).  The host (evac_rollout, evac_api.hip)
+// checks with hipOccupancyMaxActiveBlocksPerMultiprocessor that the whole grid fits the device at once (one 1024-thread
+// workgroup per CU) -- otherwise the handle runs the one-workgroup-per-env kernels -- and launches with
+// hipLaunchCooperativeKernel where the device supports it, so that the runtime, not luck, keeps the members co-resident when
+// another stream (the all-gather of the sharded env) has work in flight.  A team sits on ONE XCD (workgroup ids congruent
+// mod 8 share an XCD -- round-robin dispatch; nothing depends on it but the latency).  Spins are bounded all the same: a
+// team that lost a member sets a sticky abort flag, runs to the end without waiting, does NOT write its env's state back
+// (the state of that env stays what it was before the launch) and raises the handle's error word -- host-mapped memory that
+// the next evac_* call of the handle reads without synchronising and turns into EVAC_ERR_TEAM_ABORTED.
 #pragma once
 
 #include "evac_device.h"
@@ -136,9 +141,12 @@ struct Team {
     };
 
     static __device__ __forceinline__ void sync() { __syncthreads(); }
-    template <class C>
-    static __device__ __forceinline__ int escaped_elsewhere(const C&) { return 0; }
     static __device__ __forceinline__ void invalidate(Ctx& c) { c.tile_valid = false; }   // the state changed outside step_env (autoreset)
+    // a barrier of this launch timed out: the env's results are void and its state is not written back (rollout_body)
+    static __device__ __forceinline__ bool aborted(Ctx& c) {
+        __syncthreads();
+        return c.sm.abort != 0;
+    }
     static __device__ __forceinline__ void init(Ctx& c) {
         if (threadIdx.x == 0) c.sm.abort = 0;
         if (threadIdx.x < PW * kWave) *(i2*)c.sm.acc[threadIdx.x / kWave][threadIdx.x % kWave] = i2{0, 0};
@@ -157,7 +165,7 @@ struct Team {
                 __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else if (!arrive_and_spin(ctr, c.round * (unsigned)K)) {
                 c.sm.abort = 1;
-                __hip_atomic_store(p.team_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.team_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped: the host reads it without a sync
             }
         }
         __syncthreads();

@@ -60,6 +60,12 @@ def all_gather_envs(local: torch.Tensor, env_dim: int = -2, group=None, out: Opt
         out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
     # concatenated-along-dim-0 form: accepted by both RCCL and gloo
     flat_out = out.view((world * local.shape[0],) + tuple(local.shape[1:]))
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # testing aid (several ranks sharing one GPU rendezvous over gloo, which gathers host tensors): stage through the host
+        host = torch.empty(flat_out.shape, dtype=flat_out.dtype)
+        dist.all_gather_into_tensor(host, local.cpu(), group=group)
+        flat_out.copy_(host)
+        return out, None
     work = dist.all_gather_into_tensor(flat_out, local, group=group, async_op=async_op)
     return out, work
 
@@ -74,6 +80,70 @@ def gathered_view(gathered: torch.Tensor, env_dim: int = -2) -> torch.Tensor:
     shape = list(g.shape)
     k = env_axis - 1
     return g.reshape(shape[:k] + [world * shape[k + 1]] + shape[k + 2:])
+
+
+class DirectGather:
+    """All-gather of one rank-local tensor by COPY-ENGINE peer writes instead of an RCCL kernel (on the
+    fully connected xGMI mesh every rank can write its shard to all peers at once).
+
+    Why: the rollout workgroups occupy every CU for the whole launch (one 1024-thread workgroup per CU, all vector registers),
+    so a CU-resident collective kernel that is to overlap the compute has nowhere to run until the rollout's first workgroups
+    retire; a device-to-device ``hipMemcpyAsync`` into a peer's buffer is executed by the SDMA engines and overlaps by
+    construction.
+
+    How: every rank owns ``gathered`` = [world, *src.shape]; the buffers are exchanged once as hipIpc handles (PyTorch's own
+    CUDA-IPC tensor sharing: ``torch.multiprocessing.reductions.reduce_tensor`` through ``all_gather_object``; needs
+    HSA_ENABLE_IPC_MODE_LEGACY=0 on this driver, which the image exports) and ``issue(stream)`` enqueues world copies
+    ``peer_gathered[r][my_rank] <- src`` on ``stream``.  The event the caller records afterwards marks the end of this
+    rank's OUTGOING copies; a consumer of ``gathered`` needs all ranks to have passed theirs (a barrier / the next step's
+    rendezvous) -- bench.py's blocks end with exactly that.  RCCL stays the default path (north_star); this one is
+    ``bench.py --gather direct``."""
+
+    def __init__(self, src: torch.Tensor, gathered: torch.Tensor, group=None):
+        from torch.multiprocessing.reductions import reduce_tensor
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        assert src.is_contiguous() and gathered.is_contiguous()
+        assert tuple(gathered.shape) == (self.world,) + tuple(src.shape) and gathered.dtype == src.dtype
+        self.src, self.gathered = src, gathered
+        handles = [None] * self.world
+        dist.all_gather_object(handles, reduce_tensor(gathered), group=group)
+        self.peers = []
+        for r, (rebuild, rebuild_args) in enumerate(handles):
+            self.peers.append(gathered if r == self.rank else rebuild(*rebuild_args))   # rank r's `gathered`, mapped here
+        self._keep = handles
+        dist.barrier(group)              # every rank has mapped every buffer before anybody writes
+
+    def issue(self, stream=None) -> None:
+        """Enqueue the world copies on ``stream`` (default: the current stream).  The farthest peers first, own copy last."""
+        ctx = torch.cuda.stream(stream) if stream is not None else _null_context()
+        with ctx:
+            for k in range(1, self.world + 1):
+                r = (self.rank + k) % self.world
+                self.peers[r][self.rank].copy_(self.src, non_blocking=True)
+
+    def self_test(self) -> None:
+        """Every rank fills its source with a rank-coded pattern, gathers, and checks what the peers wrote."""
+        keep = self.src.clone()
+        self.src.fill_(float(self.rank + 1))
+        self.issue()
+        torch.cuda.synchronize(self.src.device)
+        dist.barrier(self.group)
+        got = self.gathered.reshape(self.world, -1)[:, 0].cpu()
+        want = torch.arange(1, self.world + 1, dtype=got.dtype)
+        ok = bool((got == want).all()) and bool((self.gathered.reshape(self.world, -1)[:, -1].cpu() == want).all())
+        self.src.copy_(keep)
+        dist.barrier(self.group)
+        if not ok:
+            raise RuntimeError(f"DirectGather self-test failed on rank {self.rank}: got {got.tolist()}, expected {want.tolist()}")
+
+
+class _null_context:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
 
 
 class ShardedEvacuationEnv:

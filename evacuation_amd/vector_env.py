@@ -165,15 +165,12 @@ class BatchedEvacuationEnv:
         # for A/B runs)
         self.workspace = None
         self.schedule = None
-        self.pack_stats = None
         if os.environ.get("EVAC_WORKSPACE", "1") != "0":
             nbytes = int(self.lib.evac_workspace_bytes(self._h))
             self.workspace = torch.zeros((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=dev)
             assert self.workspace.data_ptr() % 256 == 0
             _lib.check(self.lib.evac_bind_workspace(self._h, _ptr(self.workspace), C.c_int64(nbytes)), self._h)
             self.schedule = self.workspace[:8 * E].view(torch.int32).view(2, E)     # moving[E] | perm[E]
-            off = (8 * E + 255) // 256 * 256
-            self.pack_stats = self.workspace[off:off + 4].view(torch.int32)        # env-launches that ran packed (cumulative)
         # step outputs (reused every step; callers that keep them must clone, like the reference's
         # live-reference observations, env.py:98-104)
         self.obs = torch.zeros((E, self.obs_dim), dtype=torch.float32, device=dev)
@@ -208,11 +205,24 @@ class BatchedEvacuationEnv:
         x = x.to(device=self.device, dtype=dtype).contiguous()
         return self._check_tensor(x, shape, dtype, name)
 
+    def rebind_workspace(self) -> None:
+        """Bind the workspace again: the handle forgets the age of its load schedule and re-sorts the envs (from the loads
+        the workspace holds) at the next rollout launch.  bench.py restores a snapshot of the workspace before its kernel-time
+        replays, so that they run under the same env-to-SIMD deal as the timed blocks."""
+        if self.workspace is not None:
+            nbytes = int(self.lib.evac_workspace_bytes(self._h))
+            _lib.check(self.lib.evac_bind_workspace(self._h, _ptr(self.workspace), C.c_int64(nbytes)), self._h)
+
     def team_error(self) -> int:
         """Non-zero if a barrier of a team rollout (N > 512, few envs) timed out; synchronises."""
         v = C.c_int32(0)
         _lib.check(self.lib.evac_team_error(self._h, C.byref(v)), self._h)
         return int(v.value)
+
+    def team_clear_error(self) -> None:
+        """Acknowledge a team error (``EvacError`` with code ERR_TEAM_ABORTED from any call): the handle then runs one
+        workgroup per env; reset or restore the batch afterwards (the aborted launch left some envs un-stepped)."""
+        _lib.check(self.lib.evac_team_clear_error(self._h), self._h)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

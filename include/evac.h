@@ -21,9 +21,7 @@
  * kernels on (for every N > 64) / off (default: N > 512; the all-pairs kernels give the same neighbour sets); EVAC_CU_WIDE=1 / 0
  * forces / forbids the CU-wide rollout workgroups of one-wave envs (default: batches of >= 16 envs per CU); EVAC_TEAM=0 / 2 / 4 / 8
  * forbids / forces the team rollout kernels of rooms of more than 512 pedestrians (default: as many CUs per env as the batch leaves
- * free; not under EVAC_CELLS); all of them give bit-identical results.  EVAC_PACK=1 lets rollouts of one-wave envs with a
- * gravity observation run two late-episode envs (<= 32 moving pedestrians each, no episode end possible inside the launch) in
- * one wave: trajectories, flags and rewards stay bit-identical, the summed observations agree to f32 rounding (default off).
+ * free; not under EVAC_CELLS); all of them give bit-identical results.
  * EVAC_SPECIALIZE=0 keeps handles of the reference's default configuration (enslaving_degree 1, |noise_coef| <= 0.4, alpha 3 gravity
  * observation or rel + ohe Box, no wall termination) on the generic kernels instead of the k_*_default_config instantiations in
  * which those uniform parameters are compile-time constants (bit-identical, tests/test_gpu_schedule.py).
@@ -55,7 +53,7 @@
 extern "C" {
 #endif
 
-#define EVAC_VERSION 120          /* 0.1.2 */
+#define EVAC_VERSION 130          /* 0.1.3 */
 #define EVAC_MAX_PEDESTRIANS 1024 /* one workgroup (<=16 waves) per env */
 
 typedef enum evac_status {
@@ -64,7 +62,8 @@ typedef enum evac_status {
     EVAC_ERR_NOT_BOUND = -2,
     EVAC_ERR_UNSUPPORTED = -3, /* e.g. positions=grav with type=Box: wrappers/config.py:79-80 raises NotImplementedError */
     EVAC_ERR_HIP = -4,
-    EVAC_ERR_NO_DEVICE = -5
+    EVAC_ERR_NO_DEVICE = -5,
+    EVAC_ERR_TEAM_ABORTED = -6 /* an earlier team rollout lost a member: see evac_team_error / evac_team_clear_error */
 } evac_status_t;
 
 enum { EVAC_POS_ABS = 0, EVAC_POS_REL = 1, EVAC_POS_GRAV = 2 };   /* wrappers/config.py:19-24 */
@@ -192,10 +191,19 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions_or_null,
  *     SIMDs by that load;
  *   - the exchange areas of the team kernels (513..1024 pedestrians, few envs: 2 / 4 / 8 workgroups per env).
  * Performance devices only: results are bit-identical with and without the workspace.  NULL unbinds.
- * evac_team_error: non-zero if a team barrier of an earlier launch timed out (its results are void); synchronises. */
+ *
+ * Team rollouts need every workgroup of their grid resident at once (the members of a team wait for each other).  evac_rollout
+ * checks that with hipOccupancyMaxActiveBlocksPerMultiprocessor (a grid that does not fit runs one workgroup per env instead) and
+ * launches cooperatively where the device supports it (EVAC_TEAM_COOP=0: plain launches).  Should a team lose a member all the
+ * same, its waits are bounded: the launch ends, that env's state is NOT written back, and the handle's error word -- 64 bytes of
+ * host-mapped memory, the one thing besides the config the library allocates -- is raised.  Every later call on the handle
+ * (evac_reset / evac_step* / evac_rollout / evac_observe / evac_get_state / evac_set_state) then returns EVAC_ERR_TEAM_ABORTED
+ * without touching the device, until evac_team_clear_error(); the handle uses one workgroup per env from then on.
+ * evac_team_error: synchronises the device, then reports the error word (non-zero: the outputs of an earlier launch are void). */
 int64_t evac_workspace_bytes(evac_handle_t h);
 int evac_bind_workspace(evac_handle_t h, void* workspace_or_null, int64_t bytes);
 int evac_team_error(evac_handle_t h, int32_t* out);
+int evac_team_clear_error(evac_handle_t h);
 
 /* State exchange in the reference's own shapes (needed for parity tests, checkpoints):
  * pos/dir float [E][N][2], status uint8 [E][N], agent_pos/agent_dir float [E][2], now int32 [E]. */

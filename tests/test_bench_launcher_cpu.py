@@ -33,6 +33,94 @@ def test_plain_invocation_spawns_its_own_ranks():
     assert d["gather_in_global_env_order"] is True
 
 
+def _blocks_of(trace):
+    """Split a dry-run trace into the event lists of its timed blocks (between t0 and t1) and what lies outside."""
+    blocks, outside, cur = [], [], None
+    for ev in trace:
+        if ev[0] == "t0":
+            cur = []
+        elif ev[0] == "t1":
+            blocks.append(cur)
+            cur = None
+        elif cur is not None:
+            cur.append(tuple(ev))
+        else:
+            outside.append(tuple(ev))
+    return blocks, outside
+
+
+def test_timed_block_has_no_barrier_and_carries_the_previous_blocks_gather():
+    """per rank, opening barrier -> t0 -> launches -> drain compute and gather -> local t1; the closing
+    barrier is outside the timed region; with one launch per block (the driver's --steps 20) the gather of block b-1 is issued
+    after the launch of block b, inside block b (double-buffered), and drained before t1."""
+    r = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json_lines(r.stdout)[0]
+    assert d["gather_schedule"] == "pipelined" and d["chunk_sizes"] == [20] and d["launches_per_block"] == 1
+    blocks, outside = _blocks_of(d["trace"])
+    assert len(blocks) == d["blocks"] == 4
+    assert ("barrier",) in outside                           # the brackets exist ...
+    launched = []
+    for evs in blocks:
+        kinds = [e[0] for e in evs]
+        assert "barrier" not in kinds                        # ... but never inside a timed region
+        assert kinds[-1] == "drain"                          # the block ends with the rank draining compute + gather
+        (j,) = [e[1] for e in evs if e[0] == "launch"]
+        (g,) = [e[1] for e in evs if e[0] == "gather"]
+        assert g == j - 1                                    # the previous block's outputs ...
+        assert evs.index(("gather", g)) > evs.index(("launch", j))   # ... gathered under this block's compute
+        launched.append(j)
+    assert launched == list(range(launched[0], launched[0] + 4))
+    assert launched[0] >= 1                                  # the warm-up primed the pipeline: block 0 has a gather to carry
+    # every chunk is gathered exactly once, the last one by the untimed flush
+    gathered = [e[1] for e in d["trace"] if e[0] == "gather"]
+    assert gathered == list(range(launched[-1] + 1)) and d["gathers"] == len(gathered)
+    assert d["gather_in_global_env_order"] is True
+
+
+def test_split_schedule_gathers_each_half_inside_its_block():
+    r = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "10", "--dry-run", "--gather-schedule", "split"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json_lines(r.stdout)[0]
+    assert d["chunk_sizes"] == [10, 10] and d["launches_per_block"] == 2
+    blocks, _ = _blocks_of(d["trace"])
+    for evs in blocks:
+        kinds = [e[0] for e in evs]
+        assert "barrier" not in kinds and kinds[-1] == "drain"
+        ls = [e[1] for e in evs if e[0] == "launch"]
+        gs = [e[1] for e in evs if e[0] == "gather"]
+        assert len(ls) == 2 and gs == ls                     # both halves gathered inside the block that computed them
+        assert evs.index(("gather", ls[0])) < evs.index(("launch", ls[1]))   # the first half's gather runs under the second half
+
+
+def test_a_failing_collective_is_a_hard_error():
+    r = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run"], {"EVAC_BENCH_FAIL_GATHER": "1"})
+    assert r.returncode != 0
+    assert not json_lines(r.stdout)                    # never an N-GPU value without the gather traffic
+    assert "all-gather failed" in r.stderr
+    # ... unless the run asked for independent shards
+    r = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run", "--no-gather"], {"EVAC_BENCH_FAIL_GATHER": "1"})
+    assert r.returncode == 0 and json_lines(r.stdout)[0]["gathers"] == 0
+
+
+def test_chunk_pipeline_orders_buffer_reuse_after_the_gather_that_read_it():
+    sys.path.insert(0, ROOT)
+    import bench
+    log = []
+    pipe = bench.ChunkPipeline(launch=lambda j, t: log.append(("L", j, t)), gather=lambda j, t: log.append(("G", j, t)) or ("tok", j),
+                               wait_gather=lambda tok: log.append(("W",) + tok), drain_compute=lambda: log.append(("DC",)),
+                               drain_gather=lambda: log.append(("DG",)), lag=1)
+    pipe.run_block([5, 5, 3])
+    pipe.drain()
+    pipe.flush()
+    # chunk 2 reuses buffer 0, which gather 0 read: the compute stream waits for it first
+    assert log == [("L", 0, 5), ("L", 1, 5), ("G", 0, 5), ("W", "tok", 0), ("L", 2, 3), ("G", 1, 5), ("DC",), ("DG",),
+                   ("G", 2, 3), ("DC",), ("DG",)]
+    assert bench.chunk_sizes(20, 100, "pipelined", True) == [20] and bench.chunk_sizes(2000, 100, "pipelined", True) == [100] * 20
+    assert bench.chunk_sizes(20, 100, "split", True) == [10, 10] and bench.chunk_sizes(20, 100, "split", False) == [20]
+    assert bench.chunk_sizes(250, 100, "split", True) == [100, 100, 50]
+
+
 def test_a_missing_rank_is_a_hard_error():
     r = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run"], {"EVAC_BENCH_FAIL_RANK": "1"})
     assert r.returncode != 0
@@ -75,3 +163,7 @@ def test_block_plan_tiles_the_episode():
     assert per * sw == 7
     avg, info = bench.summarize_blocks([1.0, 3.0, 1.2, 2.8], [5, 1005, 5, 1005], 2, 10)
     assert abs(avg - (1.1 + 2.9) / 2) < 1e-12 and info["dense"]["episode_phase"] == 5 and info["mid_episode"]["episode_phase"] == 1005
+    # K does not divide the episode: blocks are grouped by their ACTUAL phase, never by block index
+    ph = [(5 + b * 300) % 2000 for b in range(14)]
+    avg, info = bench.summarize_blocks([1.0] * 14, ph, 7, 300)
+    assert info["distinct_phases"] == len(set(ph)) == 14 and abs(avg - 1.0) < 1e-12

@@ -1,0 +1,39 @@
+"""bench.py's multi-rank timed loop on real HIP streams: two ranks sharing the ONE GPU of the test box (gloo rendezvous --
+RCCL refuses two ranks on one device), rollout kernels on the compute stream, the gather of the previous chunk on the comm
+stream.  Checks the control flow end to end (launcher, pipeline, gather buffers, per-block max over ranks, one JSON line);
+the copy-engine gather (--gather direct: hipIpc-mapped peer buffers) is exercised the same way, both "peers" living on this
+GPU.  RCCL itself first runs on the driver's multi-GPU node."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, timeout=600):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(EVAC_BENCH_FORCE_DEVICE="0", EVAC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--blocks", "6",
+                        "--envs", "512", "--no-step-api"] + extra, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return lines[0]
+
+
+@pytest.mark.parametrize("extra", [[], ["--gather-schedule", "split"], ["--gather", "slab"], ["--gather", "direct"]])
+def test_two_ranks_on_one_gpu(extra):
+    d = _run(extra)
+    assert d["n_gpus"] == 2 and d["config"]["ranks_joined"] == 2 and d["config"]["total_envs"] == 1024
+    assert d["value"] > 0 and d["blocks"]["timed_blocks"] == 6
+    assert d["config"]["launches_per_block"] == (2 if "split" in extra else 1)
+    assert "all-gather" in d["config"]["parallelism"]
+    assert d["roofline"]["frac"] > 0

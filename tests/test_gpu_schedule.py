@@ -100,9 +100,9 @@ def test_schedule_balances_simd_groups(ea):
     rand = load[rng.permutation(E)].reshape(-1, 4).sum(1)
     assert sums.max() < rand.max() and sums.max() - sums.min() < 0.5 * (rand.max() - rand.min())
     q = np.sort(load)
-    for k in range(4):                                                     # one env per quartile in every SIMD
+    for k in range(4):                                                     # one env per quartile in every SIMD ...
         lo, hi = q[k * E // 4], q[(k + 1) * E // 4 - 1]
-        assert ((slot_load[:, k, :] >= lo) & (slot_load[:, k, :] <= hi)).all()
+        assert ((slot_load[:, 3 - k, :] >= lo) & (slot_load[:, 3 - k, :] <= hi)).all()   # ... the heaviest in the SIMD's first (oldest) wave
     env.close()
 
 

@@ -148,3 +148,87 @@ def test_workspace_binding_errors_and_sizes(ea):
     torch.cuda.synchronize()
     assert env.team_error() == 0 and torch.equal(c2.view(torch.int32), d2.view(torch.int32))
     env.close(); ref.close()
+
+
+def _env_var(name, value):
+    class _Ctx:
+        def __enter__(self):
+            self.old = os.environ.get(name)
+            os.environ[name] = value
+        def __exit__(self, *a):
+            if self.old is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = self.old
+    return _Ctx()
+
+
+def test_team_that_loses_a_member_is_reported_and_keeps_its_state(ea):
+    """a team whose members are not all resident times out.  Fault injection (EVAC_TEAM_FAULT=1: the grid
+    is launched one workgroup short, so the last env's team never completes a barrier): the launch still ends, that env's state
+    is NOT written back, the error word is raised, every later call on the handle returns EVAC_ERR_TEAM_ABORTED without a
+    sync until it is cleared, and the handle then runs one workgroup per env."""
+    import torch
+    from evacuation_amd import _lib
+    n, E = 1024, 8
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=100)
+    wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
+    with _env_var("EVAC_TEAM_FAULT", "1"):
+        tm = _make(ea, cfg, wrap, E, 9, team=8)
+    ref = _make(ea, cfg, wrap, E, 9, team=0)
+    tm.reset(); ref.reset()
+    assert "CUs/env" in tm.kernel_variant("rollout")
+    before = {k: v.clone() for k, v in tm.get_state().items()}
+    tm.rollout(3)                                        # returns at once: the error shows up on the device later
+    a = ref.rollout(3)
+    torch.cuda.synchronize()
+    assert tm.team_error() == 1
+    with pytest.raises(_lib.EvacError) as ei:
+        tm.get_state()
+    assert ei.value.code == _lib.ERR_TEAM_ABORTED and "lost a member" in str(ei.value)
+    with pytest.raises(_lib.EvacError):
+        tm.rollout(3)
+    tm.team_clear_error()
+    assert tm.team_error() == 0 and "CUs/env" not in tm.kernel_variant("rollout")     # one workgroup per env from now on
+    after = tm.get_state()
+    for k in before:                                     # the env whose team broke (the last one) kept its pre-launch state ...
+        assert torch.equal(before[k][E - 1], after[k][E - 1]), k
+    sr = ref.get_state()
+    for k in sr:                                         # ... the complete teams stepped as the reference kernels do
+        assert torch.equal(sr[k][: E - 1], after[k][: E - 1]), k
+    tm.reset(); ref.reset()                              # restore the batch, then the handle works again (cell-list kernels)
+    b = tm.rollout(4); a = ref.rollout(4)
+    torch.cuda.synchronize()
+    # (the env that was not stepped is three steps behind in its Philox noise counter: compare the others)
+    assert torch.equal(a["obs"][:, : E - 1].view(torch.int32), b["obs"][:, : E - 1].view(torch.int32))
+    tm.close(); ref.close()
+
+
+@pytest.mark.parametrize("coop", ["1", "0"])
+def test_team_rollout_with_another_stream_busy(ea, coop):
+    """the sharded env overlaps the all-gather of one chunk with the next rollout, so the team kernels
+    must stay correct while a second stream keeps kernels resident on the device (cooperative launch, or a plain launch whose
+    bounded waits simply outlast the intruder): no team error, same bits as the one-workgroup kernels."""
+    import torch
+    n, E = 1024, 32
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=60, is_new_exiting_reward=True)
+    wrap = ea.EnvWrappersConfig(positions="rel", statuses="ohe", type="Box")
+    ref = _make(ea, cfg, wrap, E, 21, team=0)
+    with _env_var("EVAC_TEAM_COOP", coop):
+        tm = _make(ea, cfg, wrap, E, 21, team=8)
+    ref.reset(); tm.reset()
+    outs = [ref.rollout(25)["slab"].clone() for _ in range(4)]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    big = torch.zeros(64 * 1024 * 1024, device=tm.device)          # 256 MB: every pass keeps all CUs busy for ~0.1 ms
+    got = []
+    for k in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(40):
+                big.mul_(1.0001).add_(1.0)
+        got.append(tm.rollout(25)["slab"].clone())
+    torch.cuda.synchronize()
+    assert tm.team_error() == 0
+    for a, b in zip(outs, got):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    ref.close(); tm.close()

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import evacuation_amd as ea
 
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
-SW = ("EVAC_CU_WIDE", "EVAC_TEAM", "EVAC_PACK", "EVAC_WORKSPACE")
+SW = ("EVAC_CU_WIDE", "EVAC_TEAM", "EVAC_WORKSPACE")
 
 
 def make(cfg, wrap, E, **env):
@@ -30,7 +30,7 @@ for name, n, E, wrap_kw, T in (("C5 teams of 8 CUs", 1024, 32, dict(positions="r
                                ("C2 CU-wide, 20-step launches", 60, 4096, dict(positions="grav", alpha=3), 20)):
     cfg = ea.EnvConfig(number_of_pedestrians=n, is_new_exiting_reward=True, is_new_followers_reward=True, max_timesteps=700)
     wrap = ea.EnvWrappersConfig(**wrap_kw)
-    a = make(cfg, wrap, E, EVAC_CU_WIDE=0, EVAC_TEAM=0, EVAC_PACK=0, EVAC_WORKSPACE=0)
+    a = make(cfg, wrap, E, EVAC_CU_WIDE=0, EVAC_TEAM=0, EVAC_WORKSPACE=0)
     b = make(cfg, wrap, E)
     a.reset(); b.reset()
     t0 = time.time()
