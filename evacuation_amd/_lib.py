@@ -54,6 +54,7 @@ SIGNATURES = {
     "evac_bind_state": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "evac_workspace_bytes": (C.c_int64, [_P]),
     "evac_bind_workspace": (C.c_int, [_P, _P, C.c_int64]),
+    "evac_reschedule": (C.c_int, [_P, _P]),
     "evac_team_error": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "evac_team_clear_error": (C.c_int, [_P]),
     "evac_reset": (C.c_int, [_P, _P, _P, _P, _P]),

@@ -465,6 +465,16 @@ int evac_bind_workspace(evac_handle_t h, void* workspace, int64_t bytes) {
     return EVAC_OK;
 }
 
+int evac_reschedule(evac_handle_t h, void* stream) {
+    if (!h) return EVAC_ERR_INVALID_ARGUMENT;
+    if (!h->sched || !(h->cu_wide || h->cu_wide4)) return EVAC_OK;       // nothing to deal
+    DeviceGuard g(h->device);
+    hipLaunchKernelGGL(evac::k_schedule, dim3(1), dim3(1024), 0, (hipStream_t)stream, h->p.n_envs, (const int*)h->sched, h->sched + h->p.n_envs,
+                       h->cu_wide4 ? 4 : 16, h->cu_wide4 ? 4 : 1);
+    h->sched_age = 0;
+    return check_launch(h, "evac_reschedule");
+}
+
 int evac_team_error(evac_handle_t h, int32_t* out) {
     if (!h || !out) return EVAC_ERR_INVALID_ARGUMENT;
     *out = 0;

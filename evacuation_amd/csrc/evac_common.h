@@ -293,6 +293,20 @@ __device__ __forceinline__ void pair_accumulate(float XI, float YI, f4 t, float 
     sx = fmaf(w, t.z, sx);
     sy = fmaf(w, t.w, sy);
 }
+// TWO columns of the neighbour sum at once in packed f32 arithmetic (the one-wave-per-env loops): the tile holds the columns
+// in pairs, xy = (X_j, X_j+1, Y_j, Y_j+1) and uv = (ux_j, ux_j+1, uy_j, uy_j+1); six v_pk_* instructions do what ten plain ones
+// do for two columns -- the same operations per column (subtract, two FMAs for the 0/1 weight, one FMA per heading component),
+// with the heading sums kept as (even columns, odd columns) halves that the caller adds at the end.
+using f2 = float __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pair2_accumulate(f2 XI2, f2 YI2, f4 xy, f4 uv, f2 r2b2, f2& sx2, f2& sy2) {
+    const f2 dx = XI2 - __builtin_shufflevector(xy, xy, 0, 1), dy = YI2 - __builtin_shufflevector(xy, xy, 2, 3);
+    const f2 a = __builtin_elementwise_fma(-dy, dy, r2b2);
+    f2 w;
+    asm("v_pk_fma_f32 %0, %1, %1, %2 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(w) : "v"(dx), "v"(a));
+    sx2 = __builtin_elementwise_fma(w, __builtin_shufflevector(uv, uv, 0, 1), sx2);
+    sy2 = __builtin_elementwise_fma(w, __builtin_shufflevector(uv, uv, 2, 3), sy2);
+}
+
 // The same pair with the unit heading stored as integers (heading * Params::head_scale, rounded): the weight's
 // bit pattern (0x3f800000 or 0) shifted down is the integer 1 or 0, and the sums are integer multiply-adds
 // (v_mad_i32_i24: |heading| < 2^23; N of them fit an int32).  Integer addition is exact, so the sum does not depend on the order in

@@ -27,6 +27,9 @@ namespace evac {
 #ifndef EVAC_BLOCK1
 #define EVAC_BLOCK1 256
 #endif
+#ifndef EVAC_PK2
+#define EVAC_PK2 1            // 0: the one-wave loops take one column per five plain instructions (the round-2 form; A/B builds)
+#endif
 
 // BLOCK1 (WPE == 1 only): threads per workgroup.  256 = four one-wave envs per workgroup (the default); 1024 = the
 // CU-WIDE workgroup of the rollout kernel for batches that fill the chip (16 envs, one workgroup per CU, four waves per
@@ -283,7 +286,16 @@ struct Wave {
             }
             const int tid = c.wave_in_env * kWave + c.lane;
             const int idx = efv ? before : n_cols + (tid - before);             // a bijection onto [0, WPE*64)
-            sm.tile[par][c.slot][idx] = f4{efv ? q.x * kTileScale : __builtin_inff(), q.y * kTileScale, efv ? ux : 0.0f, efv ? uy : 0.0f};
+            if constexpr (WPE == 1 && EVAC_PK2) {
+                // columns in PAIRS for the packed loop: pair p = idx / 2 holds (X, X', Y, Y') in tile[2p] and (ux, ux', uy, uy') in tile[2p + 1]
+                float* tf = (float*)sm.tile[par][c.slot] + (idx >> 1) * 8 + (idx & 1);
+                tf[0] = efv ? q.x * kTileScale : __builtin_inff();
+                tf[2] = q.y * kTileScale;
+                tf[4] = efv ? ux : 0.0f;
+                tf[6] = efv ? uy : 0.0f;
+            } else {
+                sm.tile[par][c.slot][idx] = f4{efv ? q.x * kTileScale : __builtin_inff(), q.y * kTileScale, efv ? ux : 0.0f, efv ? uy : 0.0f};
+            }
         }
         if constexpr (WPE > 1) {
             if (fv) sm.rowpos[par][c.slot][row_rank] = make_float2(q.x * kTileScale, q.y * kTileScale);
@@ -312,6 +324,27 @@ struct Wave {
             constexpr int B = 16;
             int j = 0;
             if constexpr (!(EVAC_ABLATE & 1)) {
+#if EVAC_PK2
+                // two columns per packed instruction (pair2_accumulate): 3 vector instructions per column instead of 5
+                const f2 XI2 = f2{XI, XI}, YI2 = f2{YI, YI}, r2b2 = f2{r2b, r2b};
+                f2 sx2 = f2{0.0f, 0.0f}, sy2 = f2{0.0f, 0.0f};
+                for (; j + B <= n8; j += B) {      // full batches: 16 columns = 8 pairs = 16 tile reads
+                    f4 t[B];
+#pragma unroll
+                    for (int k = 0; k < B; ++k) t[k] = tile[j + k];
+#pragma unroll
+                    for (int k = 0; k < B; k += 2) pair2_accumulate(XI2, YI2, t[k], t[k + 1], r2b2, sx2, sy2);
+                }
+                for (; j < n8; j += 4) {           // remainder in groups of 4 columns (n8 is a multiple of 4)
+                    f4 t[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+#pragma unroll
+                    for (int k = 0; k < 4; k += 2) pair2_accumulate(XI2, YI2, t[k], t[k + 1], r2b2, sx2, sy2);
+                }
+                sx = sx2.x + sx2.y;                // even columns + odd columns
+                sy = sy2.x + sy2.y;
+#else
                 for (; j + B <= n8; j += B) {      // full batches
                     f4 t[B];
 #pragma unroll
@@ -326,6 +359,7 @@ struct Wave {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) pair_accumulate(XI, YI, t[k], r2b, sx, sy);
                 }
+#endif
             }
         } else {
             // this wave: up to kRows row slices (64 compacted rows each) of its group of kRows waves, column share `share`
@@ -709,7 +743,15 @@ struct Sub {
         {
             const int before = rank(m_efv, c.gmask);
             const int idx = efv ? before : n_cols + (c.li - before);    // a bijection onto the group's G slots
+#if EVAC_PK2
+            float* tf = (float*)sm.tile[c.slot] + (idx >> 1) * 8 + (idx & 1);     // columns in pairs, as in Wave<1>::neighbour_sum
+            tf[0] = efv ? q.x * kTileScale : __builtin_inff();
+            tf[2] = q.y * kTileScale;
+            tf[4] = efv ? ux : 0.0f;
+            tf[6] = efv ? uy : 0.0f;
+#else
             sm.tile[c.slot][idx] = f4{efv ? q.x * kTileScale : __builtin_inff(), q.y * kTileScale, efv ? ux : 0.0f, efv ? uy : 0.0f};
+#endif
         }
         sync();
         sx = 0.0f;
@@ -731,6 +773,29 @@ struct Sub {
         const f4* __restrict__ tile = sm.tile[c.slot];           // per lane: its group's tile
         const float XI = q.x * kTileScale, YI = q.y * kTileScale;
         int j = 0;
+#if EVAC_PK2
+        // (the same packed two-column form and the same even / odd partial sums as the one-wave-per-env loop: bit-identical dynamics)
+        const f2 XI2 = f2{XI, XI}, YI2 = f2{YI, YI}, r2b2 = f2{kRPed2Big, kRPed2Big};
+        f2 sx2 = f2{0.0f, 0.0f}, sy2 = f2{0.0f, 0.0f};
+        for (; j + 8 <= n4; j += 8) {
+            f4 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = tile[j + k];
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) pair2_accumulate(XI2, YI2, t[k], t[k + 1], r2b2, sx2, sy2);
+        }
+        for (; j < n4; j += 4) {
+            f4 t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+#pragma unroll
+            for (int k = 0; k < 4; k += 2) pair2_accumulate(XI2, YI2, t[k], t[k + 1], r2b2, sx2, sy2);
+        }
+        if (any_row) {
+            sx = sx2.x + sx2.y;
+            sy = sy2.x + sy2.y;
+        }
+#else
         for (; j + 8 <= n4; j += 8) {
             f4 t[8];
 #pragma unroll
@@ -745,6 +810,7 @@ struct Sub {
 #pragma unroll
             for (int k = 0; k < 4; ++k) pair_accumulate(XI, YI, t[k], kRPed2Big, sx, sy);
         }
+#endif
     }
 };
 

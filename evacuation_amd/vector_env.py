@@ -206,12 +206,10 @@ class BatchedEvacuationEnv:
         return self._check_tensor(x, shape, dtype, name)
 
     def rebind_workspace(self) -> None:
-        """Bind the workspace again: the handle forgets the age of its load schedule and re-sorts the envs (from the loads
-        the workspace holds) at the next rollout launch.  bench.py restores a snapshot of the workspace before its kernel-time
-        replays, so that they run under the same env-to-SIMD deal as the timed blocks."""
+        """Re-deal the envs to the SIMDs now, from the loads the workspace holds (``evac_reschedule``).  bench.py restores a
+        snapshot of state + workspace before its kernel-time replays, so that they run under the deal the timed blocks had."""
         if self.workspace is not None:
-            nbytes = int(self.lib.evac_workspace_bytes(self._h))
-            _lib.check(self.lib.evac_bind_workspace(self._h, _ptr(self.workspace), C.c_int64(nbytes)), self._h)
+            _lib.check(self.lib.evac_reschedule(self._h, self._stream()), self._h)
 
     def team_error(self) -> int:
         """Non-zero if a barrier of a team rollout (N > 512, few envs) timed out; synchronises."""

@@ -202,6 +202,10 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions_or_null,
  * evac_team_error: synchronises the device, then reports the error word (non-zero: the outputs of an earlier launch are void). */
 int64_t evac_workspace_bytes(evac_handle_t h);
 int evac_bind_workspace(evac_handle_t h, void* workspace_or_null, int64_t bytes);
+/* Deal the envs to the SIMDs NOW by the loads the workspace holds (what evac_rollout does by itself every 50 to 200 env steps):
+ * for callers that restored a state + workspace snapshot and want the next launch to run under that deal.  No-op without a
+ * schedule. */
+int evac_reschedule(evac_handle_t h, void* stream);
 int evac_team_error(evac_handle_t h, int32_t* out);
 int evac_team_clear_error(evac_handle_t h);
 

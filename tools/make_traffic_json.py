@@ -11,10 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_path = os.path.join(ROOT, "profiles", "traffic.json")
 data = json.load(open(out_path)) if os.path.exists(out_path) else {}
 data = {k: v for k, v in data.items() if "hbm_bytes_per_env_step" in v}     # drop entries of the round-1 format
+# (SQ_INSTS_*: wave-instructions per dispatch, divided by the env-steps of a launch -- bench.py's valu_issue_frac)
 args = sys.argv[1:]
 for d, key, envs, inner in zip(args[0::4], args[1::4], args[2::4], args[3::4]):
     kern = "k_rollout" if key.endswith(":rollout") else "k_step"
-    vals = {"FETCH_SIZE": [], "WRITE_SIZE": []}
+    vals = {"FETCH_SIZE": [], "WRITE_SIZE": [], "SQ_INSTS_VALU": [], "SQ_INSTS_SALU": [], "SQ_INSTS_LDS": []}
     for f in glob.glob(os.path.join(d, "pmc*", "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             if kern in row.get("Kernel_Name", "") and row["Counter_Name"] in vals:
@@ -26,6 +27,9 @@ for d, key, envs, inner in zip(args[0::4], args[1::4], args[2::4], args[3::4]):
                  "envs": int(envs), "steps_per_launch": int(inner),
                  "hbm_bytes_per_launch": per_launch, "hbm_bytes_per_env_step": per_launch / (int(envs) * int(inner)),
                  "note": "FETCH_SIZE doubled per the gfx950 correction; dispatches averaged: %d" % len(vals["FETCH_SIZE"]),
+                 "valu_wave_insts_per_env_step": (sum(vals["SQ_INSTS_VALU"]) / len(vals["SQ_INSTS_VALU"]) / (int(envs) * int(inner))) if vals["SQ_INSTS_VALU"] else None,
+                 "salu_wave_insts_per_env_step": (sum(vals["SQ_INSTS_SALU"]) / len(vals["SQ_INSTS_SALU"]) / (int(envs) * int(inner))) if vals["SQ_INSTS_SALU"] else None,
+                 "lds_wave_insts_per_env_step": (sum(vals["SQ_INSTS_LDS"]) / len(vals["SQ_INSTS_LDS"]) / (int(envs) * int(inner))) if vals["SQ_INSTS_LDS"] else None,
                  "source": os.path.relpath(d, ROOT)}
     print(key, data[key])
 json.dump(data, open(out_path, "w"), indent=1, sort_keys=True)
