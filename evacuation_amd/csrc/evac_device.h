@@ -762,10 +762,10 @@ __global__ __launch_bounds__(1024) void k_schedule(int n_envs, const int* __rest
         if (r < e16) {
             const int k = r / G, j = r - k * G;
             const int g = (k & 1) ? G - 1 - j : j;   // snake: quarters 0 and 2 ascending, 1 and 3 descending
-            // (one-wave envs: the heaviest quartile goes to the SIMD's first -- oldest -- wave, see rollout_body)
-            const int kk = (per_wg == 16 && EVAC_HEAVY_FIRST) ? 3 - k : k;
+            // (the heaviest quartile goes to the SIMDs' first -- oldest -- waves, see rollout_body)
+            const int kk = EVAC_HEAVY_FIRST ? 3 - k : k;
             slot = per_wg == 16 ? (g >> 2) * 16 + kk * 4 + (g & 3)  // workgroup g / 4, SIMD g % 4, the SIMD's kk-th wave
-                                : g * 4 + k;                        // workgroup g, its k-th env
+                                : g * 4 + kk;                       // workgroup g, its kk-th env (its waves 4 kk .. 4 kk + 3: one per SIMD)
         }
         perm[slot] = e;
     }

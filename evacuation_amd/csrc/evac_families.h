@@ -27,6 +27,9 @@ namespace evac {
 #ifndef EVAC_BLOCK1
 #define EVAC_BLOCK1 256
 #endif
+#ifndef EVAC_PK_ROWS
+#define EVAC_PK_ROWS 1        // 0: the multi-wave all-pairs sweeps take every row in plain arithmetic (A/B builds; same bits)
+#endif
 #ifndef EVAC_PK2
 #define EVAC_PK2 1            // 0: the one-wave loops take one column per five plain instructions (the round-2 form; A/B builds)
 #endif
@@ -377,13 +380,27 @@ struct Wave {
                 // R row slices per lane (slots beyond n_rows hold stale positions: computed, never read)
                 auto sweep = [&](auto r_tag) {
                     constexpr int R = decltype(r_tag)::value;
+                    constexpr int R2 = EVAC_PK_ROWS ? R / 2 : 0;          // pairs of rows taken in packed arithmetic (pair_accumulate_rows2)
                     float X[R], Y[R], ax[R], ay[R];
+                    f2 X2[R2 ? R2 : 1], Y2[R2 ? R2 : 1], ax2[R2 ? R2 : 1], ay2[R2 ? R2 : 1];
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const float2 rp = sm.rowpos[par][c.slot][gbase + r * kWave];
                         X[r] = rp.x; Y[r] = rp.y;
                         ax[r] = 0.0f; ay[r] = 0.0f;
                     }
+#pragma unroll
+                    for (int r = 0; r < R2; ++r) {
+                        X2[r] = f2{X[2 * r], X[2 * r + 1]}; Y2[r] = f2{Y[2 * r], Y[2 * r + 1]};
+                        ax2[r] = f2{0.0f, 0.0f}; ay2[r] = f2{0.0f, 0.0f};
+                    }
+                    const f2 r2b2 = f2{r2b, r2b};
+                    auto column = [&](f4 t) {
+#pragma unroll
+                        for (int r = 0; r < R2; ++r) pair_accumulate_rows2(X2[r], Y2[r], t, r2b2, ax2[r], ay2[r]);
+#pragma unroll
+                        for (int r = 2 * R2; r < R; ++r) pair_accumulate(X[r], Y[r], t, r2b, ax[r], ay[r]);
+                    };
                     constexpr int B = (R <= 2 && !(kEnvBarrier && R == 2)) ? 8 : 4;   // peers per LDS round trip (register budget)
                     int j = jbeg;
                     for (; j + B <= jend; j += B) {
@@ -391,10 +408,7 @@ struct Wave {
 #pragma unroll
                         for (int k = 0; k < B; ++k) t[k] = tile[j + k];
 #pragma unroll
-                        for (int k = 0; k < B; ++k) {
-#pragma unroll
-                            for (int r = 0; r < R; ++r) pair_accumulate(X[r], Y[r], t[k], r2b, ax[r], ay[r]);
-                        }
+                        for (int k = 0; k < B; ++k) column(t[k]);
                     }
                     if constexpr (B == 8) {
                         if (j < jend) {
@@ -402,12 +416,11 @@ struct Wave {
 #pragma unroll
                             for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                                for (int r = 0; r < R; ++r) pair_accumulate(X[r], Y[r], t[k], r2b, ax[r], ay[r]);
-                            }
+                            for (int k = 0; k < 4; ++k) column(t[k]);
                         }
                     }
+#pragma unroll
+                    for (int r = 0; r < R2; ++r) { ax[2 * r] = ax2[r].x; ax[2 * r + 1] = ax2[r].y; ay[2 * r] = ay2[r].x; ay[2 * r + 1] = ay2[r].y; }
 #pragma unroll
                     for (int r = 0; r < R; ++r) sm.part[share][c.slot][gbase + r * kWave] = make_float2(ax[r], ay[r]);
                 };

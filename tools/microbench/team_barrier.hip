@@ -3,6 +3,8 @@
 // agent scope), spins until all K have arrived (acquire), then loads all K segments.  Teams are laid out either on ONE XCD
 // (workgroup ids congruent mod 8: the dispatcher deals workgroups to the 8 XCDs round-robin) or spread over all XCDs.
 // Every round is checked: a segment must carry the round's stamp.
+// Modes: 0 acquire/release fences + non-temporal loads, 1 acquire/release fences, 2 device-scope (sc1) stores / loads, relaxed
+// counter, 3 the same through the XCD's own L2 (plain stores, sc0 loads).
 // hipcc -O3 --offload-arch=gfx950 team_barrier.hip -o team_barrier && ./team_barrier
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -38,6 +40,8 @@ __global__ __launch_bounds__(BLOCK) void k_team(f4* buf /*[2][teams][K*SEG]*/, u
             f4* dst = &seg[k * SEG + threadIdx.x];
             if constexpr (MODE == 2) {   // device-scope write-through store, then wait for its acknowledgement
                 asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(dst), "v"(val) : "memory");
+            } else if constexpr (MODE == 3) {   // XCD-local: a plain store lands in the XCD's L2 (the L1 is write-through); wait for its acknowledgement
+                asm volatile("global_store_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" ::"v"(dst), "v"(val) : "memory");
             } else {
                 *dst = val;
             }
@@ -46,6 +50,7 @@ __global__ __launch_bounds__(BLOCK) void k_team(f4* buf /*[2][teams][K*SEG]*/, u
         unsigned long long t1;
         if (threadIdx.x == 0) {
             if constexpr (MODE == 2) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if constexpr (MODE == 3) asm volatile("global_atomic_add %0, %1, off\n\ts_waitcnt vmcnt(0)" ::"v"(ctr), "v"(1u) : "memory");   // in the XCD's L2
             else __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
             t_pub += t1 - t0;
@@ -53,10 +58,16 @@ __global__ __launch_bounds__(BLOCK) void k_team(f4* buf /*[2][teams][K*SEG]*/, u
             int spins = 0;     // bounded: a team that is not co-resident must not hang the GPU
             if constexpr (MODE == 2) {
                 while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
+            } else if constexpr (MODE == 3) {          // sc0: past this CU's L1, served by the XCD's L2
+                unsigned v = 0;
+                do {
+                    asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(ctr) : "memory");
+                } while (v < target && ++spins < (1 << 14));
+                if (spins >= (1 << 14)) spins = 1 << 20;
             } else {
                 while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
             }
-            if (spins >= (1 << 20)) atomicAdd(errors, 1000000u);
+            if (spins >= (1 << 20)) { atomicAdd(errors, 1000000u); rounds = r; }   // (give up: the other members will time out too)
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
             t_wait += t0 - t1;
         }
@@ -66,6 +77,12 @@ __global__ __launch_bounds__(BLOCK) void k_team(f4* buf /*[2][teams][K*SEG]*/, u
             for (int e = threadIdx.x; e < K * SEG; e += BLOCK) tile[e] = __builtin_nontemporal_load(&seg[e]);
         } else if constexpr (MODE == 1) {              // thread 0's acquire invalidated this CU's L1 (and the L2's non-coherent lines)
             for (int e = threadIdx.x; e < K * SEG; e += BLOCK) tile[e] = seg[e];
+        } else if constexpr (MODE == 3) {              // XCD-scope loads
+            for (int e = threadIdx.x; e < K * SEG; e += BLOCK) {
+                f4 v;
+                asm volatile("global_load_dwordx4 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(&seg[e]) : "memory");
+                tile[e] = v;
+            }
         } else {                                       // device-scope loads: no cache invalidation at all
             for (int e = threadIdx.x; e < K * SEG; e += BLOCK) {
                 f4 v;
@@ -93,8 +110,7 @@ __global__ __launch_bounds__(BLOCK) void k_team(f4* buf /*[2][teams][K*SEG]*/, u
 }
 
 template <int K, int BLOCK, int MODE>
-int run(int teams, int same_xcd) {
-    const int rounds = 2000;
+int run(int teams, int same_xcd, int rounds = 2000) {
     f4* buf; unsigned* ctr; unsigned* err; unsigned long long* cyc;
     CHECK(hipMalloc(&buf, sizeof(f4) * 2 * teams * K * SEG));
     CHECK(hipMalloc(&ctr, sizeof(unsigned) * teams * 32));
@@ -118,11 +134,15 @@ int run(int teams, int same_xcd) {
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     run<8, 256, 0>(32, 1);
     run<8, 256, 1>(32, 1); run<8, 256, 1>(32, 0);
     run<8, 256, 2>(32, 1); run<8, 256, 2>(32, 0);
     run<8, 1024, 1>(32, 1); run<8, 1024, 1>(32, 0);
     run<8, 1024, 2>(32, 1); run<8, 1024, 2>(32, 0);
     run<4, 1024, 2>(32, 1); run<2, 1024, 2>(32, 1);
+    // mode 3: everything through the XCD's own L2 (valid only for teams on ONE XCD: the "spread" line must show errors)
+    run<8, 1024, 3>(32, 1); run<8, 1024, 3>(32, 0, 20);
+    run<4, 1024, 3>(32, 1); run<2, 1024, 3>(32, 1);
     return 0;
 }
