@@ -2,7 +2,8 @@
 
 Mirrors /root/reference/src/env/env/config.py:3-100 and src/env/wrappers/config.py:8-93 (same names,
 defaults, meaning and error behaviour) so a user of the reference can pass the same settings.
-Logging / drawing fields are accepted for compatibility and ignored (rendering is out of scope)."""
+Logging fields are accepted for compatibility and ignored; ``draw`` / ``giff_freq`` steer the recording of frames by the
+single-env facade (evacuation_amd/env.py), whose drawing stays out of scope."""
 from __future__ import annotations
 
 from dataclasses import dataclass

@@ -588,13 +588,19 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
         hipStream_t s_ = (hipStream_t)stream;
         const int E = h->p.n_envs;
         int32_t* moving = h->sched;
-        const int32_t* perm = h->sched ? h->sched + E : nullptr;
-        if (h->sched && (h->sched_age < 0 || h->sched_age >= kScheduleEvery)) {
+        // (while the stream is being captured into a hipGraph the host-side age must not decide what the graph contains: a
+        // captured launch never re-sorts and does not age the schedule -- any permutation gives the same results, call
+        // evac_reschedule outside the graph to refresh the deal)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s_, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        const bool capturing = cap != hipStreamCaptureStatusNone;
+        if (h->sched && !capturing && (h->sched_age < 0 || h->sched_age >= kScheduleEvery)) {
             hipLaunchKernelGGL(evac::k_schedule, dim3(1), dim3(1024), 0, s_, E, (const int*)moving, h->sched + E,
                                h->cu_wide4 ? 4 : 16, h->cu_wide4 ? 4 : 1);
             h->sched_age = 0;
         }
-        if (h->sched) h->sched_age += n_steps;
+        if (h->sched && !capturing) h->sched_age += n_steps;
+        const int32_t* perm = (h->sched && h->sched_age >= 0) ? h->sched + E : nullptr;     // (never dealt yet, e.g. a first launch under capture: identity)
         if (h->cu_wide4) {
             const dim3 grid4((unsigned)((E + FW4::kEnvsPerBlock - 1) / FW4::kEnvsPerBlock));
             if (h->default_cfg && h->p.obs_pos == EVAC_POS_GRAV)

@@ -27,6 +27,12 @@ class _PedestriansView:
     def __init__(self, env: "EvacuationEnv"):
         self._env = env
         self.num = env._batched.n_ped
+        self.memory = {"positions": [], "statuses": []}       # pedestrians.py:10,27
+
+    def save(self) -> None:
+        """Pedestrians.save (pedestrians.py:33-35): one frame of (N, 2) float64 positions and (N,) Status members."""
+        self.memory["positions"].append(self.positions.astype(np.float64))
+        self.memory["statuses"].append(self.statuses.copy())
 
     @property
     def positions(self) -> np.ndarray:
@@ -59,6 +65,11 @@ class _AgentView:
         self.enslaving_degree = env.env_config.enslaving_degree
         self.start_position = np.zeros(2, dtype=np.float32)
         self.start_direction = np.zeros(2, dtype=np.float32)
+        self.memory = {"position": []}                         # area.py:17,30
+
+    def save(self) -> None:
+        """Agent.save (area.py:32-33): one (2,) float32 leader position per step."""
+        self.memory["position"].append(self.position.astype(np.float32))
 
     @property
     def position(self) -> np.ndarray:
@@ -126,6 +137,12 @@ class EvacuationEnv:
         self.experiment_name = cfg.experiment_name
         self._act = torch.zeros((1, 2), dtype=torch.float32, device=self._batched.device)
         self._cache = None
+        # the feed of the reference's animation code (env.py:81-83): frames are recorded while `draw` is set -- from the
+        # config, or switched on by reset() for every giff_freq-th episode -- exactly as the reference records them; drawing
+        # them (save_animation) stays out of scope
+        self.draw = bool(cfg.draw)
+        self.giff_freq = int(cfg.giff_freq)
+        self.save_next_episode_anim = False
 
     def with_wrappers(self, wrap_config: EnvWrappersConfig) -> "EvacuationEnv":
         """EnvWrappersConfig.wrap_env(env): the wrappers are the kernel's observation epilogue."""
@@ -164,10 +181,17 @@ class EvacuationEnv:
     def reset(self, seed=None, options=None):
         """env.py:106-139.  As in the reference, ``seed`` does not reseed the dynamics."""
         self._cache = None
+        if self.save_next_episode_anim or (self.time.n_episodes + 1) % self.giff_freq == 0:      # env.py:110-112
+            self.draw = True
+            self.save_next_episode_anim = True
         draws = None if options is None else options.get("draws")
         if draws is not None:
             draws = np.asarray(draws, dtype=np.float32)[None]
         obs, _ = self._batched.reset(seed=seed, draws=draws)
+        self._cache = None
+        self.pedestrians.memory = {"positions": [], "statuses": []}                             # pedestrians.py:27
+        self.agent.memory = {"position": []}                                                    # area.py:30
+        self.pedestrians.save()                                                                 # env.py:137: always, drawing or not
         return self._obs_to_numpy(obs), {}
 
     def step(self, action, noise=None):
@@ -183,12 +207,25 @@ class EvacuationEnv:
         if noise is not None:
             noise = np.asarray(noise, dtype=np.float32)[None]
         obs, reward, term, trunc, _ = self._batched.step(self._act, noise=noise)
-        return (self._obs_to_numpy(obs), float(reward[0].item()), bool(term[0].item()), bool(trunc[0].item()), {})
+        terminated, truncated = bool(term[0].item()), bool(trunc[0].item())
+        if self.draw:                                                                           # env.py:153-155
+            self.pedestrians.save()
+            self.agent.save()
+            if terminated or truncated:
+                # env.py:164-165 calls save_animation() here; drawing is out of scope, its bookkeeping is not (env.py:322-324):
+                # the frames stay in pedestrians.memory / agent.memory until the next reset, for the caller to render
+                if self.save_next_episode_anim:
+                    self.save_next_episode_anim = False
+                    self.draw = False
+        return (self._obs_to_numpy(obs), float(reward[0].item()), terminated, truncated, {})
 
     def render(self):
         raise NotImplementedError("rendering is out of scope of the MI355X hot path (see DESIGN.md)")
 
     def save_animation(self):
+        """The reference draws ``pedestrians.memory`` / ``agent.memory`` with matplotlib here (env.py:241-324).  Out of scope:
+        the frames are recorded (``draw``), hand them to the reference's own method with
+        ``evacuation_amd.trajectory.feed_reference_env(ref_env, env.pedestrians.memory, env.agent.memory)``."""
         raise NotImplementedError("rendering is out of scope of the MI355X hot path (see DESIGN.md)")
 
     def seed(self, seed=None):   # env.py:326-328 (a no-op there too, apart from gym bookkeeping)

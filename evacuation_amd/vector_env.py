@@ -48,9 +48,20 @@ class StepInfos(dict):
         super().__init__(**kw)
         self._env, self._term, self._trunc = env, terminated, truncated
         self._done = None
+        self._step_id = env._steps_taken
+
+    def _check_fresh(self):
+        # The flags, the terminal observations and the episode records live in buffers the env REUSES every step: an
+        # infos object first asked for "final_info" after the env has stepped again would silently describe the wrong
+        # step (a trainer that stores infos and inspects them later; asynchronous loggers).
+        if self._done is None and self._env._steps_taken != self._step_id:
+            raise RuntimeError("infos['final_info'] of an earlier step was first read after the env had stepped again: its buffers "
+                               "are reused every step (like the reference's live-reference observations, env.py:98-104) -- read it "
+                               "before the next step(), or clone infos['final_observation'] / infos['episode_stats'] at step time")
 
     def _done_mask(self):
         if self._done is None:
+            self._check_fresh()
             self._done = ((self._term != 0) | (self._trunc != 0)).cpu().numpy()
         return self._done
 
@@ -186,6 +197,7 @@ class BatchedEvacuationEnv:
         self.observation_space = Box(-np.inf, np.inf, (E, self.obs_dim), np.float32)
         self.algorithmic_bytes_per_env_step = int(self.lib.evac_algorithmic_bytes_per_env_step(self._h))
         self._was_reset = False
+        self._steps_taken = 0          # step() calls so far (StepInfos: a lazily built final_info must be read before the next one)
 
     # ------------------------------------------------------------------------------------------
     def _stream(self):
@@ -275,6 +287,7 @@ class BatchedEvacuationEnv:
             _lib.check(self.lib.evac_step_normalized(self._h, _ptr(act), _ptr(nz), _ptr(obs), _ptr(rew), _ptr(term), _ptr(trunc),
                                                      int(self.autoreset), fo, fs, _ptr(state), gamma, obs_clip, reward_clip,
                                                      eps, self._stream()), self._h)
+        self._steps_taken += 1
         infos = {}
         if self.autoreset:
             # device tensors; rows are meaningful where terminated | truncated (no host sync unless "final_info" is asked for)

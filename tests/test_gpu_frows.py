@@ -211,3 +211,62 @@ def test_cell_list_and_all_pairs_kernels_agree(ea, n, monkeypatch):
         torch.testing.assert_close(a.get_state()["pos"], b.get_state()["pos"], rtol=0, atol=1e-5)
     for env in envs.values():
         env.close()
+
+
+def test_facade_records_the_frames_the_reference_records(ea):
+    """VERDICT r02 'missing' 4: ``setup_env(cfg(draw=True))`` -- the single-env facade keeps ``pedestrians.memory`` /
+    ``agent.memory`` exactly as the reference's step() does (env.py:137,153-155; pedestrians.py:27,33-35; area.py:30-33):
+    the reset frame always, one frame per step while ``draw`` is set; checked against a reference episode's recorded
+    trajectory.  And the giff_freq rule of reset() (env.py:110-112, 322-324)."""
+    d = np.load(os.path.join(H.GOLDEN, "traj_n60_s1_noise05_ens05.npz"))
+    p = H.load_params(d["params_json"])
+    T = 25
+    env = ea.setup_env(cfg_from_params(ea, p, draw=True), ea.EnvWrappersConfig(positions="grav", alpha=3))
+    draws = np.concatenate([d["draw_pos"], d["draw_dir"]], axis=1).astype(np.float32)
+    env.reset(options={"draws": draws})
+    assert len(env.pedestrians.memory["positions"]) == 1 and env.agent.memory["position"] == []
+    for k in range(T):
+        env.step(d["action"][k], noise=d["noise"][k])
+    pm, am = env.pedestrians.memory, env.agent.memory
+    assert len(pm["positions"]) == len(pm["statuses"]) == T + 1 and len(am["position"]) == T
+    for t in range(T + 1):
+        np.testing.assert_allclose(pm["positions"][t], d["pos"][t], rtol=0, atol=ATOL, err_msg=f"frame {t}")
+        assert pm["positions"][t].dtype == np.float64 and [s.value for s in pm["statuses"][t]] == d["status"][t].tolist()
+        assert isinstance(pm["statuses"][t][0], ea.Status)
+    for t in range(T):
+        np.testing.assert_allclose(am["position"][t], d["agent_pos"][t + 1], rtol=0, atol=1e-6)
+        assert am["position"][t].dtype == np.float32
+    env.close()
+    # without draw only the reset frame is kept, until reset() switches drawing on for every giff_freq-th episode
+    env = ea.setup_env(ea.EnvConfig(number_of_pedestrians=10, max_timesteps=3, giff_freq=2), ea.EnvWrappersConfig())
+    env.reset()
+    assert env.draw is False
+    for _ in range(3):
+        out = env.step(np.array([0.3, 0.1], dtype=np.float32))
+    assert out[3] is True and len(env.pedestrians.memory["positions"]) == 1 and env.agent.memory["position"] == []
+    env.reset()                                            # second episode: (n_episodes + 1) % giff_freq == 0
+    assert env.draw is True and env.save_next_episode_anim is True
+    for _ in range(3):
+        out = env.step(np.array([0.3, 0.1], dtype=np.float32))
+    assert out[3] is True and len(env.pedestrians.memory["positions"]) == 4 and len(env.agent.memory["position"]) == 3
+    assert env.draw is False and env.save_next_episode_anim is False     # what save_animation() leaves behind (env.py:322-324)
+    env.close()
+
+
+def test_stale_infos_are_refused(ea):
+    """infos["final_info"] is built lazily from buffers the env reuses every step; first asking an OLD infos object
+    after the env has stepped again must fail loudly instead of describing the wrong step."""
+    import torch
+    E = 6
+    env = ea.BatchedEvacuationEnv(ea.EnvConfig(number_of_pedestrians=20, max_timesteps=2), ea.EnvWrappersConfig(positions="grav"), num_envs=E)
+    env.reset()
+    act = torch.zeros((E, 2), device=env.device) + 0.5
+    env.step(act)
+    _, _, _, trunc, infos = env.step(act)                 # every env truncates here
+    assert bool(trunc.all()) and "final_info" in infos and len(infos["final_info"]) == E     # read in time: fine, and cached
+    _, _, _, _, old = env.step(act)
+    env.step(act)                                          # the env moved on before `old` was looked at
+    with pytest.raises(RuntimeError, match="stepped again"):
+        _ = "final_info" in old
+    assert len(infos["final_info"]) == E                  # what was built in time stays valid
+    env.close()
