@@ -92,7 +92,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-gather", action="store_true", help="skip the all-gather of the outputs (N>1)")
     ap.add_argument("--gather", default="obs", choices=["obs", "slab", "direct"],
                     help="what the ranks all-gather per chunk and how: the observation batch (north_star) or the whole packed "
-                         "record through RCCL, or the packed record by copy-engine peer writes (direct: no CU taken)")
+                         "record through RCCL, or the observation batch by copy-engine peer writes (direct: no CU-resident collective)")
     ap.add_argument("--gather-schedule", default="pipelined", choices=["pipelined", "split"],
                     help="pipelined: the gather of chunk j-1 runs under the compute of chunk j (double-buffered, across blocks); "
                          "split: a one-launch block goes out as two K/2 launches, each gathered inside the block")
@@ -362,7 +362,7 @@ def main(argv=None):
 
     # Preallocated, reused output chunks (the trainer's rollout buffer, rpo_agent.py:158-163): the kernel writes one packed
     # slab [T, E, D+3] = [obs | reward | terminated | truncated] per launch shape and buffer parity.
-    GW = D if args.gather == "obs" else D + 3                 # gathered words per env-step
+    GW = D + 3 if args.gather == "slab" else D                # gathered words per env-step (obs, direct: the observation columns)
     chunks = {}
 
     def chunk_bufs(t, parity):
@@ -374,10 +374,10 @@ def main(argv=None):
             b["launch"] = loc.rollout_launcher(t, b)          # pre-bound ctypes call: no per-launch Python argument work
             if gather_rollout:
                 b["gathered"] = torch.empty((world, t, E, GW), dtype=torch.float32, device=device)
-                if args.gather == "obs":
+                if args.gather != "slab":
                     b["gsrc"] = torch.empty((t, E, GW), dtype=torch.float32, device=device)
                 if args.gather == "direct":
-                    b["direct"] = DirectGather(b["slab"], b["gathered"])     # peers' `gathered` buffers mapped through hipIpc
+                    b["direct"] = DirectGather(b["gsrc"], b["gathered"])     # peers' `gathered` buffers mapped through hipIpc
             chunks[key] = b
         return b
 
@@ -401,13 +401,14 @@ def main(argv=None):
         ready.record()                                        # chunk j (and everything before it) on the compute stream
         with torch.cuda.stream(comm):
             comm.wait_event(ready)
-            if args.gather == "direct":
-                b["direct"].issue(comm)
-            elif args.gather == "slab":
+            if args.gather == "slab":
                 all_gather_envs(b["slab"], out=b["gathered"])
             else:                                             # the observation columns, copied out on the comm stream
                 b["gsrc"].copy_(b["slab"][..., :D])
-                all_gather_envs(b["gsrc"], out=b["gathered"])
+                if args.gather == "direct":
+                    b["direct"].issue(comm)                   # world copy-engine writes into the peers' buffers
+                else:
+                    all_gather_envs(b["gsrc"], out=b["gathered"])
             fin = torch.cuda.Event()
             fin.record(comm)
         return fin
@@ -591,7 +592,7 @@ def main(argv=None):
             gather_desc = ", RCCL all-gather of the step outputs after every step"
         else:
             what = {"obs": "observation batch (RCCL)", "slab": "[obs|reward|flags] records (RCCL)",
-                    "direct": "[obs|reward|flags] records (copy-engine peer writes over hipIpc, no CU)"}[args.gather]
+                    "direct": "observation batch (copy-engine peer writes over hipIpc, no CU-resident collective kernel)"}[args.gather]
             how = ("issued after the NEXT chunk's launch, inside the timed block (double-buffered; block b carries block b-1's gather)"
                    if lag == 1 else "each chunk gathered as soon as it is computed, inside its block")
             gather_desc = f", all-gather of the {what} per {inner}-step chunk on a side stream, {how}"

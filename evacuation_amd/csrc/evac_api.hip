@@ -712,11 +712,13 @@ int evac_norm_step(evac_handle_t h, float* obs, float* final_obs, float* reward,
     return check_launch(h, "evac_norm_step");
 }
 
-#ifdef EVAC_STAMP
+#ifdef EVAC_STEP_TIMES
 int evac_debug_step_times(unsigned long long* out2048) {
     if (hipMemcpyFromSymbol(out2048, HIP_SYMBOL(g_step_times), 16 * 128 * sizeof(unsigned long long)) != hipSuccess) return EVAC_ERR_HIP;
     return EVAC_OK;
 }
+#endif
+#ifdef EVAC_STAMP
 // diagnostic build only: read and clear the per-phase cycle sums
 int evac_debug_stamps(unsigned long long* out16) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return EVAC_ERR_HIP;

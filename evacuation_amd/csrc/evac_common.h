@@ -26,9 +26,14 @@
 
 // Diagnostic build only (-DEVAC_STAMP, tools/stamps.sh): s_memtime stamps around the phases of a step,
 // summed per phase over all waves into g_stamps.  No stamp executes in the shipped library.
+// Diagnostic build only (-DEVAC_STEP_TIMES, tools/step_times.py): s_memrealtime at the top of every step of the 16 waves of
+// workgroup 0 -- how the waves of one CU progress through a launch.  (Separate from EVAC_STAMP: the phase stamps end every wave
+// with atomics on 16 shared words, which stall the waves still running and distort exactly this picture.)
+#ifdef EVAC_STEP_TIMES
+__device__ unsigned long long g_step_times[16][128];
+#endif
 #ifdef EVAC_STAMP
 __device__ unsigned long long g_stamps[16];
-__device__ unsigned long long g_step_times[16][128];   // s_memrealtime (100 MHz) at the top of step t of the 16 waves of workgroup 0
 struct StampState {
     unsigned long long acc[16] = {};
     unsigned long long last = 0;

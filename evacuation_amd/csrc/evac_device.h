@@ -543,7 +543,7 @@ __device__ __forceinline__ void rollout_body(
 #endif
     int staged = 0;                       // t % kStageSteps: the slot of the step in the staging block
     for (int t = 0; t < n_steps; ++t) {
-#ifdef EVAC_STAMP
+#ifdef EVAC_STEP_TIMES
         if (w.lane == 0 && t < 128 && blockIdx.x == 0 && threadIdx.x < 1024) {
             unsigned long long now_;
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");

@@ -1,6 +1,7 @@
-"""Progress of the 16 waves of workgroup 0 inside ONE rollout launch (diagnostic EVAC_STAMP build, tools/stamps.sh build):
+"""Progress of the 16 waves of workgroup 0 inside ONE rollout launch (diagnostic build: hipcc ... -DEVAC_STEP_TIMES -o
+tools/ablate_libs/libevac_steptimes.so, loaded through EVAC_LIB):
 s_memrealtime at the top of every step.  With the load schedule workgroup 0 carries the heaviest envs of the batch in its
-waves 12..15 (one per SIMD), the lightest in waves 0..3.  GPU box."""
+waves 0..3 (one per SIMD: the SIMDs' oldest waves), the lightest in waves 12..15.  GPU box."""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,7 +27,7 @@ for rep in range(2):
         d = np.diff(a[w]) * 10.0
         print(f"  wave {w:2d} (SIMD {w % 4}): start {rel[w, 0]:6.1f}  mid {rel[w, T // 2]:7.1f}  last {rel[w, -1]:7.1f}   median {np.median(d):6.0f} ns/step, max {d.max():6.0f} at step {int(d.argmax())}")
     if rep == 1:
-        for w in (12, 13, 14, 15):
+        for w in (0, 1, 2, 3):
             d = np.diff(a[w]) * 10.0
             slow = np.nonzero(d > 1.5 * np.median(d))[0]
             print(f"  wave {w}: slow steps (> 1.5 x median) at", [(int(i), round(float(rel[w, i]), 1), int(d[i])) for i in slow][:30])
