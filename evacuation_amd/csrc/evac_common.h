@@ -339,6 +339,24 @@ __device__ __forceinline__ void pair_accumulate_int(float XI, float YI, f4 t, fl
     sy = __mul24(wi, __float_as_int(hw)) + sy;
 }
 
+// Two ROWS of a lane against one column with integer heading sums (the teams' many-rows sweep): the two 0/1 weights come out
+// of four packed instructions (as pair_accumulate_rows2), then one shift and two integer multiply-adds per row -- 10
+// instructions where two pair_accumulate_int calls take 14; the same weights, the same integer sums.
+__device__ __forceinline__ void pair_accumulate_int_rows2(f2 X2, f2 Y2, f4 t, f2 r2b2, int& ax0, int& ay0, int& ax1, int& ay1) {
+    const f2 txy = __builtin_shufflevector(t, t, 0, 1);
+    f2 dx, dy, w;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dx) : "v"(X2), "v"(txy));                 // X - t.x
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dy) : "v"(Y2), "v"(txy));    // Y - t.y
+    const f2 a = __builtin_elementwise_fma(-dy, dy, r2b2);
+    asm("v_pk_fma_f32 %0, %1, %1, %2 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(w) : "v"(dx), "v"(a));
+    const float wx = w.x, wy = w.y, hz = t.z, hw = t.w;   // (bit_cast straight from a vector element picks element 0 with this compiler)
+    const int w0 = (int)(__builtin_bit_cast(unsigned, wx) >> 29), w1 = (int)(__builtin_bit_cast(unsigned, wy) >> 29);
+    ax0 = __mul24(w0, __float_as_int(hz)) + ax0;
+    ay0 = __mul24(w0, __float_as_int(hw)) + ay0;
+    ax1 = __mul24(w1, __float_as_int(hz)) + ax1;
+    ay1 = __mul24(w1, __float_as_int(hw)) + ay1;
+}
+
 // x^k for a wave-uniform integer k in [1,63] (k = alpha + 2).  The powers the reference's experiments use
 // (alpha = 2, 3, 5: run_scripts/) take a uniform branch to a straight product; anything else binary powering with
 // uniform branches -- no per-bit select masks held in scalar registers through the step loop.  A few ulp.

@@ -40,6 +40,10 @@
 
 #include "evac_device.h"
 
+#ifndef EVAC_TEAM_PK
+#define EVAC_TEAM_PK 1      // 0: the many-rows sweep of the teams in plain arithmetic (A/B builds; same bits)
+#endif
+
 namespace evac {
 
 __device__ __forceinline__ void store_dev(void* ptr, f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
@@ -395,14 +399,19 @@ struct Team {
                 const float2 ra = sm.rowpos[pw][c.lane], rb = sm.rowpos[pw + 1][c.lane];   // slots beyond the counts hold stale rows: computed, never read
                 int ax0 = 0, ay0 = 0, ax1 = 0, ay1 = 0;
                 if (na != 0 && nb != 0) {
+                    const f2 X2 = f2{ra.x, rb.x}, Y2 = f2{ra.y, rb.y}, r2b2 = f2{kRPed2Big, kRPed2Big};
                     for (int j = jbeg; j < jend; j += 4) {
                         f4 t[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
+#if EVAC_TEAM_PK
+                            pair_accumulate_int_rows2(X2, Y2, t[k], r2b2, ax0, ay0, ax1, ay1);      // (the two weights in packed arithmetic: 10 instead of 14 instructions)
+#else
                             pair_accumulate_int(ra.x, ra.y, t[k], kRPed2Big, ax0, ay0);
                             pair_accumulate_int(rb.x, rb.y, t[k], kRPed2Big, ax1, ay1);
+#endif
                         }
                     }
                 } else {
