@@ -591,7 +591,8 @@ def main(argv=None):
         elif args.mode == "step":
             gather_desc = ", RCCL all-gather of the step outputs after every step"
         else:
-            what = {"obs": "observation batch (RCCL)", "slab": "[obs|reward|flags] records (RCCL)",
+            coll = "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + ", host-staged: testing aid"
+            what = {"obs": f"observation batch ({coll})", "slab": f"[obs|reward|flags] records ({coll})",
                     "direct": "observation batch (copy-engine peer writes over hipIpc, no CU-resident collective kernel)"}[args.gather]
             how = ("issued after the NEXT chunk's launch, inside the timed block (double-buffered; block b carries block b-1's gather)"
                    if lag == 1 else "each chunk gathered as soon as it is computed, inside its block")

@@ -72,7 +72,7 @@ struct evac_handle {
     int sched_age;      // env steps rolled out since the schedule was last rebuilt (< 0: never built)
     bool team_bound;    // the workspace holds the teams' exchange areas
     int team_fit;       // -1: not checked yet; 1 / 0: the team grid fits the device at once (occupancy x CUs >= workgroups) or not
-    bool team_coop;     // team kernels are launched with hipLaunchCooperativeKernel (the device supports it; EVAC_TEAM_COOP=0: plain launches)
+    bool team_coop;     // EVAC_TEAM_COOP=1 (and the device supports it): team kernels are launched with hipLaunchCooperativeKernel
     int cus;            // compute units of the device
     bool team_fault;    // EVAC_TEAM_FAULT=1 (tests): launch the team grid one workgroup short
     // The teams' error word: 64 bytes of host-mapped memory owned by the handle.  A team that lost a member raises it from the
@@ -350,7 +350,7 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
                 int coop = 0;
                 const char* tc = std::getenv("EVAC_TEAM_COOP");
                 if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) != hipSuccess) coop = 0;
-                h->team_coop = coop != 0 && !(tc && tc[0] == '0');
+                h->team_coop = coop != 0 && tc && tc[0] == '1';      // opt-in: see evac_rollout
                 const char* tf = std::getenv("EVAC_TEAM_FAULT");
                 h->team_fault = tf && tf[0] == '1';
             }
@@ -559,8 +559,10 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
         // 513..1024 pedestrians, few envs: K workgroups (CUs) per env (evac_team.h).  The teams' barrier counters start
         // every launch at zero; workgroup b = j * 8 + xcd carries team (j / K) * 8 + xcd.  All members of a team spin on its
         // counter, so the whole grid must be resident at once: checked by team_grid_fits (occupancy x CUs >= workgroups; a grid
-        // that does not fit runs the one-workgroup-per-env kernels below) and, where the device supports it, guaranteed by a
-        // cooperative launch even when another stream has kernels in flight.
+        // that does not fit runs the one-workgroup-per-env kernels below).  A foreign kernel on another stream (the sharded
+        // env's all-gather) can delay a member, not starve it -- it ends, the member starts, and the bounded waits (~1 s) outlast
+        // it: tests/test_gpu_team.py keeps a second stream busy throughout.  EVAC_TEAM_COOP=1 launches cooperatively instead
+        // (the runtime then guarantees co-residency); it costs 3-4 % of the C5 shard's throughput and is not the default.
         hipStream_t s_ = (hipStream_t)stream;
         const int E = h->p.n_envs;
         if (hipMemsetAsync(h->p.team_ctr, 0, (size_t)E * 128, s_) != hipSuccess) return fail(h, EVAC_ERR_HIP, "evac_rollout: hipMemsetAsync failed");

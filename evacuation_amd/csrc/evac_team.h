@@ -29,9 +29,9 @@
 //
 // The members of a team must be resident together (they spin on the team's counter).  The host (evac_rollout, evac_api.hip)
 // checks with hipOccupancyMaxActiveBlocksPerMultiprocessor that the whole grid fits the device at once (one 1024-thread
-// workgroup per CU) -- otherwise the handle runs the one-workgroup-per-env kernels -- and launches with
-// hipLaunchCooperativeKernel where the device supports it, so that the runtime, not luck, keeps the members co-resident when
-// another stream (the all-gather of the sharded env) has work in flight.  A team sits on ONE XCD (workgroup ids congruent
+// workgroup per CU) -- otherwise the handle runs the one-workgroup-per-env kernels.  A kernel of another stream (the all-gather
+// of the sharded env) can delay a member until it ends, never starve it, and the waits outlast that; EVAC_TEAM_COOP=1 launches
+// with hipLaunchCooperativeKernel instead, which lets the runtime guarantee co-residency at 3-4 % of the throughput.  A team sits on ONE XCD (workgroup ids congruent
 // mod 8 share an XCD -- round-robin dispatch; nothing depends on it but the latency).  Spins are bounded all the same: a
 // team that lost a member sets a sticky abort flag, runs to the end without waiting, does NOT write its env's state back
 // (the state of that env stays what it was before the launch) and raises the handle's error word -- host-mapped memory that

@@ -193,8 +193,8 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions_or_null,
  * Performance devices only: results are bit-identical with and without the workspace.  NULL unbinds.
  *
  * Team rollouts need every workgroup of their grid resident at once (the members of a team wait for each other).  evac_rollout
- * checks that with hipOccupancyMaxActiveBlocksPerMultiprocessor (a grid that does not fit runs one workgroup per env instead) and
- * launches cooperatively where the device supports it (EVAC_TEAM_COOP=0: plain launches).  Should a team lose a member all the
+ * checks that with hipOccupancyMaxActiveBlocksPerMultiprocessor (a grid that does not fit runs one workgroup per env instead);
+ * EVAC_TEAM_COOP=1 additionally launches with hipLaunchCooperativeKernel (3-4 % slower).  Should a team lose a member all the
  * same, its waits are bounded: the launch ends, that env's state is NOT written back, and the handle's error word -- 64 bytes of
  * host-mapped memory, the one thing besides the config the library allocates -- is raised.  Every later call on the handle
  * (evac_reset / evac_step* / evac_rollout / evac_observe / evac_get_state / evac_set_state) then returns EVAC_ERR_TEAM_ABORTED

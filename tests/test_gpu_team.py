@@ -207,8 +207,9 @@ def test_team_that_loses_a_member_is_reported_and_keeps_its_state(ea):
 @pytest.mark.parametrize("coop", ["1", "0"])
 def test_team_rollout_with_another_stream_busy(ea, coop):
     """the sharded env overlaps the all-gather of one chunk with the next rollout, so the team kernels
-    must stay correct while a second stream keeps kernels resident on the device (cooperative launch, or a plain launch whose
-    bounded waits simply outlast the intruder): no team error, same bits as the one-workgroup kernels."""
+    must stay correct while a second stream keeps kernels resident on the device (a plain launch whose bounded waits simply
+    outlast the intruder -- the default --, or the cooperative launch of EVAC_TEAM_COOP=1): no team error, same bits as the
+    one-workgroup kernels."""
     import torch
     n, E = 1024, 32
     cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=60, is_new_exiting_reward=True)
