@@ -362,6 +362,8 @@ def main(argv=None):
 
     # Preallocated, reused output chunks (the trainer's rollout buffer, rpo_agent.py:158-163): the kernel writes one packed
     # slab [T, E, D+3] = [obs | reward | terminated | truncated] per launch shape and buffer parity.
+    compute = torch.cuda.current_stream(device)               # every launch of this benchmark goes to this stream
+    comm = torch.cuda.Stream(device=device) if do_gather else None
     GW = D + 3 if args.gather == "slab" else D                # gathered words per env-step (obs, direct: the observation columns)
     chunks = {}
 
@@ -371,7 +373,7 @@ def main(argv=None):
         if b is None:
             b = {"slab": torch.empty((t, E, D + 3), dtype=torch.float32, device=device),
                  "episode_stats": torch.zeros((t, E, loc.stats_words), dtype=torch.float32, device=device)}
-            b["launch"] = loc.rollout_launcher(t, b)          # pre-bound ctypes call: no per-launch Python argument work
+            b["launch"] = loc.rollout_launcher(t, b, stream=compute)   # pre-bound ctypes call: no per-launch Python argument work
             if gather_rollout:
                 b["gathered"] = torch.empty((world, t, E, GW), dtype=torch.float32, device=device)
                 if args.gather != "slab":
@@ -381,7 +383,6 @@ def main(argv=None):
             chunks[key] = b
         return b
 
-    comm = torch.cuda.Stream(device=device) if do_gather else None
     step_actions = torch.rand((E, 2), device=device) * 2 - 1
 
     def launch(j, t):
@@ -418,15 +419,12 @@ def main(argv=None):
             torch.cuda.current_stream().wait_event(fin)
 
     def drain_compute():
-        """Poll the stream until the issued work is done: a blocking wait adds the host's sleep / wake-up latency (~10 us)
-        to a block that is itself ~60 us."""
-        st = torch.cuda.current_stream()
-        while not st.query():
-            pass
+        """Everything issued to the device so far is done.  (hipDeviceSynchronize spins here; a hipStreamQuery loop costs the
+        same wait plus ~2.5 us on the NEXT launch call -- the query leaves a marker behind: tools/block_overhead.py.)"""
+        torch.cuda.synchronize()
 
     def drain_gather():
-        while not comm.query():
-            pass
+        comm.synchronize()
 
     pipe = ChunkPipeline(launch, gather if do_gather else None, wait_gather, drain_compute, drain_gather if do_gather else None, lag=lag)
 
@@ -462,7 +460,7 @@ def main(argv=None):
     state0 = [t.clone() for t in (loc.ped, loc.status, loc.agent, loc.clock, loc.acc)]   # for the kernel-timing replay below
     ws0 = loc.workspace.clone() if loc.workspace is not None else None
     n_blocks = per_sweep * sweeps
-    wall, phases = [], []
+    wall, phases, t_call = [], [], []
     # one launch per block and nothing to gather: issue it without the pipeline's bookkeeping (a few us of Python next to a 50 us kernel)
     one_launch = chunk_bufs(K, 0)["launch"] if (args.mode == "rollout" and sizes == [K] and not do_gather) else None
     for b in range(n_blocks):
@@ -471,6 +469,7 @@ def main(argv=None):
         t0 = time.perf_counter()
         if one_launch is not None:
             one_launch()                                      # EXACTLY K steps
+            t_call.append(time.perf_counter() - t0)           # (the launch call alone: reported, not subtracted)
             drain_compute()
         else:
             pipe.run_block(sizes)                             # EXACTLY K steps (+ one gather per launch)
@@ -483,6 +482,11 @@ def main(argv=None):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)             # per block: the slowest rank
         wall = [float(x) for x in tt.tolist()]
     block_s, blocks_info = summarize_blocks(wall, phases, per_sweep, K)
+    if t_call:
+        blocks_info["launch_call_us_median"] = sorted(t_call)[len(t_call) // 2] * 1e6
+    if os.environ.get("EVAC_BENCH_DUMP") and rank == 0:      # diagnostic: the raw blocks
+        with open(os.environ["EVAC_BENCH_DUMP"], "w") as f:
+            json.dump({"wall_s": wall, "phase": phases, "launch_call_s": t_call}, f)
 
     # Duration of the dominant kernel's launches, from HIP events on the launching stream.  An event pair around ONE
     # short launch also times the ~7 us between the markers and the kernel (11 % of a 20-step launch), so the average

@@ -72,6 +72,7 @@ struct evac_handle {
     int sched_age;      // env steps rolled out since the schedule was last rebuilt (< 0: never built)
     bool team_bound;    // the workspace holds the teams' exchange areas
     int team_fit;       // -1: not checked yet; 1 / 0: the team grid fits the device at once (occupancy x CUs >= workgroups) or not
+    size_t team_xchg_bytes;   // the teams' exchange area (records + tile slots), reset to the sentinel before every team launch
     bool team_coop;     // EVAC_TEAM_COOP=1 (and the device supports it): team kernels are launched with hipLaunchCooperativeKernel
     int cus;            // compute units of the device
     bool team_fault;    // EVAC_TEAM_FAULT=1 (tests): launch the team grid one workgroup short
@@ -420,7 +421,7 @@ int evac_bind_state(evac_handle_t h, float* ped, uint8_t* status, float* agent, 
 
 namespace {
 struct WorkspaceLayout {
-    size_t sched, stats, team_err, team_ctr, team_cnt, team_rec, team_tile, total;
+    size_t sched, stats, team_err, team_ctr, team_cnt, team_rec, team_tile, team_xchg_end, total;
 };
 WorkspaceLayout workspace_layout(const evac_handle* h) {
     const size_t E = (size_t)h->p.n_envs;
@@ -433,8 +434,9 @@ WorkspaceLayout workspace_layout(const evac_handle* h) {
         w.team_err = o; o = up(o + 128);
         w.team_ctr = o; o = up(o + E * 128);
         w.team_cnt = o; o = up(o + 2 * E * 64);
-        w.team_rec = o; o = up(o + 2 * E * 32 * 16);
-        w.team_tile = o; o = up(o + 2 * E * 1024 * 16);
+        w.team_rec = o; o = up(o + 3 * E * 32 * 16);          // (three slot sets: evac_team.h, exchange)
+        w.team_tile = o; o = up(o + 3 * E * 1024 * 16);
+        w.team_xchg_end = o;
     }
     w.total = o;
     return w;
@@ -460,6 +462,7 @@ int evac_bind_workspace(evac_handle_t h, void* workspace, int64_t bytes) {
         h->p.team_cnt = base + w.team_cnt;
         h->p.team_rec = base + w.team_rec;
         h->p.team_tile = base + w.team_tile;
+        h->team_xchg_bytes = w.team_xchg_end - w.team_rec;
         h->team_bound = true;
     }
     return EVAC_OK;
@@ -565,7 +568,12 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
         // (the runtime then guarantees co-residency); it costs 3-4 % of the C5 shard's throughput and is not the default.
         hipStream_t s_ = (hipStream_t)stream;
         const int E = h->p.n_envs;
+#if EVAC_TEAM_SENTINEL
+        // every slot of the exchange area starts a launch holding the sentinel (the last two rounds of the previous launch left data)
+        if (hipMemsetAsync(h->p.team_rec, 0xff, h->team_xchg_bytes, s_) != hipSuccess) return fail(h, EVAC_ERR_HIP, "evac_rollout: hipMemsetAsync failed");
+#else
         if (hipMemsetAsync(h->p.team_ctr, 0, (size_t)E * 128, s_) != hipSuccess) return fail(h, EVAC_ERR_HIP, "evac_rollout: hipMemsetAsync failed");
+#endif
         const dim3 grid(team_grid(h)), block(1024);
         int n_steps_ = (int)n_steps;
         const float2* actions_ = (const float2*)actions;
@@ -717,6 +725,12 @@ int evac_norm_step(evac_handle_t h, float* obs, float* final_obs, float* reward,
 #ifdef EVAC_STEP_TIMES
 int evac_debug_step_times(unsigned long long* out2048) {
     if (hipMemcpyFromSymbol(out2048, HIP_SYMBOL(g_step_times), 16 * 128 * sizeof(unsigned long long)) != hipSuccess) return EVAC_ERR_HIP;
+    return EVAC_OK;
+}
+#endif
+#ifdef EVAC_STAMP_WAVES
+int evac_debug_wave_stamps(unsigned long long* out256) {
+    if (hipMemcpyFromSymbol(out256, HIP_SYMBOL(g_wave_stamps), 256 * sizeof(unsigned long long)) != hipSuccess) return EVAC_ERR_HIP;
     return EVAC_OK;
 }
 #endif

@@ -34,6 +34,9 @@ __device__ unsigned long long g_step_times[16][128];
 #endif
 #ifdef EVAC_STAMP
 __device__ unsigned long long g_stamps[16];
+#ifdef EVAC_STAMP_WAVES
+__device__ unsigned long long g_wave_stamps[16][16];
+#endif
 struct StampState {
     unsigned long long acc[16] = {};
     unsigned long long last = 0;

@@ -5,18 +5,19 @@
 //
 // Member k of a team owns pedestrians [k P, (k+1) P), P = 1024 / K, in the lanes of its first P / 64 waves ("ped waves");
 // all 16 waves of the workgroup share the member's part of the pair work.  The members meet ONCE per step through global
-// memory (device-scope write-through stores, device-scope loads, a counter per team; no cache flush or invalidation:
-// tools/microbench/team_barrier.hip measures 1.5 us per publish -> barrier -> gather round of 16 KiB among 8 CUs).  What
-// travels in that round:
+// memory (device-scope write-through stores and device-scope loads, no cache flush or invalidation, and NO counter: every
+// published word validates itself against a sentinel that its slot holds between uses -- exchange() below; round 2's
+// store / acknowledgement / counter / spin / load protocol is kept as EVAC_TEAM_SENTINEL=0 for A/B builds;
+// tools/microbench/team_sentinel.hip and team_barrier.hip time both in isolation).  What travels in that round:
 //   * the step's reduction: every ped wave publishes the same 32-byte record as a wave of Cells<16> leaves in LDS; after the
 //     barrier three helper waves of every member fold the 16 records with the same DPP tree (float sums, packed counts and
 //     the prefix of the segment counts are independent chains), so rewards / observations / flags are bit-identical to the
 //     one-workgroup kernels' and every member takes the same decisions (autoreset, termination) without further talk;
 //   * the NEXT step's tile: the head of the next step (pre_pair: escaped pin, exiting heading, unit heading) depends on the
 //     pedestrian's own post-step state only, so every ped wave already publishes its moving pedestrians (position x 2^40,
-//     integer heading), compacted inside the wave's 64-entry segment, and their count; after the barrier every member
-//     gathers all 16 segments into its LDS tile -- the columns of the next step's distance matrix.  (The first step of a
-//     launch and the step after an autoreset run the same exchange on their own.)
+//     integer heading) in the wave's 64-entry segment; every member gathers all 16 segments, compacted, into its LDS
+//     tile -- the columns of the next step's distance matrix.  (The first step of a launch and the step after an
+//     autoreset run the same exchange on their own.)
 // The rows are the member's own pedestrians that need one (step_env: needs_row), compacted per ped wave.  MANY rows (early in
 // an episode): two ped waves per pass (two rows per lane), each of the 16 waves takes 1/16 of the columns (wave-uniform
 // ds_read_b128 broadcasts).  FEW rows (<= kFewRows: most of an episode under enslaving_degree 1, when only the VISCEK
@@ -27,7 +28,7 @@
 // Everything else is the common step body (step_env) and rollout scaffolding (rollout_body); waves without pedestrians
 // ("helper" waves) skip the per-pedestrian arithmetic.
 //
-// The members of a team must be resident together (they spin on the team's counter).  The host (evac_rollout, evac_api.hip)
+// The members of a team must be resident together (they poll each other's slots).  The host (evac_rollout, evac_api.hip)
 // checks with hipOccupancyMaxActiveBlocksPerMultiprocessor that the whole grid fits the device at once (one 1024-thread
 // workgroup per CU) -- otherwise the handle runs the one-workgroup-per-env kernels.  A kernel of another stream (the all-gather
 // of the sharded env) can delay a member until it ends, never starve it, and the waits outlast that; EVAC_TEAM_COOP=1 launches
@@ -43,6 +44,15 @@
 #ifndef EVAC_TEAM_PK
 #define EVAC_TEAM_PK 1      // 0: the many-rows sweep of the teams in plain arithmetic (A/B builds; same bits)
 #endif
+#ifndef EVAC_TEAM_SENTINEL
+#define EVAC_TEAM_SENTINEL 1   // 0: the exchange of rounds 2-3 (store, wait, counter, spin, load) -- A/B builds; same bits
+#endif
+#ifndef EVAC_TEAM_D0
+#define EVAC_TEAM_D0 8      // s_sleep units (64 cycles) between the member's own publish and its first poll
+#endif
+#ifndef EVAC_TEAM_DS
+#define EVAC_TEAM_DS 2      // ... between two polls
+#endif
 
 namespace evac {
 
@@ -50,6 +60,20 @@ __device__ __forceinline__ void store_dev(void* ptr, f4 v) { asm volatile("globa
 __device__ __forceinline__ void store_dev_i32(void* ptr, int v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
 __device__ __forceinline__ void lds_add(int* ptr, int v) { (void)__hip_atomic_fetch_add(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The self-validating exchange (EVAC_TEAM_SENTINEL): a slot of the exchange area holds the sentinel in all its words until
+// its writer publishes, and goes back to it one round after it was read.  No published word can be the sentinel: positions
+// and float sums that happen to carry this NaN payload are published as the canonical NaN, integer headings are 24-bit
+// fields under a flag byte, packed counts never have their top bit set.
+constexpr unsigned kSent = 0xffffffffu;
+constexpr int kEntryNull = 1 << 29, kEntryNan = 1 << 30;   // flag byte of an entry's heading-x word: no pedestrian that moves here / NaN heading
+__device__ __forceinline__ float unsent(float v) { return __builtin_bit_cast(unsigned, v) == kSent ? __builtin_nanf("") : v; }
+__device__ __forceinline__ bool fresh(f4 v) {
+    const float a = v.x, b = v.y, c = v.z, d = v.w;   // (bit_cast straight from a vector element picks element 0 with this compiler)
+    return __builtin_bit_cast(unsigned, a) != kSent && __builtin_bit_cast(unsigned, b) != kSent && __builtin_bit_cast(unsigned, c) != kSent &&
+           __builtin_bit_cast(unsigned, d) != kSent;
+}
+__device__ __forceinline__ void load_dev(f4& v, const void* ptr) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory"); }
+__device__ __forceinline__ void land(f4& a, f4& b) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b)::"memory"); }   // the loads into a and b have returned
 // Arrive at a device-scope counter and spin (ONE lane) until it has reached `target`: the arrival is a returning atomic -- its
 // result is the first sample, the last member to arrive never polls -- and the polls that follow keep TWO loads in flight
 // half a round trip apart, so that a waiting member notices the last arrival after half a load latency on average instead
@@ -111,6 +135,7 @@ struct Team {
         alignas(16) f4 red_f;                 // the folded records (three helper waves -> everybody)
         alignas(16) i4 red_i;
         i2 seg[WPE];                          // where segment w of the exchange area lands in the tile: (offset, entries)
+        int segcnt[WPE];                      // (sentinel exchange) entries | NaN headings << 16 of segment w, counted by the wave that fetched it
         i2 totals;                            // entries of the tile, NaN headings among them
         alignas(16) float stage[1][kStageSteps][12];
     };
@@ -122,6 +147,7 @@ struct Team {
         bool owner, helper;
         unsigned round = 0;                   // barrier rounds of this launch so far
         int par_tile = 0, par_rec = 0;        // double buffering of the exchange areas
+        int set = 0, prev_set = -1;           // (sentinel exchange) slot set of the round in progress (round % 3), of the round before
         // the tile in LDS: valid for the coming step?  its size, its NaN headings, this lane's row slot in it
         bool tile_valid = false, staged = false;
         int n_cols = 0, n_nan = 0, row_slot = 0;
@@ -175,6 +201,150 @@ struct Team {
         __syncthreads();
     }
 
+#if EVAC_TEAM_SENTINEL
+    static __device__ __forceinline__ f4* xtile(const Params& p, const Ctx& c, int set) { return (f4*)p.team_tile + ((size_t)set * p.n_envs + c.env) * 1024; }
+    static __device__ __forceinline__ f4* xrec(const Params& p, const Ctx& c, int set) { return (f4*)p.team_rec + ((size_t)set * p.n_envs + c.env) * (2 * WPE); }
+
+    // EVERY lane of a ped wave publishes an entry for the step that starts from state `q` -- its slot must leave the sentinel
+    // for the readers to go on; a pedestrian that does not move is flagged (kEntryNull) and dropped by the reader, a NaN
+    // heading is flagged too (the integer conversion loses it).  The row position goes to LDS, compacted per ped wave.
+    static __device__ __forceinline__ void publish_entry(const Params& p, Ctx& c, const Ped& q, bool efv, bool row, float ux, float uy) {
+        auto& sm = c.sm;
+        const unsigned long long m_row = ballot(row);
+        c.row_slot = __builtin_amdgcn_mbcnt_hi((unsigned)(m_row >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_row, 0u));
+        const float X = q.x * kTileScale, Y = q.y * kTileScale;
+        const float hs = p.head_scale;
+        const int hx = (int)__builtin_rintf(ux * hs), hy = (int)__builtin_rintf(uy * hs);
+        const bool nanh = ux != ux || uy != uy;
+        const int fx = (hx & 0xffffff) | (efv ? (nanh ? kEntryNan : 0) : kEntryNull), fy = hy & 0xffffff;
+        wait_vmem();      // the reset of this slot (a step ago) is acknowledged before the new data goes out: see exchange()
+        store_dev(xtile(p, c, c.set) + c.wave_in_env * kWave + c.lane, f4{unsent(X), unsent(Y), __builtin_bit_cast(float, fx), __builtin_bit_cast(float, fy)});
+        if (c.lane == 0) sm.rows[c.wave] = __popcll(m_row);
+        if (row) sm.rowpos[c.wave][c.row_slot] = make_float2(X, Y);
+    }
+
+    struct Fetched {       // what a wave holds of its segment after a round
+        f4 ev;
+        bool valid;
+        int rank;
+    };
+
+    // ONE ROUND of the exchange, called by all 16 waves after this member's ped waves have issued their stores into set
+    // c.set.  There is no counter: a slot holds the sentinel until its writer publishes, so every reader polls the data
+    // itself -- TILE rounds: wave w of every member entry `lane` of segment w; RECORD rounds: two helper waves the 16 records
+    // (lane w: record w), which they fold with the DPP tree of Wave<16>::reduce (same tree, same rounding) and leave in LDS.
+    // One fabric trip after the last member's stores have landed everybody has the data (the counter protocol took three:
+    // store acknowledgement, counter, loads; tools/microbench/team_sentinel.hip: 2.2 against 2.6 us per round with balanced
+    // members, 3.4 against 4.4 with imbalanced ones).  The workgroup barrier at the top parks the helper waves without memory
+    // traffic while the member's own ped waves still compute.
+    // Re-use of the slots: after the barrier at the bottom this member has seen every member's data of round r, and a member
+    // publishes round r only after all its waves have read round r - 1 (a workgroup barrier lies between): so every writer
+    // now resets its round r - 1 slots to the sentinel.  That store is acknowledged before the writer publishes again
+    // (wait_vmem in front of every publish, a step later: free), i.e. before round r + 1's data exists, which every reader
+    // must have seen before it polls set (r - 1) % 3 again at round r + 2.  With two sets the reset would race with that poll.
+    // Bounded: 2^20 polls (about a second), then the team is lost (see team_round).
+    template <bool RECORDS>
+    static __device__ __forceinline__ Fetched exchange(const Params& p, Ctx& c, bool tile) {
+        auto& sm = c.sm;
+        __syncthreads();
+        const f4* gt = xtile(p, c, c.set) + c.wave * kWave + c.lane;
+        const int w = c.lane < WPE ? c.lane : WPE - 1;
+        const bool folds = RECORDS && (c.wave == PW || c.wave == PW + 1);
+        const f4* gr = xrec(p, c, c.set) + 2 * w + (c.wave == PW + 1 ? 1 : 0);
+        f4 ev = f4{0.0f, 0.0f, __builtin_bit_cast(float, kEntryNull), 0.0f}, rv = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        if ((tile || folds) && !sm.abort) {      // (uniform)
+            __builtin_amdgcn_s_sleep(EVAC_TEAM_D0);
+            int tries = 0;
+            for (;;) {
+                if (tile) load_dev(ev, gt);
+                if (folds) load_dev(rv, gr);
+                land(ev, rv);
+                const bool stale = (tile && !fresh(ev)) || (folds && !fresh(rv));
+                if (ballot(stale) == 0ull) break;
+                if (++tries >= (1 << 20)) {
+                    if (c.lane == 0) {
+                        sm.abort = 1;
+                        __hip_atomic_store(p.team_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped: the host reads it without a sync
+                    }
+                    ev = f4{0.0f, 0.0f, __builtin_bit_cast(float, kEntryNull), 0.0f};
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(EVAC_TEAM_DS);
+            }
+        }
+        if constexpr (RECORDS) {
+            static_assert(PW + 1 < WPE, "two helper waves fold the records");
+            if (c.wave == PW) {                 // the float sums
+                f4 rf = rv;
+#define EVAC_RED_STEP(CTRL) rf.x = dpp_add<CTRL, 0xf>(rf.x); rf.y = dpp_add<CTRL, 0xf>(rf.y); rf.z = dpp_add<CTRL, 0xf>(rf.z);
+                EVAC_RED_STEP(0x111)
+                EVAC_RED_STEP(0x112)
+                EVAC_RED_STEP(0x114)
+                EVAC_RED_STEP(0x118)
+#undef EVAC_RED_STEP
+                if (c.lane == WPE - 1) sm.red_f = rf;
+            } else if (c.wave == PW + 1) {      // the packed counts
+                i4 ri = __builtin_bit_cast(i4, rv);
+#define EVAC_RED_STEP(CTRL)                                                                                       \
+    ri.x = dpp_addi<CTRL, 0xf>(ri.x); ri.y = dpp_addi<CTRL, 0xf>(ri.y); ri.z = dpp_addi<CTRL, 0xf>(ri.z);         \
+    ri.w = dpp_addi<CTRL, 0xf>(ri.w);
+                EVAC_RED_STEP(0x111)
+                EVAC_RED_STEP(0x112)
+                EVAC_RED_STEP(0x114)
+                EVAC_RED_STEP(0x118)
+#undef EVAC_RED_STEP
+                if (c.lane == WPE - 1) sm.red_i = ri;
+            }
+        }
+        Fetched f{ev, false, 0};
+        if (tile) {                             // which entries of the segment are pedestrians that move, and where they go
+            const float ez = ev.z;
+            const int fx = __builtin_bit_cast(int, ez);
+            f.valid = (fx & kEntryNull) == 0;
+            const unsigned long long mv = ballot(f.valid);
+            f.rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mv >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mv, 0u));
+            const int nn = __popcll(ballot((fx & kEntryNan) != 0) & mv);
+            if (c.lane == 0) sm.segcnt[c.wave] = __popcll(mv) | (nn << 16);
+        }
+        __syncthreads();
+        if (c.prev_set >= 0 && !c.helper) {     // (all members have read the previous round)
+            const f4 sent = f4{__builtin_bit_cast(float, kSent), __builtin_bit_cast(float, kSent), __builtin_bit_cast(float, kSent), __builtin_bit_cast(float, kSent)};
+            store_dev(xtile(p, c, c.prev_set) + c.wave_in_env * kWave + c.lane, sent);
+            if (c.lane == 0) {
+                store_dev(xrec(p, c, c.prev_set) + 2 * c.wave_in_env, sent);
+                store_dev(xrec(p, c, c.prev_set) + 2 * c.wave_in_env + 1, sent);
+            }
+        }
+        c.prev_set = c.set;
+        c.set = c.set == 2 ? 0 : c.set + 1;
+        return f;
+    }
+
+    // after exchange(tile = true): the 16 segments' moving pedestrians -> the LDS tile, in segment order (every wave computes
+    // the prefix of the 16 counts for itself: one DPP row)
+    static __device__ __forceinline__ void place_tile(Ctx& c, const Fetched& f) {
+        auto& sm = c.sm;
+        const int cw = sm.segcnt[c.lane < WPE ? c.lane : WPE - 1];
+        const int cnt = cw & 0xffff;
+        int incl = cnt, nans = cw >> 16;
+        incl = dpp_addi<0x111, 0xf>(incl); nans = dpp_addi<0x111, 0xf>(nans);
+        incl = dpp_addi<0x112, 0xf>(incl); nans = dpp_addi<0x112, 0xf>(nans);
+        incl = dpp_addi<0x114, 0xf>(incl); nans = dpp_addi<0x114, 0xf>(nans);
+        incl = dpp_addi<0x118, 0xf>(incl); nans = dpp_addi<0x118, 0xf>(nans);
+        const int off = __builtin_amdgcn_readlane(incl - cnt, c.wave);
+        const int n_cols = __builtin_amdgcn_readlane(incl, WPE - 1), n_nan = __builtin_amdgcn_readlane(nans, WPE - 1);
+        if (f.valid) {
+            const float ez = f.ev.z, ew = f.ev.w;
+            const int hx = (__builtin_bit_cast(int, ez) << 8) >> 8, hy = (__builtin_bit_cast(int, ew) << 8) >> 8;   // (flag byte off, sign back)
+            sm.tile[off + f.rank] = f4{f.ev.x, f.ev.y, __builtin_bit_cast(float, hx), __builtin_bit_cast(float, hy)};
+        }
+        if (threadIdx.x < kPad) sm.tile[n_cols + threadIdx.x] = f4{__builtin_inff(), 0.0f, 0.0f, 0.0f};
+        c.n_cols = n_cols;
+        c.n_nan = n_nan;
+        c.tile_valid = true;
+        __syncthreads();
+    }
+#else
     // A pedestrian's tile entry for the step that starts from state `q` goes to its wave's segment of the exchange area
     // (compacted inside the wave: no barrier), the wave's count with it; the row position to LDS.
     static __device__ __forceinline__ void publish_entry(const Params& p, Ctx& c, const Ped& q, bool efv, bool row, float ux, float uy) {
@@ -235,6 +405,8 @@ struct Team {
         c.tile_valid = true;
     }
 
+#endif
+
     // step_env, after the move and the classifier: the next step's entry, from a copy of the post-step state
     static __device__ __forceinline__ void stage_next(const Params& p, Ctx& c, const Ped& q, bool work) {
         Ped n = q;
@@ -244,6 +416,39 @@ struct Team {
         c.staged = true;
     }
 
+#if EVAC_TEAM_SENTINEL
+    template <bool GUARD, class C>
+    static __device__ __forceinline__ void reduce(const Params& p, C& c, Sums& s, const unsigned long long (&pred)[8]) {
+        wave_sum3(s.f0, s.f1, s.f2);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s.i[k] = mask_count(pred[k]);
+        const bool staged = c.staged;          // uniform over the team: this round also carries the next step's tile
+        c.staged = false;
+        if (!c.helper && c.lane == 0) {        // the wave's record: the same 32 bytes as a wave of Cells<16> leaves in LDS
+            f4* rec = xrec(p, c, c.set);
+            wait_vmem();                       // (the slot's reset, a step ago)
+            store_dev(rec + 2 * c.wave_in_env, f4{unsent(s.f0), unsent(s.f1), unsent(s.f2), 0.0f});
+            const i4 ri = i4{s.i[0] | (s.i[1] << 16), s.i[2] | (s.i[3] << 16), s.i[4] | (s.i[5] << 16), s.i[6] | (s.i[7] << 16)};
+            store_dev(rec + 2 * c.wave_in_env + 1, __builtin_bit_cast(f4, ri));
+        }
+        EVAC_T(c, 12);   // (sub-phase: per-pedestrian work of the ped waves, record stores)
+        const Fetched f = exchange<true>(p, c, staged);
+        EVAC_T(c, 13);   // (sub-phase: the round -- waiting for the member's ped waves, polls, folds)
+        const f4 rf = c.sm.red_f;
+        const i4 ri = c.sm.red_i;
+        EVAC_T(c, 14);
+        if (staged) place_tile(c, f);
+        EVAC_T(c, 15);   // (sub-phase: LDS tile of the next step)
+        s.f0 = rf.x;
+        s.f1 = rf.y;
+        s.f2 = rf.z;
+        const int a = ri.x, b = ri.y, d = ri.z, g = ri.w;
+        s.i[0] = a & 0xffff; s.i[1] = a >> 16;
+        s.i[2] = b & 0xffff; s.i[3] = b >> 16;
+        s.i[4] = d & 0xffff; s.i[5] = d >> 16;
+        s.i[6] = g & 0xffff; s.i[7] = g >> 16;
+    }
+#else
     template <bool GUARD, class C>
     static __device__ __forceinline__ void reduce(const Params& p, C& c, Sums& s, const unsigned long long (&pred)[8]) {
         wave_sum3(s.f0, s.f1, s.f2);
@@ -338,6 +543,7 @@ struct Team {
         s.i[4] = d & 0xffff; s.i[5] = d >> 16;
         s.i[6] = g & 0xffff; s.i[7] = g >> 16;
     }
+#endif
     template <class C>
     static __device__ __forceinline__ void exit_publish(C&, bool, float, float) {}
     template <class C>
@@ -348,9 +554,13 @@ struct Team {
         auto& sm = c.sm;
         if (!c.tile_valid) {      // first step of a launch, or the step after an autoreset: the exchange on its own (uniform over the team)
             if (!c.helper) publish_entry(p, c, q, efv, row, ux, uy);
+#if EVAC_TEAM_SENTINEL
+            place_tile(c, exchange<false>(p, c, true));
+#else
             team_round(p, c);
             gather_tile(p, c);
             __syncthreads();
+#endif
         }
         c.tile_valid = false;     // consumed: the step's reduction brings the next one
         EVAC_T(c, 2);   // exchange (only when the tile was not delivered by the previous step)

@@ -298,9 +298,10 @@ class BatchedEvacuationEnv:
         """Name of the kernel instantiation behind ``step`` ("step") or ``rollout`` ("rollout")."""
         return self.lib.evac_kernel_variant(self._h, 1 if mode == "rollout" else 0).decode()
 
-    def rollout_launcher(self, n_steps: int, out: TDict):
-        """A zero-argument callable that enqueues ``rollout(n_steps, out=out)`` (RandomAgent actions) on the
-        current stream with all ctypes arguments prepared once: for loops that launch the same shape many times."""
+    def rollout_launcher(self, n_steps: int, out: TDict, stream=None):
+        """A zero-argument callable that enqueues ``rollout(n_steps, out=out)`` (RandomAgent actions) with all ctypes
+        arguments prepared once: for loops that launch the same shape many times.  On the stream that is current at
+        each call, or always on ``stream`` (a torch stream) if one is given -- which saves the lookup, ~1.5 us per call."""
         T, E, D = int(n_steps), self.num_envs, self.obs_dim
         slab = self._check_tensor(out["slab"], (T, E, D + 3), torch.float32, "slab")
         stats = out.get("episode_stats")
@@ -309,6 +310,14 @@ class BatchedEvacuationEnv:
         fn, h = self.lib.evac_rollout, self._h
         a_slab, a_stats, dev = _ptr(slab), _ptr(stats), self.device
         cur = torch.cuda.current_stream
+        if stream is not None:
+            a_stream = C.c_void_p(stream.cuda_stream)
+
+            def launch_on_stream():
+                rc = fn(h, T, None, None, a_slab, a_stats, 0, None, None, a_stream)
+                if rc != 0:
+                    _lib.check(rc, h)
+            return launch_on_stream
 
         def launch():
             rc = fn(h, T, None, None, a_slab, a_stats, 0, None, None, C.c_void_p(cur(dev).cuda_stream))

@@ -17,7 +17,7 @@ constexpr int SEG = 128;   // entries per workgroup
 
 template <int K, int BLOCK, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_team(f4* buf /*[2][teams][K*SEG]*/, unsigned* counters, int teams, int rounds, int same_xcd,
-                                              unsigned* errors, unsigned long long* cycles) {
+                                              unsigned* errors, unsigned long long* cycles, int skew = 0, int gap = 0) {
     __shared__ f4 tile[K * SEG];
     int team, k;
     if (same_xcd) {            // b = j * 8 + xcd; team t lives on xcd t % 8, its k-th member is j = (t / 8) * K + k
@@ -33,6 +33,8 @@ __global__ __launch_bounds__(BLOCK) void k_team(f4* buf /*[2][teams][K*SEG]*/, u
     unsigned bad = 0;
     unsigned long long t0 = 0, t_pub = 0, t_wait = 0, t_gather = 0;
     for (int r = 0; r < rounds; ++r) {
+        for (int g = 0; g < gap; g += 64) __builtin_amdgcn_s_sleep(1);
+        for (int g = 0; g < ((k + r) % K) * skew; g += 64) __builtin_amdgcn_s_sleep(1);   // imbalance between the members, rotating
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
         f4* seg = buf + ((size_t)(r & 1) * teams + team) * (K * SEG);
         if (threadIdx.x < SEG) {
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(BLOCK) void k_team(f4* buf /*[2][teams][K*SEG]*/, u
 }
 
 template <int K, int BLOCK, int MODE>
-int run(int teams, int same_xcd, int rounds = 2000) {
+int run(int teams, int same_xcd, int rounds = 2000, int skew = 0, int gap = 0) {
     f4* buf; unsigned* ctr; unsigned* err; unsigned long long* cyc;
     CHECK(hipMalloc(&buf, sizeof(f4) * 2 * teams * K * SEG));
     CHECK(hipMalloc(&ctr, sizeof(unsigned) * teams * 32));
@@ -119,15 +121,15 @@ int run(int teams, int same_xcd, int rounds = 2000) {
         CHECK(hipMemset(ctr, 0, sizeof(unsigned) * teams * 32)); CHECK(hipMemset(err, 0, 4)); CHECK(hipMemset(cyc, 0, 24));
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL((k_team<K, BLOCK, MODE>), dim3(teams * K), dim3(BLOCK), 0, 0, buf, ctr, teams, rounds, same_xcd, err, cyc);
+        hipLaunchKernelGGL((k_team<K, BLOCK, MODE>), dim3(teams * K), dim3(BLOCK), 0, 0, buf, ctr, teams, rounds, same_xcd, err, cyc, skew, gap);
         CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
         unsigned h_err; unsigned long long h_cyc[3];
         CHECK(hipMemcpy(&h_err, err, 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(h_cyc, cyc, 24, hipMemcpyDeviceToHost));
         const double n = (double)teams * K * rounds;
         if (pass == 1)
-            printf("mode %d K=%d block=%4d teams=%3d %-9s: %6.2f us per round | cycles per round: publish %5.0f, wait %5.0f, gather %5.0f | errors %u\n", MODE, K, BLOCK, teams,
-                   same_xcd ? "one XCD" : "spread", ms * 1e3 / rounds, h_cyc[0] / n, h_cyc[1] / n, h_cyc[2] / n, h_err);
+            printf("mode %d K=%d block=%4d teams=%3d %-9s skew %4d gap %4d: %6.2f us per round | cycles per round: publish %5.0f, wait %5.0f, gather %5.0f | errors %u\n", MODE, K, BLOCK, teams,
+                   same_xcd ? "one XCD" : "spread", skew, gap, ms * 1e3 / rounds, h_cyc[0] / n, h_cyc[1] / n, h_cyc[2] / n, h_err);
     }
     CHECK(hipFree(buf)); CHECK(hipFree(ctr)); CHECK(hipFree(err)); CHECK(hipFree(cyc));
     return 0;
@@ -141,6 +143,7 @@ int main() {
     run<8, 1024, 1>(32, 1); run<8, 1024, 1>(32, 0);
     run<8, 1024, 2>(32, 1); run<8, 1024, 2>(32, 0);
     run<4, 1024, 2>(32, 1); run<2, 1024, 2>(32, 1);
+    run<8, 1024, 2>(32, 1, 2000, 0, 2048); run<8, 1024, 2>(32, 1, 2000, 128, 2048); run<8, 1024, 2>(32, 1, 2000, 512, 2048);   // with a step's worth of work between the rounds and imbalance
     // mode 3: everything through the XCD's own L2 (valid only for teams on ONE XCD: the "spread" line must show errors)
     run<8, 1024, 3>(32, 1); run<8, 1024, 3>(32, 0, 20);
     run<4, 1024, 3>(32, 1); run<2, 1024, 3>(32, 1);

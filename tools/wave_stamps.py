@@ -1,0 +1,28 @@
+"""Per-phase cycles of each of the 16 waves of workgroup 0 in ONE rollout launch (diagnostic build: hipcc ... -DEVAC_STAMP
+-DEVAC_STAMP_WAVES -o tools/ablate_libs/libevac_wavestamps.so, loaded through EVAC_LIB).  With the load schedule workgroup 0
+carries the heaviest envs of the batch in its waves 0..3: this is the heavy wave's own breakdown -- the chain that ends the
+launch -- next to the light waves'.  GPU box."""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import evacuation_amd as ea
+from evacuation_amd import _lib
+lib = _lib.load()
+E, T = 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 100
+env = ea.BatchedEvacuationEnv(ea.EnvConfig(number_of_pedestrians=60, is_new_exiting_reward=True), ea.EnvWrappersConfig(positions="grav"), num_envs=E, seed=1)
+env.reset()
+names = ["action+noise", "leader+pre-pair", "tile write", "pair loop", "head/move", "classify+reduce", "reward/flags", "reset/obs/stores"]
+buf = (C.c_ulonglong * 256)()
+out = env.rollout(T)
+done = T
+for target in (0, 600, 1200, 1800):
+    while done + T <= target:
+        env.rollout(T, out=out); done += T
+    env.rollout(T, out=out); done += T; torch.cuda.synchronize()
+    lib.evac_debug_wave_stamps(buf)
+    a = np.array(buf[:], dtype=np.float64).reshape(16, 16)
+    print(f"== steps {done - T}..{done} of the episode; cycles per step per wave of workgroup 0 (lifetime {a[:, 9].max() * 0.01:.1f} us max)")
+    print("   wave  total  " + "  ".join(f"{n:>16s}" for n in names) + "   sub 12..15")
+    for w in range(16):
+        print(f"   {w:4d} {a[w, :8].sum() / T:6.0f}  " + "  ".join(f"{a[w, k] / T:16.0f}" for k in range(8)) + "   " + " ".join(f"{a[w, k] / T:.0f}" for k in range(12, 16))
+              + f"   clock {a[w, 8] / max(a[w, 9], 1) * 100:.0f} MHz")
