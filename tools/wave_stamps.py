@@ -8,8 +8,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import evacuation_amd as ea
 from evacuation_amd import _lib
 lib = _lib.load()
-E, T = 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 100
-env = ea.BatchedEvacuationEnv(ea.EnvConfig(number_of_pedestrians=60, is_new_exiting_reward=True), ea.EnvWrappersConfig(positions="grav"), num_envs=E, seed=1)
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+N, E = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (60, 4096)
+env = ea.BatchedEvacuationEnv(ea.EnvConfig(number_of_pedestrians=N, is_new_exiting_reward=True), ea.EnvWrappersConfig(positions="grav"), num_envs=E, seed=1)
+print(env.kernel_variant("rollout"))
 env.reset()
 names = ["action+noise", "leader+pre-pair", "tile write", "pair loop", "head/move", "classify+reduce", "reward/flags", "reset/obs/stores"]
 buf = (C.c_ulonglong * 256)()
