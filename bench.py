@@ -65,6 +65,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy peak)
 VALU_ISSUE_PEAK = 39.3e12       # lane-ops/s at one wave64 VALU instruction per 4 cycles per SIMD: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
+VALU_PIPE_PEAK = 78.6e12        # ... per 2 cycles: what a SIMD's vector pipe takes from >= 4 issuing waves (MI355X_MICROARCH.md; tools/microbench/valu_rates.hip)
 EPISODE = 2000                  # max_timesteps of the synthetic workload
 
 WORKLOADS = {
@@ -633,13 +634,17 @@ def main(argv=None):
                          "valu_issue_frac": (valu_insts * 64.0 * E * inner / kernel_s / VALU_ISSUE_PEAK) if valu_insts else None,
                          "valu_wave_insts_per_env_step": valu_insts,
                          "valu_issue_peak_lane_ops_per_s": VALU_ISSUE_PEAK,
+                         "valu_pipe_frac": (valu_insts * 64.0 * E * inner / kernel_s / VALU_PIPE_PEAK) if valu_insts else None,
+                         "valu_pipe_peak_lane_ops_per_s": VALU_PIPE_PEAK,
                          "hbm_traffic_frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          "note": "achieved = algorithmic bytes / launch time (task contract): an EQUIVALENT-bandwidth figure, the state "
                                  "stays in registers between the steps of a launch and the counter-measured HBM traffic (traffic, "
                                  "hbm_traffic_frac) is a few per cent of it; the resource that binds is the VALU: valu_issue_frac = "
                                  "SQ_INSTS_VALU per env-step (rocprofv3 --pmc, profiles/traffic.json) x 64 lanes x env-steps per launch / "
                                  "kernel time against 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 39.3e12 lane-ops/s (one wave64 VALU "
-                                 "instruction per 4 cycles per SIMD)"},
+                                 "instruction per 4 cycles per SIMD: about what ONE wave per SIMD can issue); valu_pipe_frac = the same "
+                                 "against 78.6e12 (one per 2 cycles: the vector pipe's own rate, reached only with four or more waves of "
+                                 "a SIMD issuing -- a packed-f32 instruction takes 4 of those cycles and counts as one here)"},
             "step_api": step_api,
         }
         out["cpu_baseline"] = cpu_base
