@@ -33,10 +33,12 @@ chunk's compute; with one launch per block (the driver's --steps 20) block b the
 gathers block b-1's observations (the warm-up primes the pipeline, so every timed block carries exactly one
 gather per launch and drains it before t1).  `--gather-schedule split`: a block's K steps go out as two K/2
 launches and each half is gathered as soon as it is computed, all inside the block (the first half's gather
-runs under the second half, the second half's is exposed).  `--gather direct` replaces RCCL's kernel by
-copy-engine peer writes over hipIpc-mapped buffers (no CU is taken from the rollout workgroups that occupy all
-of them; evacuation_amd/distributed.py DirectGather); a collective that fails is a hard error -- an N-GPU
-`value` is never printed without the gather traffic unless --no-gather was given.
+runs under the second half, the second half's is exposed).  RCCL's all-gather is the default; two forms without a
+library collective write straight into the peers' hipIpc-mapped buffers: `--gather peer` (ONE hand-written kernel,
+evac_peer_gather, storing the observation columns to all peers at once over xGMI; built to fit beside the rollout
+workgroups, which hold every CU) and `--gather direct` (copy-engine writes, one peer after another; no CU at all).
+A collective that fails is a hard error -- an N-GPU `value` is never printed without the gather traffic unless
+--no-gather was given.
 
 `roofline` follows the task contract: ALGORITHMIC bytes per launch (32N + 38 + 4D per
 env-step, times the env-steps of one launch) divided by the mean duration of the timed launches, measured
@@ -91,9 +93,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-api", action="store_true", help="skip the one-launch-per-step side measurement")
     ap.add_argument("--no-gather", action="store_true", help="skip the all-gather of the outputs (N>1)")
-    ap.add_argument("--gather", default="obs", choices=["obs", "slab", "direct"],
+    ap.add_argument("--gather", default="obs", choices=["obs", "slab", "direct", "peer"],
                     help="what the ranks all-gather per chunk and how: the observation batch (north_star) or the whole packed "
-                         "record through RCCL, or the observation batch by copy-engine peer writes (direct: no CU-resident collective)")
+                         "record through RCCL; or the observation batch written into the peers' hipIpc-mapped buffers by one "
+                         "peer-store kernel (peer) or by copy-engine writes (direct) -- no library collective")
     ap.add_argument("--gather-schedule", default="pipelined", choices=["pipelined", "split"],
                     help="pipelined: the gather of chunk j-1 runs under the compute of chunk j (double-buffered, across blocks); "
                          "split: a one-launch block goes out as two K/2 launches, each gathered inside the block")
@@ -345,7 +348,7 @@ def main(argv=None):
             raise SystemExit(f"bench.py: {dist.get_world_size()} ranks joined, --gpus {args.gpus} requested")
 
     import evacuation_amd as ea
-    from evacuation_amd.distributed import DirectGather, ShardedEvacuationEnv, all_gather_envs, pack_outputs
+    from evacuation_amd.distributed import DirectGather, PeerStoreGather, ShardedEvacuationEnv, all_gather_envs, pack_outputs
 
     cfg = ea.EnvConfig(number_of_pedestrians=n_ped, is_new_exiting_reward=True, is_new_followers_reward=True,
                        intrinsic_reward_coef=0.0, max_timesteps=EPISODE)       # SURVEY.md 8(d) synthetic inputs
@@ -377,10 +380,12 @@ def main(argv=None):
             b["launch"] = loc.rollout_launcher(t, b, stream=compute)   # pre-bound ctypes call: no per-launch Python argument work
             if gather_rollout:
                 b["gathered"] = torch.empty((world, t, E, GW), dtype=torch.float32, device=device)
-                if args.gather != "slab":
+                if args.gather in ("obs", "direct"):
                     b["gsrc"] = torch.empty((t, E, GW), dtype=torch.float32, device=device)
                 if args.gather == "direct":
                     b["direct"] = DirectGather(b["gsrc"], b["gathered"])     # peers' `gathered` buffers mapped through hipIpc
+                if args.gather == "peer":
+                    b["peer"] = PeerStoreGather(b["slab"], D, b["gathered"])  # ... and written by one kernel, columns picked on the way
             chunks[key] = b
         return b
 
@@ -405,6 +410,8 @@ def main(argv=None):
             comm.wait_event(ready)
             if args.gather == "slab":
                 all_gather_envs(b["slab"], out=b["gathered"])
+            elif args.gather == "peer":
+                b["peer"].issue(comm)                         # one launch: the observation columns to every peer
             else:                                             # the observation columns, copied out on the comm stream
                 b["gsrc"].copy_(b["slab"][..., :D])
                 if args.gather == "direct":
@@ -443,6 +450,8 @@ def main(argv=None):
             if args.gather == "direct":
                 b0["direct"].issue(torch.cuda.current_stream())
                 b0["direct"].self_test()
+            elif args.gather == "peer":
+                b0["peer"].self_test()
             else:
                 all_gather_envs(b0["slab"] if args.gather == "slab" else b0["gsrc"], out=b0["gathered"])
             torch.cuda.synchronize()
@@ -598,7 +607,8 @@ def main(argv=None):
         else:
             coll = "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + ", host-staged: testing aid"
             what = {"obs": f"observation batch ({coll})", "slab": f"[obs|reward|flags] records ({coll})",
-                    "direct": "observation batch (copy-engine peer writes over hipIpc, no CU-resident collective kernel)"}[args.gather]
+                    "direct": "observation batch (copy-engine peer writes over hipIpc, no CU-resident collective kernel)",
+                    "peer": "observation batch (one peer-store kernel, evac_peer_gather, into hipIpc-mapped buffers; no library collective)"}[args.gather]
             how = ("issued after the NEXT chunk's launch, inside the timed block (double-buffered; block b carries block b-1's gather)"
                    if lag == 1 else "each chunk gathered as soon as it is computed, inside its block")
             gather_desc = f", all-gather of the {what} per {inner}-step chunk on a side stream, {how}"

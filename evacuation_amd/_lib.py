@@ -15,7 +15,7 @@ POS = {"abs": 0, "rel": 1, "grav": 2}
 STAT = {"no": 0, "ohe": 1, "cat": 2}
 TYPE = {"Dict": 0, "Box": 1}
 MAX_PEDESTRIANS = 1024
-VERSION = 130
+VERSION = 131
 EPISODE_STATS_WORDS = 10       # evac_episode_stats_t: 8 floats + 2 int32
 
 
@@ -57,6 +57,7 @@ SIGNATURES = {
     "evac_reschedule": (C.c_int, [_P, _P]),
     "evac_team_error": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "evac_team_clear_error": (C.c_int, [_P]),
+    "evac_peer_gather": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "evac_reset": (C.c_int, [_P, _P, _P, _P, _P]),
     "evac_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     "evac_rollout": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libevac.so")
 SOURCES = [os.path.join(CSRC, "evac_api.hip")]
-DEPENDS = SOURCES + [os.path.join(CSRC, f) for f in ("evac_common.h", "evac_families.h", "evac_device.h", "evac_subwave.h", "evac_team.h")] + [
+DEPENDS = SOURCES + [os.path.join(CSRC, f) for f in ("evac_common.h", "evac_families.h", "evac_device.h", "evac_subwave.h", "evac_team.h", "evac_gather.h")] + [
     os.path.join(os.path.dirname(HERE), "include", "evac.h")]
 ARCH = "gfx950"
 # -ffp-contract=off: fused multiply-adds are written explicitly in the kernels, so the f32 arithmetic

@@ -13,6 +13,7 @@
 #include "evac_device.h"
 #include "evac_subwave.h"
 #include "evac_team.h"
+#include "evac_gather.h"
 
 namespace {
 
@@ -476,6 +477,33 @@ int evac_reschedule(evac_handle_t h, void* stream) {
                        h->cu_wide4 ? 4 : 16, h->cu_wide4 ? 4 : 1);
     h->sched_age = 0;
     return check_launch(h, "evac_reschedule");
+}
+
+int evac_peer_gather(const float* src, int64_t rows, int32_t row_words, int32_t take_words, float* const* peer_dst, int32_t world,
+                     int32_t my_rank, int32_t wgs_per_peer, void* stream) {
+    if (!src || !peer_dst || rows <= 0 || row_words <= 0 || take_words <= 0 || take_words > row_words || world < 1 ||
+        world > evac::kMaxPeers || my_rank < 0 || my_rank >= world)
+        return EVAC_ERR_INVALID_ARGUMENT;
+    if (rows * (int64_t)take_words >= (int64_t)1 << 31) return EVAC_ERR_INVALID_ARGUMENT;      // (32-bit element indices)
+    evac::PeerPtrs pp{};
+    for (int r = 0; r < world; ++r) {
+        if (!peer_dst[r]) return EVAC_ERR_INVALID_ARGUMENT;
+        pp.dst[r] = peer_dst[r];
+    }
+    const unsigned n = (unsigned)(rows * take_words);
+    int w = wgs_per_peer > 0 ? wgs_per_peer : 8;
+    const int need = (int)((n + 1023u) / 1024u);                 // (no more workgroups than 1024-element pieces)
+    if (w > need) w = need < 1 ? 1 : need;
+    const dim3 grid((unsigned)(w * world)), block(256);
+    hipStream_t s_ = (hipStream_t)stream;
+    if (take_words == 6)
+        hipLaunchKernelGGL((evac::k_peer_gather<6>), grid, block, 0, s_, src, n, (unsigned)row_words, 6u, pp, (int)my_rank, (int)world, n, w);
+    else if (take_words == 9)
+        hipLaunchKernelGGL((evac::k_peer_gather<9>), grid, block, 0, s_, src, n, (unsigned)row_words, 9u, pp, (int)my_rank, (int)world, n, w);
+    else
+        hipLaunchKernelGGL((evac::k_peer_gather<0>), grid, block, 0, s_, src, n, (unsigned)row_words, (unsigned)take_words, pp, (int)my_rank,
+                           (int)world, n, w);
+    return hipGetLastError() == hipSuccess ? EVAC_OK : EVAC_ERR_HIP;
 }
 
 int evac_team_error(evac_handle_t h, int32_t* out) {

@@ -100,22 +100,16 @@ class DirectGather:
     ``bench.py --gather direct``."""
 
     def __init__(self, src: torch.Tensor, gathered: torch.Tensor, group=None):
-        from torch.multiprocessing.reductions import reduce_tensor
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         assert src.is_contiguous() and gathered.is_contiguous()
         assert tuple(gathered.shape) == (self.world,) + tuple(src.shape) and gathered.dtype == src.dtype
         self.src, self.gathered = src, gathered
-        handles = [None] * self.world
-        dist.all_gather_object(handles, reduce_tensor(gathered), group=group)
-        self.peers = []
-        for r, (rebuild, rebuild_args) in enumerate(handles):
-            self.peers.append(gathered if r == self.rank else rebuild(*rebuild_args))   # rank r's `gathered`, mapped here
-        self._keep = handles
-        dist.barrier(group)              # every rank has mapped every buffer before anybody writes
+        self.peers, self._keep = _map_peer_buffers(gathered, group)      # rank r's `gathered`, mapped here
 
     def issue(self, stream=None) -> None:
-        """Enqueue the world copies on ``stream`` (default: the current stream).  The farthest peers first, own copy last."""
+        """Enqueue the world copies on ``stream`` (default: the current stream), the farthest peers first, own copy last.
+        Copies of ONE stream execute one after another (each takes its link alone); PeerStoreGather writes to all peers at once."""
         ctx = torch.cuda.stream(stream) if stream is not None else _null_context()
         with ctx:
             for k in range(1, self.world + 1):
@@ -136,6 +130,92 @@ class DirectGather:
         dist.barrier(self.group)
         if not ok:
             raise RuntimeError(f"DirectGather self-test failed on rank {self.rank}: got {got.tolist()}, expected {want.tolist()}")
+
+
+def _map_peer_buffers(gathered: torch.Tensor, group=None):
+    """Every rank's `gathered` buffer mapped into this process (hipIpc through PyTorch's CUDA-IPC tensor sharing); returns the
+    list of tensors by rank (this rank's own entry is `gathered` itself) and what must be kept alive with them."""
+    from torch.multiprocessing.reductions import reduce_tensor
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    handles = [None] * world
+    dist.all_gather_object(handles, reduce_tensor(gathered), group=group)
+    peers = [gathered if r == rank else rebuild(*rebuild_args) for r, (rebuild, rebuild_args) in enumerate(handles)]
+    dist.barrier(group)                  # every rank has mapped every buffer before anybody writes
+    return peers, handles
+
+
+class PeerStoreGather:
+    """All-gather of the observation columns of a rank-local record slab by ONE hand-written kernel that stores into every
+    peer's buffer over xGMI (``evac_peer_gather``, csrc/evac_gather.h) -- no library collective, no staging copy of the columns.
+
+    ``slab`` [..., row_words] (the rollout kernel's packed records), ``take_words`` leading columns of every record,
+    ``gathered`` [world, ..., take_words] on every rank; the buffers are mapped once (hipIpc, as DirectGather).  The kernel is
+    built to run beside a rollout launch that holds every CU (29 vector registers per lane against the 64 the rollout leaves
+    free per SIMD lane), so ``issue(stream)`` on a side stream overlaps the next chunk's compute.  The event the caller records
+    afterwards marks the end of this rank's OUTGOING stores; a consumer of ``gathered`` needs all ranks to have passed theirs.
+    ``bench.py --gather peer``."""
+
+    def __init__(self, slab: torch.Tensor, take_words: int, gathered: torch.Tensor, group=None, wgs_per_peer: int = 8):
+        import ctypes as C
+        from . import _lib
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        assert slab.is_contiguous() and gathered.is_contiguous() and slab.dtype == gathered.dtype == torch.float32
+        self.row_words, self.take = int(slab.shape[-1]), int(take_words)
+        self.rows = slab.numel() // self.row_words
+        assert tuple(gathered.shape) == (self.world,) + tuple(slab.shape[:-1]) + (self.take,), (gathered.shape, slab.shape, take_words)
+        self.slab, self.gathered, self.wgs = slab, gathered, int(wgs_per_peer)
+        self.peers, self._keep = _map_peer_buffers(gathered, group)
+        self._enable_peer_access()
+        self._lib = _lib.load()
+        self._ptrs = (C.c_void_p * self.world)(*[p.data_ptr() for p in self.peers])
+        self._src = C.c_void_p(slab.data_ptr())
+        self._C = C
+
+    def _enable_peer_access(self) -> None:
+        """The stores come from THIS device's kernel: it needs access to the devices that own the mapped buffers (best effort:
+        'already enabled' and single-device test setups are fine; a missing link shows up in self_test)."""
+        import ctypes as C
+        mine = self.slab.device.index
+        others = sorted({p.device.index for p in self.peers} - {mine})
+        if not others:
+            return
+        try:
+            hip = C.CDLL("libamdhip64.so")
+            with torch.cuda.device(mine):
+                for d in others:
+                    hip.hipDeviceEnablePeerAccess(C.c_int(d), C.c_uint(0))
+                hip.hipGetLastError()
+        except OSError:
+            pass
+
+    def issue(self, stream=None) -> None:
+        st = stream if stream is not None else torch.cuda.current_stream(self.slab.device)
+        rc = self._lib.evac_peer_gather(self._src, self.rows, self.row_words, self.take, self._ptrs, self.world, self.rank, self.wgs,
+                                        self._C.c_void_p(st.cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"evac_peer_gather failed with status {rc}")
+
+    def self_test(self) -> None:
+        """Every rank fills its slab with a rank- and position-coded pattern, gathers, and checks every slice it received."""
+        keep = self.slab.clone()
+        flat = self.slab.view(-1, self.row_words)
+        base = torch.arange(flat.numel(), dtype=torch.float32, device=self.slab.device).view_as(flat) % 4093.0
+        flat.copy_(base + 5000.0 * (self.rank + 1))
+        dist.barrier(self.group)
+        self.issue()
+        torch.cuda.synchronize(self.slab.device)
+        dist.barrier(self.group)
+        got = self.gathered.view(self.world, -1, self.take)
+        ok = True
+        for r in range(self.world):
+            want = base[:, : self.take] + 5000.0 * (r + 1)
+            ok = ok and bool(torch.equal(got[r], want))
+        self.slab.copy_(keep)
+        torch.cuda.synchronize(self.slab.device)
+        dist.barrier(self.group)
+        if not ok:
+            raise RuntimeError(f"PeerStoreGather self-test failed on rank {self.rank}")
 
 
 class _null_context:

@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define EVAC_VERSION 130          /* 0.1.3 */
+#define EVAC_VERSION 131          /* 0.1.3 + evac_peer_gather */
 #define EVAC_MAX_PEDESTRIANS 1024 /* one workgroup (<=16 waves) per env */
 
 typedef enum evac_status {
@@ -208,6 +208,18 @@ int evac_bind_workspace(evac_handle_t h, void* workspace_or_null, int64_t bytes)
 int evac_reschedule(evac_handle_t h, void* stream);
 int evac_team_error(evac_handle_t h, int32_t* out);
 int evac_team_clear_error(evac_handle_t h);
+
+/* The all-gather of the returned observation batch across the ranks of an env-sharded run (BASELINE.json north_star; the
+ * reference steps all envs in one process, src/agents/rpo_agent.py:123-126, and has no analogue) as PEER STORES over xGMI,
+ * without a library collective: columns [0, take_words) of this rank's record slab src[rows][row_words] -- the rollout's
+ * packed [obs | reward | terminated | truncated] records; take_words = obs_dim picks the observation -- are written to
+ * slice my_rank of every rank's buffer peer_dst[r] = [world][rows][take_words] (r = my_rank: the local buffer; the others:
+ * the peers' buffers mapped into this process, e.g. through hipIpcOpenMemHandle).  One launch on `stream`, all peers at once,
+ * wgs_per_peer workgroups of 256 threads each (0: 8); compiled to fit beside a running rollout kernel (evac_gather.h).  A
+ * consumer of a buffer needs every rank's launch to have completed (a rendezvous of the ranks).  No handle: any device
+ * pointers.  EVAC_ERR_INVALID_ARGUMENT: NULL pointers, world > 16, rows * take_words >= 2^31. */
+int evac_peer_gather(const float* src, int64_t rows, int32_t row_words, int32_t take_words, float* const* peer_dst, int32_t world,
+                     int32_t my_rank, int32_t wgs_per_peer, void* stream);
 
 /* State exchange in the reference's own shapes (needed for parity tests, checkpoints):
  * pos/dir float [E][N][2], status uint8 [E][N], agent_pos/agent_dir float [E][2], now int32 [E]. */

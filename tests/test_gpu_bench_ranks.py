@@ -29,7 +29,7 @@ def _run(extra, timeout=600):
     return lines[0]
 
 
-@pytest.mark.parametrize("extra", [[], ["--gather-schedule", "split"], ["--gather", "slab"], ["--gather", "direct"]])
+@pytest.mark.parametrize("extra", [[], ["--gather-schedule", "split"], ["--gather", "slab"], ["--gather", "direct"], ["--gather", "peer"]])
 def test_two_ranks_on_one_gpu(extra):
     d = _run(extra)
     assert d["n_gpus"] == 2 and d["config"]["ranks_joined"] == 2 and d["config"]["total_envs"] == 1024
