@@ -338,22 +338,18 @@ struct Wave {
 #pragma unroll
                     for (int k = 0; k < B; k += 2) pair2_accumulate(XI2, YI2, t[k], t[k + 1], r2b2, sx2, sy2);
                 }
-                // the remainder (4, 8 or 12 columns: n8 is a multiple of 4) in ONE batch -- one LDS round trip, not one per group of 4
-                // (the heaviest envs, 57..60 moving pedestrians, have 12 left: their wave ends the launch)
-                const int rem = n8 - j;
-                if (rem == 12) {
-                    f4 t[12];
-#pragma unroll
-                    for (int k = 0; k < 12; ++k) t[k] = tile[j + k];
-#pragma unroll
-                    for (int k = 0; k < 12; k += 2) pair2_accumulate(XI2, YI2, t[k], t[k + 1], r2b2, sx2, sy2);
-                } else if (rem == 8) {
+                // the remainder (4, 8 or 12 columns: n8 is a multiple of 4) in at most two batches, 8 + 4 -- two LDS round trips,
+                // not one per group of 4 (the heaviest envs, 57..60 moving pedestrians, have 12 left: their wave ends the
+                // launch; a 12-column batch would be one trip, but costs the generic kernel two spilled registers)
+                if (n8 - j >= 8) {
                     f4 t[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) t[k] = tile[j + k];
 #pragma unroll
                     for (int k = 0; k < 8; k += 2) pair2_accumulate(XI2, YI2, t[k], t[k + 1], r2b2, sx2, sy2);
-                } else if (rem == 4) {
+                    j += 8;
+                }
+                if (j < n8) {
                     f4 t[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
