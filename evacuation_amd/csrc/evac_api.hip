@@ -757,6 +757,13 @@ int evac_debug_step_times(unsigned long long* out2048) {
 }
 #endif
 #ifdef EVAC_STAMP_WAVES
+int evac_debug_stamp_block(int block, unsigned long long* slowest) {      // set the reporting workgroup; read and clear the slowest-workgroup word
+    unsigned long long z = 0;
+    if (slowest && hipMemcpyFromSymbol(slowest, HIP_SYMBOL(g_slowest), 8) != hipSuccess) return EVAC_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_slowest), &z, 8) != hipSuccess) return EVAC_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_block), &block, 4) != hipSuccess) return EVAC_ERR_HIP;
+    return EVAC_OK;
+}
 int evac_debug_wave_stamps(unsigned long long* out256) {
     if (hipMemcpyFromSymbol(out256, HIP_SYMBOL(g_wave_stamps), 256 * sizeof(unsigned long long)) != hipSuccess) return EVAC_ERR_HIP;
     return EVAC_OK;

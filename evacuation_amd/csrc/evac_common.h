@@ -36,6 +36,8 @@ __device__ unsigned long long g_step_times[16][128];
 __device__ unsigned long long g_stamps[16];
 #ifdef EVAC_STAMP_WAVES
 __device__ unsigned long long g_wave_stamps[16][16];
+__device__ int g_stamp_block;                 // the workgroup whose waves report (tools/wave_stamps.py sets it to the slowest one of a first pass)
+__device__ unsigned long long g_slowest;      // max over workgroups of (lifetime of wave 0 << 20 | workgroup)
 #endif
 struct StampState {
     unsigned long long acc[16] = {};

@@ -685,7 +685,8 @@ __device__ __forceinline__ void rollout_body(
     bool stamp_me = w.lane == 0;
     if constexpr (F::kHelpers) stamp_me = stamp_me && !w.helper;   // team kernels: the critical path runs through the ped waves
 #ifdef EVAC_STAMP_WAVES   // per wave of workgroup 0, plain stores: the heaviest wave's own phase breakdown (tools/wave_stamps.py)
-    if (w.lane == 0 && blockIdx.x == 0 && threadIdx.x < 1024) {
+    if (w.lane == 0 && threadIdx.x == 0) atomicMax(&g_slowest, ((rt1_ - rt0_) << 20) | (unsigned long long)blockIdx.x);
+    if (w.lane == 0 && (int)blockIdx.x == g_stamp_block && threadIdx.x < 1024) {
         for (int k = 0; k < 16; ++k) g_wave_stamps[threadIdx.x >> 6][k] = w.stamp.acc[k];
         g_wave_stamps[threadIdx.x >> 6][8] = w.stamp.last - ck0_;
         g_wave_stamps[threadIdx.x >> 6][9] = rt1_ - rt0_;
