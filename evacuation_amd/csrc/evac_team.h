@@ -47,6 +47,9 @@
 #ifndef EVAC_TEAM_SENTINEL
 #define EVAC_TEAM_SENTINEL 1   // 0: the exchange of rounds 2-3 (store, wait, counter, spin, load) -- A/B builds; same bits
 #endif
+#ifndef EVAC_TEAM_FEW_ROWS
+#define EVAC_TEAM_FEW_ROWS 64   // needed rows of a member up to which its sweep is transposed (A/B at C5: 32 the same, 96 / 128 12-15 % slower)
+#endif
 #ifndef EVAC_TEAM_D0
 #define EVAC_TEAM_D0 8      // s_sleep units (64 cycles) between the member's own publish and its first poll
 #endif
@@ -123,7 +126,7 @@ struct Team {
     static constexpr int P = 1024 / K;                   // pedestrians per member
     static constexpr int PW = P / kWave;                 // ped waves per member
     static constexpr int kPad = 8;
-    static constexpr int kFewRows = 64;                  // needed rows of a member up to which the transposed sweep is used (neighbour_sum)
+    static constexpr int kFewRows = EVAC_TEAM_FEW_ROWS;                  // needed rows of a member up to which the transposed sweep is used (neighbour_sum)
     static constexpr const char* kName = K == 8 ? "8 CUs/env, all pairs over the team's tile" : (K == 4 ? "4 CUs/env, all pairs over the team's tile" : "2 CUs/env, all pairs over the team's tile");
 
     struct Smem {
