@@ -68,7 +68,7 @@ struct evac_handle {
     bool cu_wide;       // rollouts of one-wave envs in CU-wide workgroups (the batch fills every CU with 16 envs)
     bool cu_wide4;      // the same for four-wave envs (4 envs per CU-wide workgroup)
     bool default_cfg;   // the configuration the specialised rollout kernels assume (k_rollout_default_config)
-    int team_k;         // rollouts of 513..1024-pedestrian envs by teams of 2 / 4 / 8 workgroups per env (0: one workgroup per env)
+    int team_k;         // rollouts of 513..1024-pedestrian envs by teams of 2 / 4 / 8 / 16 workgroups per env (0: one workgroup per env)
     int32_t* sched;     // inside the caller's workspace (evac_bind_workspace): moving[E] | perm[E], or NULL
     int sched_age;      // env steps rolled out since the schedule was last rebuilt (< 0: never built)
     bool team_bound;    // the workspace holds the teams' exchange areas
@@ -161,7 +161,7 @@ const void* team_kernel(const evac_handle* h) {
 #define EVAC_TEAM_FN(K_)                                                                                                          \
     (dflt ? (grav ? (const void*)evac::k_rollout_default_config<evac::Team<K_>, true> : (const void*)evac::k_rollout_default_config<evac::Team<K_>, false>) \
           : (grav ? (const void*)evac::k_rollout<evac::Team<K_>, true> : (const void*)evac::k_rollout<evac::Team<K_>, false>))
-    return h->team_k == 8 ? EVAC_TEAM_FN(8) : (h->team_k == 4 ? EVAC_TEAM_FN(4) : EVAC_TEAM_FN(2));
+    return h->team_k == 16 ? EVAC_TEAM_FN(16) : (h->team_k == 8 ? EVAC_TEAM_FN(8) : (h->team_k == 4 ? EVAC_TEAM_FN(4) : EVAC_TEAM_FN(2)));
 #undef EVAC_TEAM_FN
 }
 unsigned team_grid(const evac_handle* h) {
@@ -321,7 +321,7 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         h->sched = nullptr;
         h->sched_age = -1;
         // teams: as many CUs per env as the batch leaves free -- all members must be resident together (one 1024-thread
-        // workgroup per CU), teams are laid out in rows of 8 (one per XCD).  EVAC_TEAM=0 disables, 2 / 4 / 8 forces a size.
+        // workgroup per CU), teams are laid out in rows of 8 (one per XCD).  EVAC_TEAM=0 disables, 2 / 4 / 8 / 16 forces a size.
         h->team_k = 0;
         h->team_bound = false;
         h->team_fit = -1;
@@ -333,7 +333,7 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
             const char* tm = std::getenv("EVAC_TEAM");
             const int want = tm ? std::atoi(tm) : -1;
             const int rows = (num_envs + 7) / 8 * 8;
-            for (int k = 8; k >= 2; k >>= 1)
+            for (int k = 16; k >= 2; k >>= 1)
                 if ((want < 0 || want == k) && rows * k <= cus) { h->team_k = k; break; }
             if (want == 0 || (want < 0 && std::getenv("EVAC_CELLS"))) h->team_k = 0;   // an A/B run of the one-workgroup families
         }
@@ -373,7 +373,7 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         if (h->cu_wide) fam = evac::Wave<1, 1024>::kName;
         if (h->cu_wide4) fam = evac::Wave<4, 1024>::kName;
         h->variant[1] = std::string("k_rollout") + kind + fam + (grav ? ", grav obs>" : ", generic obs>");
-        if (h->team_k) fam = h->team_k == 8 ? evac::Team<8>::kName : (h->team_k == 4 ? evac::Team<4>::kName : evac::Team<2>::kName);
+        if (h->team_k) fam = h->team_k == 16 ? evac::Team<16>::kName : (h->team_k == 8 ? evac::Team<8>::kName : (h->team_k == 4 ? evac::Team<4>::kName : evac::Team<2>::kName));
         h->variant[2] = std::string("k_rollout") + kind + fam + (grav ? ", grav obs>" : ", generic obs>");
     }
     *out = h;

@@ -1,5 +1,5 @@
 // Device code of libevac, part 4: the TEAM family -- one env of 513..1024 pedestrians spread over K workgroups on K
-// compute units (K = 2, 4 or 8), for batches that would otherwise leave most of the chip idle (BASELINE config 5 runs 32
+// compute units (K = 2, 4, 8 or 16), for batches that would otherwise leave most of the chip idle (BASELINE config 5 runs 32
 // envs of 1024 pedestrians per GPU: with one workgroup per env 224 of 256 CUs have nothing to do, and mid-episode, when the
 // crowd has flocked into one corner of the room, the neighbour sum of ONE env is ~350 k true pairs -- tools/row_lengths.py).
 //
@@ -119,7 +119,7 @@ __device__ __forceinline__ bool arrive_and_spin(unsigned* ctr, unsigned target) 
 template <int K_>
 struct Team {
     static constexpr int K = K_;
-    static_assert(K == 2 || K == 4 || K == 8, "a team has 2, 4 or 8 members");
+    static_assert(K == 2 || K == 4 || K == 8 || K == 16, "a team has 2, 4, 8 or 16 members");
     static constexpr int WPE = 16;                       // waves per workgroup = ped waves per team
     static constexpr bool kEnvUniform = true, kPace = false, kHelpers = true, kExitLane = false, kPipelined = true, kEnvBarrier = false;
     static constexpr int kBlock = 1024, kThreadsPerEnv = 1024, kEnvsPerBlock = 1;
@@ -127,7 +127,7 @@ struct Team {
     static constexpr int PW = P / kWave;                 // ped waves per member
     static constexpr int kPad = 8;
     static constexpr int kFewRows = EVAC_TEAM_FEW_ROWS;                  // needed rows of a member up to which the transposed sweep is used (neighbour_sum)
-    static constexpr const char* kName = K == 8 ? "8 CUs/env, all pairs over the team's tile" : (K == 4 ? "4 CUs/env, all pairs over the team's tile" : "2 CUs/env, all pairs over the team's tile");
+    static constexpr const char* kName = K == 16 ? "16 CUs/env, all pairs over the team's tile" : (K == 8 ? "8 CUs/env, all pairs over the team's tile" : (K == 4 ? "4 CUs/env, all pairs over the team's tile" : "2 CUs/env, all pairs over the team's tile"));
 
     struct Smem {
         f4 tile[1024 + kPad];                 // the team's moving pedestrians: (X, Y, heading x, heading y as integers)
@@ -605,8 +605,23 @@ struct Team {
             const int jbeg = __builtin_amdgcn_readfirstlane(c.wave * per * 4);
             const int jend = __builtin_amdgcn_readfirstlane(min((c.wave + 1) * per, groups) * 4);
             const f4* __restrict__ tile = sm.tile;
+            if constexpr (PW == 1) {       // teams of 16: one ped wave per member, one row per lane
+                if (sm.rows[0] != 0) {
+                    const float2 rr = sm.rowpos[0][c.lane];
+                    int ax = 0, ay = 0;
+                    for (int j = jbeg; j < jend; j += 4) {
+                        f4 t[4];
 #pragma unroll
-            for (int pw = 0; pw < PW; pw += 2) {
+                        for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) pair_accumulate_int(rr.x, rr.y, t[k], kRPed2Big, ax, ay);
+                    }
+                    lds_add(&sm.acc[0][c.lane][0], ax);
+                    lds_add(&sm.acc[0][c.lane][1], ay);
+                }
+            }
+#pragma unroll
+            for (int pw = 0; pw + 1 < PW; pw += 2) {
                 const int na = sm.rows[pw], nb = sm.rows[pw + 1];
                 if (na + nb == 0) continue;                                    // uniform
                 const float2 ra = sm.rowpos[pw][c.lane], rb = sm.rowpos[pw + 1][c.lane];   // slots beyond the counts hold stale rows: computed, never read

@@ -19,7 +19,7 @@
  * kernels also for N <= 32 (default: 4 envs per wave for N <= 16, 2 for N <= 32; same results, see
  * tests/test_gpu_parity.py::test_subwave_kernels_match_one_wave_per_env); EVAC_CELLS=1 / 0 forces the cell-list
  * kernels on (for every N > 64) / off (default: N > 512; the all-pairs kernels give the same neighbour sets); EVAC_CU_WIDE=1 / 0
- * forces / forbids the CU-wide rollout workgroups of one-wave envs (default: batches of >= 16 envs per CU); EVAC_TEAM=0 / 2 / 4 / 8
+ * forces / forbids the CU-wide rollout workgroups of one-wave envs (default: batches of >= 16 envs per CU); EVAC_TEAM=0 / 2 / 4 / 8 / 16
  * forbids / forces the team rollout kernels of rooms of more than 512 pedestrians (default: as many CUs per env as the batch leaves
  * free; not under EVAC_CELLS); all of them give bit-identical results.
  * EVAC_SPECIALIZE=0 keeps handles of the reference's default configuration (enslaving_degree 1, |noise_coef| <= 0.4, alpha 3 gravity
@@ -189,7 +189,7 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions_or_null,
  *   - the rollout schedule of large batches of one-wave envs (>= 16 envs per CU): moving[E] | perm[E] int32 -- every launch
  *     leaves the pedestrians still moving of each env in moving[] and, every 50 to 200 env steps, the envs are re-dealt to the
  *     SIMDs by that load;
- *   - the exchange areas of the team kernels (513..1024 pedestrians, few envs: 2 / 4 / 8 workgroups per env).
+ *   - the exchange areas of the team kernels (513..1024 pedestrians, few envs: 2 / 4 / 8 / 16 workgroups per env).
  * Performance devices only: results are bit-identical with and without the workspace.  NULL unbinds.
  *
  * Team rollouts need every workgroup of their grid resident at once (the members of a team wait for each other).  evac_rollout

@@ -37,6 +37,8 @@ def _make(ea, cfg, wrap, E, seed, team):
     (600, 16, 4, dict(positions="abs", statuses="cat", type="Dict"), 1.0),    # members without pedestrians (600 < 1024)
     (1024, 16, 2, dict(positions="rel", statuses="no", type="Box"), 1.0),
     (777, 40, 4, dict(positions="grav", alpha=3), 0.1),
+    (1024, 16, 16, dict(positions="rel", statuses="ohe", type="Box"), 1.0),   # teams of 16 (batches of <= 16 envs per GPU): one ped wave per member
+    (700, 9, 16, dict(positions="grav", alpha=3), 0.5),                       # ... members without pedestrians, idle team slots, follower rows
 ])
 def test_team_rollout_equals_one_workgroup_per_env(ea, n, E, team, wrap_kw, ens):
     import torch
@@ -65,7 +67,7 @@ def test_team_rollout_equals_one_workgroup_per_env(ea, n, E, team, wrap_kw, ens)
     ref.close(); tm.close()
 
 
-@pytest.mark.parametrize("n,E,team,ens", [(1024, 8, 8, 1.0), (1024, 8, 2, 1.0), (900, 8, 4, 1.0), (1024, 4, 8, 0.9)])
+@pytest.mark.parametrize("n,E,team,ens", [(1024, 8, 8, 1.0), (1024, 8, 2, 1.0), (900, 8, 4, 1.0), (1024, 4, 8, 0.9), (1024, 8, 16, 1.0)])
 def test_team_rollout_late_in_an_episode(ea, n, E, team, ens):
     """Late in an episode a member has few rows to evaluate (only its VISCEK pedestrians under enslaving_degree 1) and the
     pair sweep runs transposed -- rows dealt to the waves, lanes over the columns (Team::neighbour_sum); with
