@@ -176,15 +176,18 @@ def test_cu_wide_four_wave_rollout_vs_oracle(ea):
     assert peds >= 0.3 * all_peds and scalars >= 0.8 * 24 * 20, (peds, all_peds, scalars)
 
 
-def test_team_default_config_rollout_vs_oracle(ea):
-    """BASELINE config 5's kernel: N = 1024, 8 CUs per env, rel + ohe Box observation, 8 envs x 10 free-running steps.  At
+@pytest.mark.parametrize("team", ["8", "16"])
+def test_team_default_config_rollout_vs_oracle(ea, team):
+    """BASELINE config 5's kernel: N = 1024, 8 CUs per env (what a 32-env shard gets; forced here, a batch of 8 envs would take
+    16) and the 16-CU form, rel + ohe Box observation, 8 envs x 10 free-running steps.  At
     N = 1024 half a million pair distances per step make near-ties common and their effect spreads through the crowd one
     interaction radius per step, so the comparison is per pedestrian (oracle_episode): every pedestrian row of the observation
     and of the final state that no tie can have reached."""
     p = O.OracleParams(number_of_pedestrians=1024, is_new_exiting_reward=True, max_timesteps=2000)
     wrap = ea.EnvWrappersConfig(positions="rel", statuses="ohe", type="Box")
-    peds, all_peds, scalars = check_against_oracle(ea, p, wrap, E=8, T=10, seed=0x5EED0005, offset=64,
-                                                   expect_variant=("k_rollout_default_config", "8 CUs/env"))
+    with _Env(EVAC_TEAM=team):
+        peds, all_peds, scalars = check_against_oracle(ea, p, wrap, E=8, T=10, seed=0x5EED0005, offset=64,
+                                                       expect_variant=("k_rollout_default_config", f"<{team} CUs/env"))
     assert peds >= 0.5 * all_peds and scalars >= 40, (peds, all_peds, scalars)
 
 
