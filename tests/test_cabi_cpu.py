@@ -166,7 +166,7 @@ def test_kernel_resource_budgets():
         if "Wave<4, 1024>" in name:        # the CU-wide form of the four-wave envs: a few spilled scalars at most
             assert k["private_segment_fixed_size"] <= 16, (name, k)
     assert sum("Cells<" in n and "k_rollout<" in n for n in names) == 8      # 4 sizes x 2 observation faces
-    assert sum("Team<" in n and "k_rollout<" in n for n in names) == 6       # 3 team sizes x 2 observation faces
+    assert sum("Team<" in n and "k_rollout<" in n for n in names) == 8       # 4 team sizes x 2 observation faces
     for fam in ("Wave<1, 1024>", "Wave<4, 1024>"):                           # generic + default-configuration faces, 2 observation faces each
         assert sum(fam in n and "k_rollout<" in n for n in names) == 2 and sum(fam in n and "k_rollout_default_config<" in n for n in names) == 2
     assert sum("k_rollout_default_config" in n for n in names) >= 30 and sum("k_step_default_config" in n for n in names) >= 20
