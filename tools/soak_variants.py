@@ -25,6 +25,8 @@ def make(cfg, wrap, E, **env):
 ok = True
 for name, n, E, wrap_kw, T in (("C5 teams of 8 CUs", 1024, 32, dict(positions="rel", statuses="ohe", type="Box"), 100),
                                ("C5 teams of 4 CUs", 1024, 64, dict(positions="grav", alpha=3), 50),
+                               ("teams of 16 CUs", 1024, 16, dict(positions="rel", statuses="ohe", type="Box"), 100),
+                               ("teams of 2 CUs (N = 700)", 700, 128, dict(positions="grav", alpha=3), 100),
                                ("C3 CU-wide", 256, 1024, dict(positions="grav", alpha=3), 100),
                                ("C2 CU-wide + schedule", 60, 4096, dict(positions="grav", alpha=3), 100),
                                ("C2 CU-wide, 20-step launches", 60, 4096, dict(positions="grav", alpha=3), 20)):
