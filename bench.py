@@ -566,6 +566,17 @@ def main(argv=None):
         dt = time.perf_counter() - t1
         step_api = {"env_steps_per_s": E * n_api / dt, "us_per_step": dt / n_api * 1e6,
                     "note": "one evac_step launch per step from Python/ctypes, single GPU, no gather"}
+        go = loc.step_launcher(step_actions, stream=torch.cuda.current_stream())     # the same step with its arguments bound once
+        for _ in range(50):
+            go()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_api):
+            go()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        step_api["launcher_us_per_step"] = dt / n_api * 1e6
+        step_api["launcher_env_steps_per_s"] = E * n_api / dt
         try:    # the same step captured once into a hipGraph and replayed (what a graph-captured trainer loop pays)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())

@@ -77,6 +77,43 @@ def test_step_writes_the_trainers_storage_directly(ea):
     a.close(); b.close()
 
 
+def test_step_launchers_equal_step(ea):
+    """step_launcher: one pre-bound call per row of the trainer's storage (no per-call argument work) == step(out_*=), with
+    autoreset rows, final observations and episode records included; a launcher re-used with its action tensor re-filled."""
+    import torch
+    n, E, T = 60, 48, 14
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=6, is_new_exiting_reward=True)
+    wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
+    a = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=5)
+    b = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=5)
+    D = a.obs_dim
+    obs = torch.zeros((T + 1, E, D), device=a.device)
+    rew = torch.zeros((T, E), device=a.device)
+    term = torch.zeros((T, E), dtype=torch.uint8, device=a.device)
+    trunc = torch.zeros((T, E), dtype=torch.uint8, device=a.device)
+    acts = torch.rand((T, E, 2), device=a.device) * 2 - 1
+    a.reset(); b.reset()
+    go = [a.step_launcher(acts[t], out_obs=obs[t + 1], out_reward=rew[t], out_terminated=term[t], out_truncated=trunc[t]) for t in range(T)]
+    for t in range(T):
+        go[t]()
+        ob, rb, teb, trb, info = b.step(acts[t])
+        assert torch.equal(obs[t + 1].view(torch.int32), ob.view(torch.int32)) and torch.equal(rew[t].view(torch.int32), rb.view(torch.int32))
+        assert torch.equal(term[t], teb) and torch.equal(trunc[t], trb)
+        assert torch.equal(a.final_obs.view(torch.int32), b.final_obs.view(torch.int32))
+        assert torch.equal(a.final_stats.view(torch.int32), b.final_stats.view(torch.int32))
+    assert trunc[5].all() and trunc[11].all()
+    act = torch.zeros((E, 2), device=a.device)
+    one = a.step_launcher(act)                                # the env's own output tensors, one action tensor re-filled in place
+    for t in range(3):
+        act.copy_(acts[t])
+        one()
+        ob, rb, _, _, _ = b.step(acts[t])
+        assert torch.equal(a.obs.view(torch.int32), ob.view(torch.int32)) and torch.equal(a.reward.view(torch.int32), rb.view(torch.int32))
+    with pytest.raises(ValueError):
+        a.step_launcher(acts[0].double())
+    a.close(); b.close()
+
+
 def test_normalized_env_accepts_destinations(ea):
     import torch
     E, T = 16, 6
