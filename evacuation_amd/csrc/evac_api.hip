@@ -422,7 +422,7 @@ int evac_bind_state(evac_handle_t h, float* ped, uint8_t* status, float* agent, 
 
 namespace {
 struct WorkspaceLayout {
-    size_t sched, stats, team_err, team_ctr, team_cnt, team_rec, team_tile, team_xchg_end, total;
+    size_t sched, stats, team_rec, team_tile, team_xchg_end, total;
 };
 WorkspaceLayout workspace_layout(const evac_handle* h) {
     const size_t E = (size_t)h->p.n_envs;
@@ -432,9 +432,6 @@ WorkspaceLayout workspace_layout(const evac_handle* h) {
     w.sched = o; o = up(o + 2 * E * sizeof(int32_t));
     w.stats = o; o = up(o + 64);
     if (h->team_k) {
-        w.team_err = o; o = up(o + 128);
-        w.team_ctr = o; o = up(o + E * 128);
-        w.team_cnt = o; o = up(o + 2 * E * 64);
         w.team_rec = o; o = up(o + 3 * E * 32 * 16);          // (three slot sets: evac_team.h, exchange)
         w.team_tile = o; o = up(o + 3 * E * 1024 * 16);
         w.team_xchg_end = o;
@@ -458,9 +455,7 @@ int evac_bind_workspace(evac_handle_t h, void* workspace, int64_t bytes) {
     char* base = (char*)workspace;
     h->sched = (int32_t*)(base + w.sched);
     if (h->team_k) {
-        h->p.team_err = h->team_flag_dev;           // (the workspace keeps its 128-byte slot: older layouts stay valid)
-        h->p.team_ctr = (unsigned*)(base + w.team_ctr);
-        h->p.team_cnt = base + w.team_cnt;
+        h->p.team_err = h->team_flag_dev;           // (host-mapped memory of the handle, not part of the workspace)
         h->p.team_rec = base + w.team_rec;
         h->p.team_tile = base + w.team_tile;
         h->team_xchg_bytes = w.team_xchg_end - w.team_rec;
@@ -587,21 +582,15 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
         EVAC_DISPATCH(h, k_rollout_diag, stream, h->p, (int)n_steps, (const float2*)actions, (float2*)actions_out, slab_out,
                       final_stats, (int)capture_envs, capture, noise);
     else if (h->team_k && h->team_bound && team_grid_fits(h)) {
-        // 513..1024 pedestrians, few envs: K workgroups (CUs) per env (evac_team.h).  The teams' barrier counters start
-        // every launch at zero; workgroup b = j * 8 + xcd carries team (j / K) * 8 + xcd.  All members of a team spin on its
+        // 513..1024 pedestrians, few envs: K workgroups (CUs) per env (evac_team.h).  Workgroup b = j * 8 + xcd carries team (j / K) * 8 + xcd.  All members of a team spin on its
         // counter, so the whole grid must be resident at once: checked by team_grid_fits (occupancy x CUs >= workgroups; a grid
         // that does not fit runs the one-workgroup-per-env kernels below).  A foreign kernel on another stream (the sharded
         // env's all-gather) can delay a member, not starve it -- it ends, the member starts, and the bounded waits (~1 s) outlast
         // it: tests/test_gpu_team.py keeps a second stream busy throughout.  EVAC_TEAM_COOP=1 launches cooperatively instead
         // (the runtime then guarantees co-residency); it costs 3-4 % of the C5 shard's throughput and is not the default.
         hipStream_t s_ = (hipStream_t)stream;
-        const int E = h->p.n_envs;
-#if EVAC_TEAM_SENTINEL
         // every slot of the exchange area starts a launch holding the sentinel (the last two rounds of the previous launch left data)
         if (hipMemsetAsync(h->p.team_rec, 0xff, h->team_xchg_bytes, s_) != hipSuccess) return fail(h, EVAC_ERR_HIP, "evac_rollout: hipMemsetAsync failed");
-#else
-        if (hipMemsetAsync(h->p.team_ctr, 0, (size_t)E * 128, s_) != hipSuccess) return fail(h, EVAC_ERR_HIP, "evac_rollout: hipMemsetAsync failed");
-#endif
         const dim3 grid(team_grid(h)), block(1024);
         int n_steps_ = (int)n_steps;
         const float2* actions_ = (const float2*)actions;

@@ -108,10 +108,11 @@ struct Params {
     float4* agent;
     int4* clock;
     float4* acc;
-    // exchange areas of the team kernels (evac_team.h), inside the caller's workspace: tile [2][E][1024] x 16 B,
-    // cnt [2][E][8] x 8 B, rec [2][E][32] x 16 B, ctr [E][32] x 4 B (zeroed by the host before every launch), err [32] x 4 B
-    void *team_tile, *team_cnt, *team_rec;
-    unsigned *team_ctr, *team_err;
+    // exchange areas of the team kernels (evac_team.h, exchange()), inside the caller's workspace: three slot sets of
+    // rec [3][E][32] x 16 B and tile [3][E][1024] x 16 B, contiguous, reset to the sentinel (0xff bytes) by the host in front of
+    // every team launch; team_err: the handle's host-mapped error word
+    void *team_tile, *team_rec;
+    unsigned* team_err;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -119,11 +120,9 @@ struct Params {
 // against the Random123 known-answer vectors.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
-#ifndef EVAC_NO_KEY_BARRIER
     // Keep the ten round keys from being hoisted out of the caller's loop as 20 live SGPRs (the step loop is
     // already over the scalar-register budget); recomputing them is 20 s_add per call.
     asm volatile("" : "+s"(k0), "+s"(k1));
-#endif
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         // one 32x32->64 multiply (v_mad_u64_u32) per product instead of a v_mul_hi_u32 / v_mul_lo_u32 pair
@@ -159,36 +158,14 @@ __device__ __forceinline__ int dpp_addi(int v) {
 // Sums over the 64 lanes, results wave-uniform (SGPRs).  row_shr 1/2/4/8 leave each row's total in its lane 15;
 // row_bcast:15 / row_bcast:31 fold the rows into lane 63 (the rocPRIM gfx9 scheme), ~2.5x cheaper than six
 // ds_bpermute butterflies (tools/microbench/valu_rates.hip).
-// Three sums at once, the three DPP chains interleaved step by step: a DPP source written by the previous
-// VALU instruction costs wait states (the compiler pads a single chain with s_nop); with three independent
-// chains in lock-step the hazard is covered by real work.
+// Three DPP chains interleaved step by step (the sub-wave families' group sums): a DPP source written by the previous VALU
+// instruction costs wait states; with three independent chains in lock-step the hazard is covered by real work.
 #define EVAC_DPP3(CTRL, MASK) a = dpp_add<CTRL, MASK>(a); b = dpp_add<CTRL, MASK>(b); c = dpp_add<CTRL, MASK>(c);
 template <int LANE>
 __device__ __forceinline__ float readlane_const(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), LANE));
 }
-// The two row_bcast steps with a partial row mask: written through update_dpp the compiler emits
-// v_mov 0 / v_mov_dpp / v_add for each (the masked-off rows must add 0); as v_add_f32_dpp on the accumulator itself the
-// masked-off rows simply keep their value -- one instruction per step.  The three chains are interleaved so that every
-// DPP source was written at least two instructions earlier (the DPP read-after-VALU-write wait states); the leading
-// s_nop covers the compiler's last row_shr step, the trailing one the readers that follow.
-__device__ __forceinline__ void dpp_bcast_fold3(float& a, float& b, float& c) {
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(a), "+v"(b), "+v"(c));
-}
-#ifndef EVAC_SUM3_PERMLANE
-#define EVAC_SUM3_PERMLANE 1      // 0: the three interleaved DPP chains of rounds 1-2 (A/B builds)
-#endif
 __device__ __forceinline__ void wave_sum3(float& a, float& b, float& c) {
-#if EVAC_SUM3_PERMLANE
     // gfx950's half / row swaps PACK the three sums into one register before a single DPP chain runs:
     //   v_permlane32_swap a, b : a' = [a.lo | b.lo], b' = [a.hi | b.hi]  ->  a' + b' = 32-lane partial sums [a | b]
     //   the same with (c, 0)                                             ->                                  [c | 0]
@@ -213,16 +190,6 @@ __device__ __forceinline__ void wave_sum3(float& a, float& b, float& c) {
     a = readlane_const<15>(s);
     c = readlane_const<31>(s);
     b = readlane_const<47>(s);
-#else
-    EVAC_DPP3(0x111, 0xf)
-    EVAC_DPP3(0x112, 0xf)
-    EVAC_DPP3(0x114, 0xf)
-    EVAC_DPP3(0x118, 0xf)
-    dpp_bcast_fold3(a, b, c);
-    a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
-    b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 63));
-    c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), 63));
-#endif
 }
 // Two integer sums over the 64 lanes, the totals in LANE 63 (the row_shr / row_bcast scheme of wave_sum3, two chains
 // interleaved; the s_nop between the bcast steps is the DPP read-after-VALU-write wait state the third chain covers there).

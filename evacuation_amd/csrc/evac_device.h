@@ -12,21 +12,6 @@
 #include "evac_common.h"
 #include "evac_families.h"
 
-#ifndef EVAC_LAZY_HEADING
-#define EVAC_LAZY_HEADING 1   // 0: every wave evaluates the heading block and draws its noise every step (A/B builds)
-#endif
-#ifndef EVAC_PRIO_START
-#define EVAC_PRIO_START 1     // 0: every wave starts a launch at priority 0 (A/B builds)
-#endif
-#ifndef EVAC_HEAVY_FIRST
-#define EVAC_HEAVY_FIRST 1    // 0: k_schedule puts the heaviest quartile into the SIMD's youngest wave (the round-2 deal; A/B builds)
-#endif
-#ifndef EVAC_ROT7
-#define EVAC_ROT7 1           // 0: normalise, rotate, scale as three steps (the round-2 form; A/B builds)
-#endif
-#ifndef EVAC_NT_SLAB
-#define EVAC_NT_SLAB 0        // 1: the rollout's slab rows leave with non-temporal stores (A/B builds)
-#endif
 
 namespace evac {
 
@@ -137,16 +122,11 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
         // noise draw, see rollout_body): the neighbour sum it would normalise is 0 there, or the NaN of a poisoned env, and
         // 0 * (a finite heading) is the 0 that 0 * 0 is (up to the sign of a zero direction component).
         float ndx = sx, ndy = sy;
-#if EVAC_LAZY_HEADING
         if (ballot(row) != 0ull) {
             asm volatile("");                 // (a real uniform branch: keep the compiler from if-converting 25 instructions)
-#else
-        {
-#endif
             const bool zero_mean = sx == 0.0f && sy == 0.0f;
             float sn, cs;
             noise_sincos(noise, p.small_noise, sn, cs);
-#if EVAC_ROT7
             // step_size * unit mean heading, then ONE rotation: 7 instructions (scale the normaliser, two products, two
             // multiply-adds) where normalise / rotate / scale took 10
             const float ils = frsq(sx * sx + sy * sy) * p.step_size;
@@ -154,13 +134,6 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
             const float cy = zero_mean ? 0.0f : sy * ils;
             ndx = __builtin_fmaf(cx, cs, -(cy * sn));
             ndy = __builtin_fmaf(cy, cs, cx * sn);
-#else
-            const float il = frsq(sx * sx + sy * sy);
-            const float cx = zero_mean ? 1.0f : sx * il;
-            const float cy = zero_mean ? 0.0f : sy * il;
-            ndx = (cx * cs - cy * sn) * p.step_size;
-            ndy = (cy * cs + cx * sn) * p.step_size;
-#endif
         }
         q.dx = fv ? ndx : q.dx;                                             // area.py:136
         q.dy = fv ? ndy : q.dy;
@@ -293,9 +266,6 @@ __device__ __forceinline__ int simd_wave_slot() {   // slot of this wave among t
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     return (int)(hw & 3u);
 }
-#ifndef EVAC_PRIO
-#define EVAC_PRIO 1     // 0: leave the arbitration to wave age (A/B builds)
-#endif
 
 // Pace keeping of the CU-wide workgroups: a wave publishes its step counter and takes as priority the number of its
 // SIMD-mates that are ahead of it (one-wave envs: wave w runs on SIMD w % 4; four-wave envs: wave k of every env on SIMD k).
@@ -418,7 +388,7 @@ __device__ __forceinline__ void step_kernel_body(
     float nz = 0.0f;
     if (noise_in) {
         if (active) nz = noise_in[(size_t)w.env * p.n_ped + w.i];
-    } else if (!EVAC_LAZY_HEADING || ballot(needs_row(p, q.st)) != 0ull) {   // (only a lane whose row is evaluated uses its draw: step_env)
+    } else if (ballot(needs_row(p, q.st)) != 0ull) {   // (only a lane whose row is evaluated uses its draw: step_env)
         nz = philox_noise(p, gid, w.i, e.total);
     }
     StepOut o;
@@ -513,10 +483,10 @@ __device__ __forceinline__ void rollout_body(
     // (the wave's place among its SIMD-mates: recomputed where it is used rather than held in two more scalar registers)
 #define EVAC_PACE_SIMD (F::WPE == 1 ? (w.slot & 3) : (w.wave_in_env & 3))
 #define EVAC_PACE_K (F::WPE == 1 ? (w.slot >> 2) : w.slot)
-    if constexpr (EVAC_PRIO && F::kPace) {
+    if constexpr (F::kPace) {
         if (w.lane == 0) sm.progress[EVAC_PACE_SIMD * 4 + EVAC_PACE_K] = 0;
     }
-    constexpr bool kRotate = EVAC_PRIO && !F::kPace && std::is_same<F, Wave<F::WPE>>::value && F::WPE < 16;
+    constexpr bool kRotate = !F::kPace && std::is_same<F, Wave<F::WPE>>::value && F::WPE < 16;
     int prio_slot = 0;
     if constexpr (kRotate) prio_slot = simd_wave_slot();
 #ifdef EVAC_STAMP
@@ -526,21 +496,19 @@ __device__ __forceinline__ void rollout_body(
     const unsigned long long ck0_ = w.stamp.last;
 #endif
     // Start-of-launch priorities.  With a schedule (k_schedule) the SIMD's k-th wave carries an env of the k-th load quartile
-    // (EVAC_HEAVY_FIRST: the heaviest in the SIMD's OLDEST wave, so that age -- the arbiter's tie-break -- works for it too),
+    // (the heaviest in the SIMD's OLDEST wave, so that age -- the arbiter's tie-break -- works for it too),
     // and the heaviest wave of a SIMD ends the launch: it starts with the highest priority instead of earning it over the
     // first steps (pace_step's information is a step old; with equal priorities the twelve lighter waves of the CU ran their
     // first steps first and the heavy ones began 3-4 us late: tools/step_times.py).  `pace_seen` is seeded so that step 0
     // confirms that rank.
     int pace_seen = 0, pace_prio = 0;
-#if EVAC_PRIO_START
-    if constexpr (EVAC_PRIO && F::kPace && F::WPE == 1) {
+    if constexpr (F::kPace && F::WPE == 1) {
         if (perm) {
-            pace_prio = EVAC_HEAVY_FIRST ? 3 - (w.slot >> 2) : (w.slot >> 2);
+            pace_prio = 3 - (w.slot >> 2);
             set_wave_priority(pace_prio);
             pace_seen = (w.lane & 3) < pace_prio ? (1 << 30) : -1;
         }
     }
-#endif
     int staged = 0;                       // t % kStageSteps: the slot of the step in the staging block
     for (int t = 0; t < n_steps; ++t) {
 #ifdef EVAC_STEP_TIMES
@@ -563,7 +531,7 @@ __device__ __forceinline__ void rollout_body(
                 }
             }
         }
-        if constexpr (EVAC_PRIO && F::kPace) pace_step(sm, EVAC_PACE_SIMD, EVAC_PACE_K, w.lane, t, pace_seen, pace_prio);
+        if constexpr (F::kPace) pace_step(sm, EVAC_PACE_SIMD, EVAC_PACE_K, w.lane, t, pace_seen, pace_prio);
 #undef EVAC_PACE_SIMD
 #undef EVAC_PACE_K
         const int slot64 = t & 63;
@@ -593,11 +561,7 @@ __device__ __forceinline__ void rollout_body(
         bool draws = true;                      // (team kernels: waves without pedestrians draw no noise)
         if constexpr (F::kHelpers) draws = !w.helper;
         float nz = 0.0f;
-#if EVAC_LAZY_HEADING
         const bool wants_noise = ballot(needs_row(p, q.st)) != 0ull;
-#else
-        const bool wants_noise = true;
-#endif
         if (draws && wants_noise && !(EVAC_ABLATE & 4)) {
             const int group = (int)(e.total >> 2);
             if (group != noise_group) {
@@ -655,11 +619,7 @@ __device__ __forceinline__ void rollout_body(
                         if (fl_s <= staged) {
                             const float v = sm.stage[w.slot][fl_s][fl_k];
                             float* dst = &slab_out[((size_t)(t - staged + fl_s) * E + w.env) * kGravRow + fl_k];
-#if EVAC_NT_SLAB
-                            __builtin_nontemporal_store(v, dst);
-#else
                             *dst = v;
-#endif
                         }
                     }
                 }
@@ -772,7 +732,7 @@ __global__ __launch_bounds__(1024) void k_schedule(int n_envs, const int* __rest
             const int k = r / G, j = r - k * G;
             const int g = (k & 1) ? G - 1 - j : j;   // snake: quarters 0 and 2 ascending, 1 and 3 descending
             // (the heaviest quartile goes to the SIMDs' first -- oldest -- waves, see rollout_body)
-            const int kk = EVAC_HEAVY_FIRST ? 3 - k : k;
+            const int kk = 3 - k;
             slot = per_wg == 16 ? (g >> 2) * 16 + kk * 4 + (g & 3)  // workgroup g / 4, SIMD g % 4, the SIMD's kk-th wave
                                 : g * 4 + kk;                       // workgroup g, its kk-th env (its waves 4 kk .. 4 kk + 3: one per SIMD)
         }

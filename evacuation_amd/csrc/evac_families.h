@@ -24,21 +24,12 @@ namespace evac {
 // ------------------------------------------------------------------------------------------------
 // Wave<WPE>: all pairs, wave-uniform broadcast reads of a compacted LDS tile
 // ------------------------------------------------------------------------------------------------
-#ifndef EVAC_BLOCK1
-#define EVAC_BLOCK1 256
-#endif
-#ifndef EVAC_PK_ROWS
-#define EVAC_PK_ROWS 1        // 0: the multi-wave all-pairs sweeps take every row in plain arithmetic (A/B builds; same bits)
-#endif
-#ifndef EVAC_PK2
-#define EVAC_PK2 1            // 0: the one-wave loops take one column per five plain instructions (the round-2 form; A/B builds)
-#endif
 
 // BLOCK1 (WPE == 1 only): threads per workgroup.  256 = four one-wave envs per workgroup (the default); 1024 = the
 // CU-WIDE workgroup of the rollout kernel for batches that fill the chip (16 envs, one workgroup per CU, four waves per
 // SIMD): the waves that share a SIMD are then known (wave w runs on SIMD w % 4), so the host can deal the envs to SIMDs by
 // load (k_schedule) and the waves of a SIMD can keep pace with each other through LDS (rollout_body, kPace).
-template <int WPE_, int BLOCK1_ = EVAC_BLOCK1>
+template <int WPE_, int BLOCK1_ = 256>
 struct Wave {
     static constexpr int WPE = WPE_;
     static constexpr bool kEnvUniform = true;
@@ -289,7 +280,7 @@ struct Wave {
             }
             const int tid = c.wave_in_env * kWave + c.lane;
             const int idx = efv ? before : n_cols + (tid - before);             // a bijection onto [0, WPE*64)
-            if constexpr (WPE == 1 && EVAC_PK2) {
+            if constexpr (WPE == 1) {
                 // columns in PAIRS for the packed loop: pair p = idx / 2 holds (X, X', Y, Y') in tile[2p] and (ux, ux', uy, uy') in tile[2p + 1]
                 float* tf = (float*)sm.tile[par][c.slot] + (idx >> 1) * 8 + (idx & 1);
                 tf[0] = efv ? q.x * kTileScale : __builtin_inff();
@@ -327,7 +318,6 @@ struct Wave {
             constexpr int B = 16;
             int j = 0;
             if constexpr (!(EVAC_ABLATE & 1)) {
-#if EVAC_PK2
                 // two columns per packed instruction (pair2_accumulate): 3 vector instructions per column instead of 5
                 const f2 XI2 = f2{XI, XI}, YI2 = f2{YI, YI}, r2b2 = f2{r2b, r2b};
                 f2 sx2 = f2{0.0f, 0.0f}, sy2 = f2{0.0f, 0.0f};
@@ -358,22 +348,6 @@ struct Wave {
                 }
                 sx = sx2.x + sx2.y;                // even columns + odd columns
                 sy = sy2.x + sy2.y;
-#else
-                for (; j + B <= n8; j += B) {      // full batches
-                    f4 t[B];
-#pragma unroll
-                    for (int k = 0; k < B; ++k) t[k] = tile[j + k];
-#pragma unroll
-                    for (int k = 0; k < B; ++k) pair_accumulate(XI, YI, t[k], r2b, sx, sy);
-                }
-                for (; j < n8; j += 4) {           // remainder in groups of 4 (n8 is a multiple of 4)
-                    f4 t[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) pair_accumulate(XI, YI, t[k], r2b, sx, sy);
-                }
-#endif
             }
         } else {
             // this wave: up to kRows row slices (64 compacted rows each) of its group of kRows waves, column share `share`
@@ -391,7 +365,7 @@ struct Wave {
                 // R row slices per lane (slots beyond n_rows hold stale positions: computed, never read)
                 auto sweep = [&](auto r_tag) {
                     constexpr int R = decltype(r_tag)::value;
-                    constexpr int R2 = EVAC_PK_ROWS ? R / 2 : 0;          // pairs of rows taken in packed arithmetic (pair_accumulate_rows2)
+                    constexpr int R2 = R / 2;         // pairs of rows taken in packed arithmetic (pair_accumulate_rows2)
                     float X[R], Y[R], ax[R], ay[R];
                     f2 X2[R2 ? R2 : 1], Y2[R2 ? R2 : 1], ax2[R2 ? R2 : 1], ay2[R2 ? R2 : 1];
 #pragma unroll
@@ -490,14 +464,8 @@ struct Cells {
     static constexpr int kEnvsPerBlock = 1;
     static constexpr bool kPace = false, kHelpers = false, kExitLane = true, kPipelined = false, kEnvBarrier = false;
     static constexpr int kPad = 8;   // +inf entries behind the last moving pedestrian (>= entries per batch)
-#ifndef EVAC_ROW_BATCH
-#define EVAC_ROW_BATCH 8
-#endif
-    static constexpr int kRowBatch = EVAC_ROW_BATCH;   // tile entries per LDS round trip of a row
-#ifndef EVAC_TRANSPOSED_WORK
-#define EVAC_TRANSPOSED_WORK 1024
-#endif
-    static constexpr int kTransposedWork = EVAC_TRANSPOSED_WORK;   // needed rows x passes of 64 columns up to which the sweep is transposed (step 4')
+    static constexpr int kRowBatch = 8;   // tile entries per LDS round trip of a row
+    static constexpr int kTransposedWork = 1024;   // needed rows x passes of 64 columns up to which the sweep is transposed (step 4')
     static constexpr const char* kName = WPE == 2 ? "2 waves/env, cell list" : (WPE == 4 ? "4 waves/env, cell list" : (WPE == 8 ? "8 waves/env, cell list" : "16 waves/env, cell list"));
 
     struct Smem {
@@ -767,15 +735,11 @@ struct Sub {
         {
             const int before = rank(m_efv, c.gmask);
             const int idx = efv ? before : n_cols + (c.li - before);    // a bijection onto the group's G slots
-#if EVAC_PK2
             float* tf = (float*)sm.tile[c.slot] + (idx >> 1) * 8 + (idx & 1);     // columns in pairs, as in Wave<1>::neighbour_sum
             tf[0] = efv ? q.x * kTileScale : __builtin_inff();
             tf[2] = q.y * kTileScale;
             tf[4] = efv ? ux : 0.0f;
             tf[6] = efv ? uy : 0.0f;
-#else
-            sm.tile[c.slot][idx] = f4{efv ? q.x * kTileScale : __builtin_inff(), q.y * kTileScale, efv ? ux : 0.0f, efv ? uy : 0.0f};
-#endif
         }
         sync();
         sx = 0.0f;
@@ -797,7 +761,6 @@ struct Sub {
         const f4* __restrict__ tile = sm.tile[c.slot];           // per lane: its group's tile
         const float XI = q.x * kTileScale, YI = q.y * kTileScale;
         int j = 0;
-#if EVAC_PK2
         // (the same packed two-column form and the same even / odd partial sums as the one-wave-per-env loop: bit-identical dynamics)
         const f2 XI2 = f2{XI, XI}, YI2 = f2{YI, YI}, r2b2 = f2{kRPed2Big, kRPed2Big};
         f2 sx2 = f2{0.0f, 0.0f}, sy2 = f2{0.0f, 0.0f};
@@ -819,22 +782,6 @@ struct Sub {
             sx = sx2.x + sx2.y;
             sy = sy2.x + sy2.y;
         }
-#else
-        for (; j + 8 <= n4; j += 8) {
-            f4 t[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = tile[j + k];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) pair_accumulate(XI, YI, t[k], kRPed2Big, sx, sy);
-        }
-        for (; j < n4; j += 4) {
-            f4 t[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pair_accumulate(XI, YI, t[k], kRPed2Big, sx, sy);
-        }
-#endif
     }
 };
 

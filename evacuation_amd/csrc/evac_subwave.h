@@ -154,11 +154,9 @@ __device__ __forceinline__ void rollout_body_sub(typename Sub<G>::Smem& sm, cons
     bool have = false;
     float2 lane_act = make_float2(0.f, 0.f), lane_adir = make_float2(0.f, 0.f);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): keep the state loads' wait out of the loop
-    const int prio_slot = EVAC_PRIO ? simd_wave_slot() : 0;
+    const int prio_slot = simd_wave_slot();
     for (int t = 0; t < n_steps; ++t) {
-        if constexpr (EVAC_PRIO != 0) {
-            if (p.fair) set_wave_priority(t + prio_slot);   // even progress of the waves of a SIMD (evac_device.h)
-        }
+        if (p.fair) set_wave_priority(t + prio_slot);   // even progress of the waves of a SIMD (evac_device.h)
         const int slotG = t & (G - 1);
         if (slotG == 0) {                 // actions of the next G steps, one step per lane of the group
             if (actions) {

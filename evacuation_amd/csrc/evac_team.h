@@ -7,7 +7,7 @@
 // all 16 waves of the workgroup share the member's part of the pair work.  The members meet ONCE per step through global
 // memory (device-scope write-through stores and device-scope loads, no cache flush or invalidation, and NO counter: every
 // published word validates itself against a sentinel that its slot holds between uses -- exchange() below; round 2's
-// store / acknowledgement / counter / spin / load protocol is kept as EVAC_TEAM_SENTINEL=0 for A/B builds;
+// store / acknowledgement / counter / spin / load protocol is tools/experiments/r04_team_counter_exchange.patch;
 // tools/microbench/team_sentinel.hip and team_barrier.hip time both in isolation).  What travels in that round:
 //   * the step's reduction: every ped wave publishes the same 32-byte record as a wave of Cells<16> leaves in LDS; after the
 //     barrier three helper waves of every member fold the 16 records with the same DPP tree (float sums, packed counts and
@@ -41,29 +41,18 @@
 
 #include "evac_device.h"
 
-#ifndef EVAC_TEAM_PK
-#define EVAC_TEAM_PK 1      // 0: the many-rows sweep of the teams in plain arithmetic (A/B builds; same bits)
-#endif
-#ifndef EVAC_TEAM_SENTINEL
-#define EVAC_TEAM_SENTINEL 1   // 0: the exchange of rounds 2-3 (store, wait, counter, spin, load) -- A/B builds; same bits
-#endif
-#ifndef EVAC_TEAM_FEW_ROWS
-#define EVAC_TEAM_FEW_ROWS 64   // needed rows of a member up to which its sweep is transposed (A/B at C5: 32 the same, 96 / 128 12-15 % slower)
-#endif
-#ifndef EVAC_TEAM_D0
-#define EVAC_TEAM_D0 8      // s_sleep units (64 cycles) between the member's own publish and its first poll
-#endif
-#ifndef EVAC_TEAM_DS
-#define EVAC_TEAM_DS 2      // ... between two polls
-#endif
-
 namespace evac {
+
+// (measured at C5, profiles/r03_g_c5_ab_few_rows_threshold.txt and r03_g_c5_ab_sentinel_exchange.txt)
+constexpr int kTeamFewRows = 64;     // needed rows of a member up to which its sweep is transposed (32 the same, 96 / 128 12-15 % slower)
+constexpr int kTeamFirstPoll = 8;    // s_sleep units (64 cycles) between the member's own publish and its first poll (8-12 flat, 2-4 cost 2-3 %)
+constexpr int kTeamPollGap = 2;      // ... between two polls
 
 __device__ __forceinline__ void store_dev(void* ptr, f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
 __device__ __forceinline__ void store_dev_i32(void* ptr, int v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
 __device__ __forceinline__ void lds_add(int* ptr, int v) { (void)__hip_atomic_fetch_add(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// The self-validating exchange (EVAC_TEAM_SENTINEL): a slot of the exchange area holds the sentinel in all its words until
+// The self-validating exchange: a slot of the exchange area holds the sentinel in all its words until
 // its writer publishes, and goes back to it one round after it was read.  No published word can be the sentinel: positions
 // and float sums that happen to carry this NaN payload are published as the canonical NaN, integer headings are 24-bit
 // fields under a flag byte, packed counts never have their top bit set.
@@ -77,44 +66,6 @@ __device__ __forceinline__ bool fresh(f4 v) {
 }
 __device__ __forceinline__ void load_dev(f4& v, const void* ptr) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory"); }
 __device__ __forceinline__ void land(f4& a, f4& b) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b)::"memory"); }   // the loads into a and b have returned
-// Arrive at a device-scope counter and spin (ONE lane) until it has reached `target`: the arrival is a returning atomic -- its
-// result is the first sample, the last member to arrive never polls -- and the polls that follow keep TWO loads in flight
-// half a round trip apart, so that a waiting member notices the last arrival after half a load latency on average instead
-// of a whole one.  Returning atomics and loads return in issue order (vmcnt).  Bounded (2^20 rounds of two loads, a fraction of
-// a second); returns false on a timeout.  No other vector-memory operation may be outstanding on entry.
-__device__ __forceinline__ bool arrive_and_spin(unsigned* ctr, unsigned target) {
-    unsigned a, b;
-    int n;
-    asm volatile(
-        "s_mov_b32 %2, 0\n\t"
-        "global_atomic_add %0, %3, %5, off sc0\n\t"
-        "s_sleep 5\n\t"
-        "global_load_dword %1, %3, off sc1\n\t"
-        "s_waitcnt vmcnt(1)\n\t"
-        "v_add_u32 %0, 1, %0\n\t"
-        "s_branch 3f\n"
-        "1:\n\t"
-        "s_waitcnt vmcnt(1)\n"
-        "3:\n\t"
-        "v_sub_u32 %0, %0, %4\n\t"
-        "v_cmp_gt_i32 vcc, 0, %0\n\t"
-        "s_cbranch_vccz 2f\n\t"
-        "global_load_dword %0, %3, off sc1\n\t"
-        "s_waitcnt vmcnt(1)\n\t"
-        "v_sub_u32 %1, %1, %4\n\t"
-        "v_cmp_gt_i32 vcc, 0, %1\n\t"
-        "s_cbranch_vccz 2f\n\t"
-        "global_load_dword %1, %3, off sc1\n\t"
-        "s_add_u32 %2, %2, 1\n\t"
-        "s_cmp_lt_u32 %2, 0x100000\n\t"
-        "s_cbranch_scc1 1b\n"
-        "2:\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(a), "=&v"(b), "=&s"(n)
-        : "v"(ctr), "v"(target), "v"(1u)
-        : "vcc", "scc", "memory");
-    return n < 0x100000;
-}
 
 template <int K_>
 struct Team {
@@ -126,7 +77,7 @@ struct Team {
     static constexpr int P = 1024 / K;                   // pedestrians per member
     static constexpr int PW = P / kWave;                 // ped waves per member
     static constexpr int kPad = 8;
-    static constexpr int kFewRows = EVAC_TEAM_FEW_ROWS;                  // needed rows of a member up to which the transposed sweep is used (neighbour_sum)
+    static constexpr int kFewRows = kTeamFewRows;                  // needed rows of a member up to which the transposed sweep is used (neighbour_sum)
     static constexpr const char* kName = K == 16 ? "16 CUs/env, all pairs over the team's tile" : (K == 8 ? "8 CUs/env, all pairs over the team's tile" : (K == 4 ? "4 CUs/env, all pairs over the team's tile" : "2 CUs/env, all pairs over the team's tile"));
 
     struct Smem {
@@ -138,7 +89,7 @@ struct Team {
         alignas(16) f4 red_f;                 // the folded records (three helper waves -> everybody)
         alignas(16) i4 red_i;
         i2 seg[WPE];                          // where segment w of the exchange area lands in the tile: (offset, entries)
-        int segcnt[WPE];                      // (sentinel exchange) entries | NaN headings << 16 of segment w, counted by the wave that fetched it
+        int segcnt[WPE];                      // entries | NaN headings << 16 of segment w, counted by the wave that fetched it
         i2 totals;                            // entries of the tile, NaN headings among them
         alignas(16) float stage[1][kStageSteps][12];
     };
@@ -148,9 +99,7 @@ struct Team {
         Smem& sm;
         int env, slot, wave_in_env, lane, i, member, wave;
         bool owner, helper;
-        unsigned round = 0;                   // barrier rounds of this launch so far
-        int par_tile = 0, par_rec = 0;        // double buffering of the exchange areas
-        int set = 0, prev_set = -1;           // (sentinel exchange) slot set of the round in progress (round % 3), of the round before
+        int set = 0, prev_set = -1;           // slot set of the round in progress (round % 3), of the round before
         // the tile in LDS: valid for the coming step?  its size, its NaN headings, this lane's row slot in it
         bool tile_valid = false, staged = false;
         int n_cols = 0, n_nan = 0, row_slot = 0;
@@ -186,25 +135,6 @@ struct Team {
         __syncthreads();
     }
 
-    // publish -> barrier: every thread's device-scope stores are acknowledged, then the workgroup arrives at the team's
-    // counter and waits until all K members have.
-    static __device__ __forceinline__ void team_round(const Params& p, Ctx& c) {
-        wait_vmem();
-        __syncthreads();
-        c.round += 1u;
-        if (threadIdx.x == 0) {
-            unsigned* ctr = p.team_ctr + (size_t)c.env * 32;
-            if (c.sm.abort) {        // a lost team: keep counting, wait for nobody
-                __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else if (!arrive_and_spin(ctr, c.round * (unsigned)K)) {
-                c.sm.abort = 1;
-                __hip_atomic_store(p.team_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped: the host reads it without a sync
-            }
-        }
-        __syncthreads();
-    }
-
-#if EVAC_TEAM_SENTINEL
     static __device__ __forceinline__ f4* xtile(const Params& p, const Ctx& c, int set) { return (f4*)p.team_tile + ((size_t)set * p.n_envs + c.env) * 1024; }
     static __device__ __forceinline__ f4* xrec(const Params& p, const Ctx& c, int set) { return (f4*)p.team_rec + ((size_t)set * p.n_envs + c.env) * (2 * WPE); }
 
@@ -256,7 +186,7 @@ struct Team {
         const f4* gr = xrec(p, c, c.set) + 2 * w + (c.wave == PW + 1 ? 1 : 0);
         f4 ev = f4{0.0f, 0.0f, __builtin_bit_cast(float, kEntryNull), 0.0f}, rv = f4{0.0f, 0.0f, 0.0f, 0.0f};
         if ((tile || folds) && !sm.abort) {      // (uniform)
-            __builtin_amdgcn_s_sleep(EVAC_TEAM_D0);
+            __builtin_amdgcn_s_sleep(kTeamFirstPoll);
             int tries = 0;
             for (;;) {
                 if (tile) load_dev(ev, gt);
@@ -272,7 +202,7 @@ struct Team {
                     ev = f4{0.0f, 0.0f, __builtin_bit_cast(float, kEntryNull), 0.0f};
                     break;
                 }
-                __builtin_amdgcn_s_sleep(EVAC_TEAM_DS);
+                __builtin_amdgcn_s_sleep(kTeamPollGap);
             }
         }
         if constexpr (RECORDS) {
@@ -347,68 +277,6 @@ struct Team {
         c.tile_valid = true;
         __syncthreads();
     }
-#else
-    // A pedestrian's tile entry for the step that starts from state `q` goes to its wave's segment of the exchange area
-    // (compacted inside the wave: no barrier), the wave's count with it; the row position to LDS.
-    static __device__ __forceinline__ void publish_entry(const Params& p, Ctx& c, const Ped& q, bool efv, bool row, float ux, float uy) {
-        auto& sm = c.sm;
-        const int par = c.par_tile;
-        const unsigned long long m_col = ballot(efv), m_row = ballot(row);
-        const int col_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m_col >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_col, 0u));
-        c.row_slot = __builtin_amdgcn_mbcnt_hi((unsigned)(m_row >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_row, 0u));
-        f4* gtile = (f4*)p.team_tile + ((size_t)par * p.n_envs + c.env) * 1024;
-        int* gcnt = (int*)p.team_cnt + ((size_t)par * p.n_envs + c.env) * WPE;
-        const float X = q.x * kTileScale, Y = q.y * kTileScale;
-        if (efv) {
-            const float hs = p.head_scale;
-            const int hx = (int)__builtin_rintf(ux * hs), hy = (int)__builtin_rintf(uy * hs);
-            store_dev(gtile + c.wave_in_env * kWave + col_rank, f4{X, Y, __builtin_bit_cast(float, hx), __builtin_bit_cast(float, hy)});
-        }
-        const int n_nan = __popcll(ballot(ux != ux || uy != uy) & m_col);   // (conjunction on the masks)
-        if (c.lane == 0) {
-            store_dev_i32(gcnt + c.wave_in_env, __popcll(m_col) | (n_nan << 16));
-            sm.rows[c.wave] = __popcll(m_row);
-        }
-        if (row) sm.rowpos[c.wave][c.row_slot] = make_float2(X, Y);
-    }
-
-    // after the barrier: all 16 segments -> the LDS tile (thread t fetches entry t % 64 of ped wave t / 64)
-    static __device__ __forceinline__ void gather_tile(const Params& p, Ctx& c) {
-        auto& sm = c.sm;
-        const int par = c.par_tile;
-        c.par_tile = par ^ 1;
-        const f4* gtile = (const f4*)p.team_tile + ((size_t)par * p.n_envs + c.env) * 1024;
-        const int* gcnt = (const int*)p.team_cnt + ((size_t)par * p.n_envs + c.env) * WPE;
-        i4 cv[4];                            // count | NaN headings << 16 of the 16 ped waves; the loads and their wait in ONE statement
-        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
-                     "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
-                     : "=&v"(cv[0]), "=&v"(cv[1]), "=&v"(cv[2]), "=&v"(cv[3]) : "v"(gcnt) : "memory");
-        const int t = threadIdx.x, gw = t >> 6, e = t & (kWave - 1);
-        int off = 0, cnt = 0, n_cols = 0, n_nan = 0;
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int w4[4] = {cv[h].x, cv[h].y, cv[h].z, cv[h].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int k16 = 4 * h + k, ck = w4[k] & 0xffff;
-                off += k16 < gw ? ck : 0;
-                cnt = k16 == gw ? ck : cnt;
-                n_cols += ck;
-                n_nan += w4[k] >> 16;
-            }
-        }
-        if (e < cnt) {
-            f4 v;
-            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(gtile + gw * kWave + e) : "memory");
-            sm.tile[off + e] = v;
-        }
-        if (t < kPad) sm.tile[n_cols + t] = f4{__builtin_inff(), 0.0f, 0.0f, 0.0f};
-        c.n_cols = n_cols;
-        c.n_nan = n_nan;
-        c.tile_valid = true;
-    }
-
-#endif
 
     // step_env, after the move and the classifier: the next step's entry, from a copy of the post-step state
     static __device__ __forceinline__ void stage_next(const Params& p, Ctx& c, const Ped& q, bool work) {
@@ -419,7 +287,6 @@ struct Team {
         c.staged = true;
     }
 
-#if EVAC_TEAM_SENTINEL
     template <bool GUARD, class C>
     static __device__ __forceinline__ void reduce(const Params& p, C& c, Sums& s, const unsigned long long (&pred)[8]) {
         wave_sum3(s.f0, s.f1, s.f2);
@@ -451,102 +318,6 @@ struct Team {
         s.i[4] = d & 0xffff; s.i[5] = d >> 16;
         s.i[6] = g & 0xffff; s.i[7] = g >> 16;
     }
-#else
-    template <bool GUARD, class C>
-    static __device__ __forceinline__ void reduce(const Params& p, C& c, Sums& s, const unsigned long long (&pred)[8]) {
-        wave_sum3(s.f0, s.f1, s.f2);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s.i[k] = mask_count(pred[k]);
-        const int par = c.par_rec;
-        c.par_rec = par ^ 1;
-        f4* rec = (f4*)p.team_rec + ((size_t)par * p.n_envs + c.env) * (2 * WPE);
-        const bool staged = c.staged;          // uniform over the team: this round also carries the next step's tile
-        c.staged = false;
-        if (!c.helper && c.lane == 0) {
-            store_dev(rec + 2 * c.wave_in_env, f4{s.f0, s.f1, s.f2, 0.0f});
-            const i4 ri = i4{s.i[0] | (s.i[1] << 16), s.i[2] | (s.i[3] << 16), s.i[4] | (s.i[5] << 16), s.i[6] | (s.i[7] << 16)};
-            store_dev(rec + 2 * c.wave_in_env + 1, __builtin_bit_cast(f4, ri));
-        }
-        EVAC_T(c, 12);   // (sub-phase: per-pedestrian work of the ped waves / waiting for them, record stores)
-        team_round(p, c);
-        EVAC_T(c, 13);   // (sub-phase: the team barrier)
-        // ONE load phase.  Every wave reads entry `lane` of the segment of ped wave `c.wave` (wave w of every member gathers
-        // segment w; which of its 64 entries are real is known from the counts, so that load need not wait for them).  Three
-        // HELPER waves read, in the same statement, the 16 records (lane w: record w) resp. the 16 segment counts, fold them
-        // and leave the result in LDS for everybody: the float sums, the packed counts and the prefix of the segment counts are
-        // independent chains, and the ped waves -- the critical path of the step -- only fetch their tile entry.  (Every wave
-        // folding for itself costs 7 device-scope loads of the same three cache lines by 128 waves of a team: 5000 cycles of
-        // the step.)
-        static_assert(PW + 2 < WPE, "three helper waves fold the records");
-        const f4* gtile = (const f4*)p.team_tile + ((size_t)c.par_tile * p.n_envs + c.env) * 1024 + c.wave * kWave + c.lane;
-        const int w = c.lane < WPE ? c.lane : WPE - 1;
-        f4 ev;
-        if (c.wave == PW) {                 // the float sums: the fold of Wave<16>::reduce, instruction for instruction (same tree, same rounding)
-            f4 rf;
-            asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
-                         : "=&v"(rf), "=&v"(ev) : "v"(rec + 2 * w), "v"(gtile) : "memory");
-#define EVAC_RED_STEP(CTRL) rf.x = dpp_add<CTRL, 0xf>(rf.x); rf.y = dpp_add<CTRL, 0xf>(rf.y); rf.z = dpp_add<CTRL, 0xf>(rf.z);
-            EVAC_RED_STEP(0x111)
-            EVAC_RED_STEP(0x112)
-            EVAC_RED_STEP(0x114)
-            EVAC_RED_STEP(0x118)
-#undef EVAC_RED_STEP
-            if (c.lane == WPE - 1) c.sm.red_f = rf;
-        } else if (c.wave == PW + 1) {      // the packed counts
-            f4 rb;
-            asm volatile("global_load_dwordx4 %0, %2, off offset:16 sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
-                         : "=&v"(rb), "=&v"(ev) : "v"(rec + 2 * w), "v"(gtile) : "memory");
-            i4 ri = __builtin_bit_cast(i4, rb);
-#define EVAC_RED_STEP(CTRL)                                                                                       \
-    ri.x = dpp_addi<CTRL, 0xf>(ri.x); ri.y = dpp_addi<CTRL, 0xf>(ri.y); ri.z = dpp_addi<CTRL, 0xf>(ri.z);         \
-    ri.w = dpp_addi<CTRL, 0xf>(ri.w);
-            EVAC_RED_STEP(0x111)
-            EVAC_RED_STEP(0x112)
-            EVAC_RED_STEP(0x114)
-            EVAC_RED_STEP(0x118)
-#undef EVAC_RED_STEP
-            if (c.lane == WPE - 1) c.sm.red_i = ri;
-        } else if (c.wave == PW + 2) {      // where segment w lands in the tile: exclusive prefix of the 16 counts (lanes 0..15, one DPP row)
-            const int* gcnt = (const int*)p.team_cnt + ((size_t)c.par_tile * p.n_envs + c.env) * WPE + w;
-            int cw;
-            asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
-                         : "=&v"(cw), "=&v"(ev) : "v"(gcnt), "v"(gtile) : "memory");
-            const int cnt = cw & 0xffff;
-            int incl = cnt, nans = cw >> 16;
-            incl = dpp_addi<0x111, 0xf>(incl); nans = dpp_addi<0x111, 0xf>(nans);
-            incl = dpp_addi<0x112, 0xf>(incl); nans = dpp_addi<0x112, 0xf>(nans);
-            incl = dpp_addi<0x114, 0xf>(incl); nans = dpp_addi<0x114, 0xf>(nans);
-            incl = dpp_addi<0x118, 0xf>(incl); nans = dpp_addi<0x118, 0xf>(nans);
-            if (c.lane < WPE) c.sm.seg[c.lane] = i2{incl - cnt, cnt};
-            if (c.lane == WPE - 1) c.sm.totals = i2{incl, nans};
-        } else {
-            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(ev) : "v"(gtile) : "memory");
-        }
-        __syncthreads();
-        EVAC_T(c, 14);   // (sub-phase: loads of records, counts, tile entry)
-        const f4 rf = c.sm.red_f;
-        const i4 ri = c.sm.red_i;
-        if (staged) {
-            const i2 sg = c.sm.seg[c.wave], tot = c.sm.totals;
-            if (c.lane < sg.y) c.sm.tile[sg.x + c.lane] = ev;
-            if (threadIdx.x < kPad) c.sm.tile[tot.x + threadIdx.x] = f4{__builtin_inff(), 0.0f, 0.0f, 0.0f};
-            c.n_cols = tot.x;
-            c.n_nan = tot.y;
-            c.par_tile ^= 1;
-            c.tile_valid = true;
-            __syncthreads();
-        }
-        EVAC_T(c, 15);   // (sub-phase: LDS tile of the next step)
-        s.f0 = rf.x;
-        s.f1 = rf.y;
-        s.f2 = rf.z;
-        const int a = ri.x, b = ri.y, d = ri.z, g = ri.w;
-        s.i[0] = a & 0xffff; s.i[1] = a >> 16;
-        s.i[2] = b & 0xffff; s.i[3] = b >> 16;
-        s.i[4] = d & 0xffff; s.i[5] = d >> 16;
-        s.i[6] = g & 0xffff; s.i[7] = g >> 16;
-    }
-#endif
     template <class C>
     static __device__ __forceinline__ void exit_publish(C&, bool, float, float) {}
     template <class C>
@@ -557,13 +328,7 @@ struct Team {
         auto& sm = c.sm;
         if (!c.tile_valid) {      // first step of a launch, or the step after an autoreset: the exchange on its own (uniform over the team)
             if (!c.helper) publish_entry(p, c, q, efv, row, ux, uy);
-#if EVAC_TEAM_SENTINEL
             place_tile(c, exchange<false>(p, c, true));
-#else
-            team_round(p, c);
-            gather_tile(p, c);
-            __syncthreads();
-#endif
         }
         c.tile_valid = false;     // consumed: the step's reduction brings the next one
         EVAC_T(c, 2);   // exchange (only when the tile was not delivered by the previous step)
@@ -634,12 +399,7 @@ struct Team {
                         for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-#if EVAC_TEAM_PK
                             pair_accumulate_int_rows2(X2, Y2, t[k], r2b2, ax0, ay0, ax1, ay1);      // (the two weights in packed arithmetic: 10 instead of 14 instructions)
-#else
-                            pair_accumulate_int(ra.x, ra.y, t[k], kRPed2Big, ax0, ay0);
-                            pair_accumulate_int(rb.x, rb.y, t[k], kRPed2Big, ax1, ay1);
-#endif
                         }
                     }
                 } else {
