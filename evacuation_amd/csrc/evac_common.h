@@ -284,6 +284,14 @@ __device__ __forceinline__ void pair2_accumulate(f2 XI2, f2 YI2, f4 xy, f4 uv, f
     sy2 = __builtin_elementwise_fma(w, __builtin_shufflevector(uv, uv, 2, 3), sy2);
 }
 
+// x + y of a packed pair as ONE v_add_f32 on the two halves of the register pair: the empty asm hides one half from the
+// vectoriser, which otherwise moves three registers around to use v_pk_add_f32 on two such sums at once.
+__device__ __forceinline__ float hsum2(f2 v) {
+    float lo = v.x;
+    asm("" : "+v"(lo));
+    return lo + v.y;
+}
+
 // TWO ROWS of one lane against one column in packed f32 arithmetic (the multi-wave all-pairs sweeps, where a lane carries up
 // to four rows): (X, X') and (Y, Y') of the two rows against the column's t.x / t.y, broadcast into both halves by op_sel; six
 // v_pk_* instructions for two rows instead of ten plain ones, the same operations per row in the same order -- bit-identical
@@ -393,7 +401,7 @@ struct Env {
 };
 struct StepOut {
     float reward;
-    bool terminated, truncated;
+    bool terminated, truncated, done;     // done = terminated | truncated
     int n_escaped, n_exiting, n_follower, n_viscek;
     float gx, gy, ex, ey;   // gravity observation of the post-step state (GRAV kernels): ped sums, exit term * n_followers
 };

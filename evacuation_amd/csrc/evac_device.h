@@ -217,13 +217,25 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     out.n_exiting = out.n_viscek = 0;   // filled by finish_counts() when the episode ends
 
     out.terminated = term_agent || (s.i[2] == p.n_ped);   // area.py:175-178, env.py:171
+    // (the episode ends: ONE scalar condition for the callers' rare branch -- min of the pedestrians still inside and the steps
+    // left -- instead of two compares, two mask selects and an OR every step)
+    out.done = term_agent || min(p.n_ped - s.i[2], p.max_timesteps - e.now) <= 0;
     if (!work) return;                        // helper waves: the flags steer them, rewards and episode sums are the ped waves'
     float r_ped = p.init_reward;
     if constexpr (F::kEnvUniform) {
         // Real uniform branches (the empty asm keeps the compiler from if-converting them into always-executed
         // arithmetic + selects): on most steps nobody changes status and the bonus terms are skipped.
-        const int moved = ((p.flags & kFlagNewExitingReward) ? s.i[0] : 0) | ((p.flags & kFlagNewFollowersReward) ? s.i[1] : 0);
-        if (moved != 0) {
+        bool moved;
+        if constexpr (F::kThreadsPerEnv == kWave) {
+            // one wave per env: the test is taken on the ballots themselves (the reward switches as loop-invariant masks), the
+            // two popcounts move into the branch
+            unsigned long long m0 = (p.flags & kFlagNewExitingReward) ? ~0ull : 0ull, m1 = (p.flags & kFlagNewFollowersReward) ? ~0ull : 0ull;
+            asm("" : "+s"(m0), "+s"(m1));      // (opaque: two s_and_b64 on the ballots, not a select per half of each)
+            moved = ((pred[0] & m0) | (pred[1] & m1)) != 0ull;
+        } else {
+            moved = (((p.flags & kFlagNewExitingReward) ? s.i[0] : 0) | ((p.flags & kFlagNewFollowersReward) ? s.i[1] : 0)) != 0;
+        }
+        if (moved) {
             asm volatile("");
             const float tf = 1.0f - (float)e.now * p.inv_200n;              // reward.py:26
             if (p.flags & kFlagNewExitingReward) r_ped += (15.0f + 10.0f * tf) * (float)s.i[0];
@@ -269,12 +281,10 @@ __device__ __forceinline__ int simd_wave_slot() {   // slot of this wave among t
 
 // Pace keeping of the CU-wide workgroups: a wave publishes its step counter and takes as priority the number of its
 // SIMD-mates that are ahead of it (one-wave envs: wave w runs on SIMD w % 4; four-wave envs: wave k of every env on SIMD k).
-// Cost per step: one LDS write, one LDS read whose result is used a whole step later (`seen`: a hint may be a step old, and
+// Cost per step: one LDS write (all lanes, no exec mask: rollout_body), one LDS read whose result is used a whole step later (`seen`: a hint may be a step old, and
 // the wave never waits for the round trip), one compare + popcount, and the s_setprio switch only when the rank changes.
-template <class Smem>
-__device__ __forceinline__ void pace_step(Smem& sm, int simd, int k, int lane, int t, int& seen, int& prio) {   // this wave: the SIMD's k-th
-    int* mine = &sm.progress[simd * 4];
-    if (lane == 0) mine[k] = t;
+__device__ __forceinline__ void pace_step(int* slot, const int* mine, int lane, int t, int& seen, int& prio) {   // `mine`: the SIMD's four counters
+    *slot = t;                                                         // (lane 0: the wave's counter; the others: the sink)
     const unsigned ahead_mask = (unsigned)ballot(seen >= t) & 0xfu;   // lanes 0..3 hold the four counters as read one step ago
     seen = mine[lane & 3];
     const int ahead = __popc(ahead_mask) & 3;                          // (t = 0: the zero-initialised `seen` counts all four: & 3)
@@ -469,12 +479,27 @@ __device__ __forceinline__ void rollout_body(
     const uint32_t gid = p.env_id_offset + (uint32_t)w.env;
     const size_t E = (size_t)p.n_envs;
     const int row = p.obs_dim + 3;
-    uint32_t nzw[4] = {0u, 0u, 0u, 0u};       // the four noise words of Philox block `noise_group` (wave-uniform; -1: none)
+    // The four noise words of Philox block `noise_group` (-1: none), ROTATED every step so that nzw[0] is the word of the step
+    // at hand: three register moves per step where picking word `total & 3` took three scalar compare / select pairs and
+    // three v_cndmask.
+    uint32_t nzw[4] = {0u, 0u, 0u, 0u};
     int noise_group = -1;
     // RandomAgent actions and the leader directions they give (area.py:189-192) are produced 64 steps at a
     // time, one step per LANE (a per-wave scalar Philox would cost ~100 SALU instructions every step),
-    // and fetched per step with v_readlane.
+    // and fetched per step with v_readlane.  The first block is drawn HERE, under the state loads (only the env's clock
+    // word is needed for it: a scalar load); the later ones at the bottom of the step in front of theirs.
     float2 lane_act = make_float2(0.f, 0.f), lane_adir = make_float2(0.f, 0.f);
+    auto draw_actions = [&](int t_first) {
+        if (actions) {
+            if (t_first + w.lane < n_steps) lane_act = actions[(size_t)(t_first + w.lane) * E + w.env];
+        } else if constexpr (EVAC_ABLATE & 4) {
+            lane_act = make_float2(0.3f, -0.7f);
+        } else {
+            lane_act = philox_action(p, gid, e.total + (uint32_t)w.lane);   // e.total grows by exactly 1 per step
+        }
+        lane_adir = agent_direction(p, lane_act.x, lane_act.y);
+    };
+    draw_actions(0);
     // flush mapping of the staged outputs: lane l carries word l % 9 of staged step l / 9
     const int fl_s = w.lane / kGravRow, fl_k = w.lane - fl_s * kGravRow;
     // Retire the state loads HERE, or their first use inside the loop puts `s_waitcnt vmcnt(0)` -- which
@@ -483,8 +508,12 @@ __device__ __forceinline__ void rollout_body(
     // (the wave's place among its SIMD-mates: recomputed where it is used rather than held in two more scalar registers)
 #define EVAC_PACE_SIMD (F::WPE == 1 ? (w.slot & 3) : (w.wave_in_env & 3))
 #define EVAC_PACE_K (F::WPE == 1 ? (w.slot >> 2) : w.slot)
+    // (pace keeping: lane 0 publishes the wave's step counter; the other lanes store theirs to a sink row of the wave's own, so
+    // that the store needs no exec mask -- one address register, computed once, instead of a save / restore pair per step)
+    int* pace_slot = nullptr;
     if constexpr (F::kPace) {
-        if (w.lane == 0) sm.progress[EVAC_PACE_SIMD * 4 + EVAC_PACE_K] = 0;
+        pace_slot = w.lane == 0 ? &sm.progress[EVAC_PACE_SIMD * 4 + EVAC_PACE_K] : &sm.pace_sink[threadIdx.x >> 6][w.lane];
+        *pace_slot = 0;
     }
     constexpr bool kRotate = !F::kPace && std::is_same<F, Wave<F::WPE>>::value && F::WPE < 16;
     int prio_slot = 0;
@@ -509,7 +538,10 @@ __device__ __forceinline__ void rollout_body(
             pace_seen = (w.lane & 3) < pace_prio ? (1 << 30) : -1;
         }
     }
-    int staged = 0;                       // t % kStageSteps: the slot of the step in the staging block
+    // Staging block of the slab rows (GRAV kernels): the step's row goes to byte offset `stage_off`; the block is flushed after
+    // step `flush_t` (its seventh row, or the launch's last); `stage_t0` = the step its first row belongs to.
+    int stage_off = 0, stage_t0 = 0, flush_t = min(kStageSteps, n_steps) - 1;
+    constexpr int kStageRowBytes = (int)sizeof(sm.stage[0][0]);
     for (int t = 0; t < n_steps; ++t) {
 #ifdef EVAC_STEP_TIMES
         if (w.lane == 0 && t < 128 && blockIdx.x == 0 && threadIdx.x < 1024) {
@@ -531,20 +563,10 @@ __device__ __forceinline__ void rollout_body(
                 }
             }
         }
-        if constexpr (F::kPace) pace_step(sm, EVAC_PACE_SIMD, EVAC_PACE_K, w.lane, t, pace_seen, pace_prio);
+        if constexpr (F::kPace) pace_step(pace_slot, &sm.progress[EVAC_PACE_SIMD * 4], w.lane, t, pace_seen, pace_prio);
 #undef EVAC_PACE_SIMD
 #undef EVAC_PACE_K
         const int slot64 = t & 63;
-        if (slot64 == 0) {
-            if (actions) {
-                if (t + w.lane < n_steps) lane_act = actions[(size_t)(t + w.lane) * E + w.env];
-            } else if constexpr (EVAC_ABLATE & 4) {
-                lane_act = make_float2(0.3f, -0.7f);
-            } else {
-                lane_act = philox_action(p, gid, e.total + (uint32_t)w.lane);   // e.total grows by exactly 1 per step
-            }
-            lane_adir = agent_direction(p, lane_act.x, lane_act.y);
-        }
         float2 a = make_float2(0.f, 0.f), adir;
         if constexpr (DIAG) {
             a.x = readlane_f(lane_act.x, slot64);
@@ -556,8 +578,9 @@ __device__ __forceinline__ void rollout_body(
         // One Philox call serves four consecutive steps of this pedestrian: word (total & 3) of the block with counter
         // total >> 2.  The draw is LAZY: only a lane whose row is evaluated uses its noise (step_env), so a wave without such a
         // lane -- most waves late in an episode -- neither draws nor, at the next group of four steps, calls Philox at all;
-        // `noise_group` is the block the four words in registers belong to.  The word is picked by the wave-uniform index
-        // (a scalar-indexed register move), not by rotating the four registers every step.
+        // `noise_group` is the block the four words in registers belong to; they are rotated by one at the bottom of every
+        // step (drawn or not), so the step's word is nzw[0] -- and a block first drawn in the middle of its group (the launch
+        // did not start on a multiple of four, or the wave skipped its first steps) is rotated into place where it is drawn.
         bool draws = true;                      // (team kernels: waves without pedestrians draw no noise)
         if constexpr (F::kHelpers) draws = !w.helper;
         float nz = 0.0f;
@@ -569,9 +592,15 @@ __device__ __forceinline__ void rollout_body(
                 const uint4 r = philox4x32_10(make_uint4(gid, (uint32_t)w.i, e.total >> 2, kStreamNoise), p.seed_lo, p.seed_hi);
                 nzw[0] = r.x; nzw[1] = r.y; nzw[2] = r.z; nzw[3] = r.w;
                 noise_group = group;
+                for (unsigned k = e.total & 3u; k != 0u; --k) {      // (rare: see above)
+                    asm volatile("");
+                    const uint32_t f = nzw[0];
+                    nzw[0] = nzw[1]; nzw[1] = nzw[2]; nzw[2] = nzw[3]; nzw[3] = f;
+                }
             }
-            nz = u01_centred(nzw[e.total & 3u]) * p.noise_coef;
+            nz = u01_centred(nzw[0]) * p.noise_coef;
         }
+        nzw[0] = nzw[1]; nzw[1] = nzw[2]; nzw[2] = nzw[3];           // the next step's word moves up
         if constexpr (DIAG) {
             if (noise_in) nz = active ? noise_in[((size_t)t * E + w.env) * p.n_ped + w.i] : 0.0f;   // injection mode
         }
@@ -594,7 +623,11 @@ __device__ __forceinline__ void rollout_body(
             }
         }
         float o6[6] = {e.ax, e.ay, o.ex, o.ey, o.gx, o.gy};
-        if (o.terminated || o.truncated) {   // wave-/workgroup-uniform, rare
+        float f_term = 0.0f, f_trunc = 0.0f;
+        if (o.done) {                        // wave-/workgroup-uniform, rare
+            asm volatile("");                // (a real branch: the two flags are constants on the other path)
+            f_term = o.terminated ? 1.0f : 0.0f;
+            f_trunc = o.truncated ? 1.0f : 0.0f;
             if (final_stats) {
                 finish_counts<F>(p, w, q, o);
                 if (w.owner) write_stats(final_stats + (size_t)t * E + w.env, e, o);
@@ -604,26 +637,28 @@ __device__ __forceinline__ void rollout_body(
             if constexpr (GRAV) grav_observation<F>(p, w, active, q, e, o6);
         }
         float* rowp = slab_out + ((size_t)t * E + w.env) * row;
-        const float f_term = o.terminated ? 1.0f : 0.0f, f_trunc = o.truncated ? 1.0f : 0.0f;
         if constexpr (GRAV) {
             if constexpr (!(EVAC_ABLATE & 16)) {
                 if (w.owner) {
-                    float* st = sm.stage[w.slot][staged];
+                    float* st = (float*)((char*)sm.stage[w.slot][0] + stage_off);
                     *(f4*)(st + 0) = f4{o6[0], o6[1], o6[2], o6[3]};
                     *(f4*)(st + 4) = f4{o6[4], o6[5], o.reward, f_term};
                     st[8] = f_trunc;
                 }
-                if (staged == kStageSteps - 1 || t == n_steps - 1) {
+                stage_off += kStageRowBytes;
+                if (t == flush_t) {
                     if (w.wave_in_env == 0) {   // the wave that staged them: in-order LDS, no barrier needed
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        if (fl_s <= staged) {
+                        if (fl_s <= t - stage_t0) {
                             const float v = sm.stage[w.slot][fl_s][fl_k];
-                            float* dst = &slab_out[((size_t)(t - staged + fl_s) * E + w.env) * kGravRow + fl_k];
+                            float* dst = &slab_out[((size_t)(stage_t0 + fl_s) * E + w.env) * kGravRow + fl_k];
                             *dst = v;
                         }
                     }
+                    stage_off = 0;
+                    stage_t0 = t + 1;
+                    flush_t = min(t + kStageSteps, n_steps - 1);
                 }
-                staged = staged == kStageSteps - 1 ? 0 : staged + 1;
             }
         } else {
             if constexpr (!(EVAC_ABLATE & 2)) {
@@ -636,6 +671,10 @@ __device__ __forceinline__ void rollout_body(
                 rowp[p.obs_dim + 1] = f_term;
                 rowp[p.obs_dim + 2] = f_trunc;
             }
+        }
+        if (slot64 == 63) {                  // the actions of the next 64 steps
+            asm volatile("");
+            if (t + 1 < n_steps) draw_actions(t + 1);
         }
         EVAC_T(w, 7);   // autoreset check, observation epilogue, output stores
     }

@@ -54,6 +54,7 @@ struct Wave {
     // rows of kRows waves (its group: kRows pedestrians per lane) and fetches only 1/kRows of the peers; the kRows
     // partial sums of a row meet in LDS.  Same VALU work, 1/kRows of the LDS reads, one more barrier.
     static constexpr int kRows = WPE == 1 ? 1 : (WPE == 2 ? 2 : 4);
+    static constexpr int kPairs = WPE * kWave / 2;     // WPE == 1: column pairs of the packed tile (neighbour_sum)
 
     struct Smem {
         f4 tile[kTiles][kEnvsPerBlock][WPE * kWave];   // (x, y, ux, uy) of every pedestrian
@@ -68,6 +69,7 @@ struct Wave {
         // rollout outputs of up to kStageSteps steps, flushed with ONE 64-lane store (GRAV kernels)
         alignas(16) float stage[kEnvsPerBlock][kStageSteps][12];   // rows written as two 16-byte vectors + 1 word
         alignas(16) int progress[kPace ? 16 : 4];                  // kPace: step counter of every wave, [SIMD][wave of the SIMD]
+        int pace_sink[kPace ? 16 : 1][kPace ? kWave : 1];           // kPace: where lanes 1..63 of a wave store when lane 0 publishes the counter
     };
 
     struct Ctx {
@@ -281,12 +283,16 @@ struct Wave {
             const int tid = c.wave_in_env * kWave + c.lane;
             const int idx = efv ? before : n_cols + (tid - before);             // a bijection onto [0, WPE*64)
             if constexpr (WPE == 1) {
-                // columns in PAIRS for the packed loop: pair p = idx / 2 holds (X, X', Y, Y') in tile[2p] and (ux, ux', uy, uy') in tile[2p + 1]
-                float* tf = (float*)sm.tile[par][c.slot] + (idx >> 1) * 8 + (idx & 1);
+                // columns in PAIRS for the packed loop: pair p = idx / 2 holds (X, X', Y, Y') in tile[p] and (ux, ux', uy, uy') in
+                // tile[32 + p].  All position chunks first, then all heading chunks: a lane's four dwords go to dword 4 p + (idx & 1)
+                // + {0, 2} and 128 more, so the 32 lanes of a store group land on 16 chunks x 2 = all 32 write banks, two deep at
+                // most -- free for ds_write_b32 (MI355X_MICROARCH.md, LDS).  Interleaved (tile[2p], tile[2p + 1]) the same stores
+                // hit 8 banks four deep: 15.6 % of the kernel's LDS cycles were conflict cycles (profiles/r03_g_c2_driver_pmc_summary.txt).
+                float* tf = (float*)sm.tile[par][c.slot] + (idx >> 1) * 4 + (idx & 1);
                 tf[0] = efv ? q.x * kTileScale : __builtin_inff();
                 tf[2] = q.y * kTileScale;
-                tf[4] = efv ? ux : 0.0f;
-                tf[6] = efv ? uy : 0.0f;
+                tf[kPairs * 4 + 0] = efv ? ux : 0.0f;
+                tf[kPairs * 4 + 2] = efv ? uy : 0.0f;
             } else {
                 sm.tile[par][c.slot][idx] = f4{efv ? q.x * kTileScale : __builtin_inff(), q.y * kTileScale, efv ? ux : 0.0f, efv ? uy : 0.0f};
             }
@@ -316,38 +322,41 @@ struct Wave {
             const float XI = q.x * kTileScale, YI = q.y * kTileScale;
             // peers per LDS round trip: 16 (3.31 vs 3.34 us at 8, 3.49 at 4)
             constexpr int B = 16;
-            int j = 0;
             if constexpr (!(EVAC_ABLATE & 1)) {
                 // two columns per packed instruction (pair2_accumulate): 3 vector instructions per column instead of 5
                 const f2 XI2 = f2{XI, XI}, YI2 = f2{YI, YI}, r2b2 = f2{r2b, r2b};
                 f2 sx2 = f2{0.0f, 0.0f}, sy2 = f2{0.0f, 0.0f};
-                for (; j + B <= n8; j += B) {      // full batches: 16 columns = 8 pairs = 16 tile reads
-                    f4 t[B];
+                const f4* __restrict__ txy = tile;             // pair m: (X, X', Y, Y')
+                const f4* __restrict__ tuv = tile + kPairs;    //         (ux, ux', uy, uy')
+                int m = 0;                                     // pair index = column / 2
+                const int mp = n8 >> 1;
+                for (; m + B / 2 <= mp; m += B / 2) {          // full batches: 16 columns = 8 pairs = 16 tile reads
+                    f4 a[B / 2], u[B / 2];
 #pragma unroll
-                    for (int k = 0; k < B; ++k) t[k] = tile[j + k];
+                    for (int k = 0; k < B / 2; ++k) { a[k] = txy[m + k]; u[k] = tuv[m + k]; }
 #pragma unroll
-                    for (int k = 0; k < B; k += 2) pair2_accumulate(XI2, YI2, t[k], t[k + 1], r2b2, sx2, sy2);
+                    for (int k = 0; k < B / 2; ++k) pair2_accumulate(XI2, YI2, a[k], u[k], r2b2, sx2, sy2);
                 }
                 // the remainder (4, 8 or 12 columns: n8 is a multiple of 4) in at most two batches, 8 + 4 -- two LDS round trips,
                 // not one per group of 4 (the heaviest envs, 57..60 moving pedestrians, have 12 left: their wave ends the
                 // launch; a 12-column batch would be one trip, but costs the generic kernel two spilled registers)
-                if (n8 - j >= 8) {
-                    f4 t[8];
+                if (mp - m >= 4) {
+                    f4 a[4], u[4];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) t[k] = tile[j + k];
+                    for (int k = 0; k < 4; ++k) { a[k] = txy[m + k]; u[k] = tuv[m + k]; }
 #pragma unroll
-                    for (int k = 0; k < 8; k += 2) pair2_accumulate(XI2, YI2, t[k], t[k + 1], r2b2, sx2, sy2);
-                    j += 8;
+                    for (int k = 0; k < 4; ++k) pair2_accumulate(XI2, YI2, a[k], u[k], r2b2, sx2, sy2);
+                    m += 4;
                 }
-                if (j < n8) {
-                    f4 t[4];
+                if (m < mp) {
+                    f4 a[2], u[2];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+                    for (int k = 0; k < 2; ++k) { a[k] = txy[m + k]; u[k] = tuv[m + k]; }
 #pragma unroll
-                    for (int k = 0; k < 4; k += 2) pair2_accumulate(XI2, YI2, t[k], t[k + 1], r2b2, sx2, sy2);
+                    for (int k = 0; k < 2; ++k) pair2_accumulate(XI2, YI2, a[k], u[k], r2b2, sx2, sy2);
                 }
-                sx = sx2.x + sx2.y;                // even columns + odd columns
-                sy = sy2.x + sy2.y;
+                sx = hsum2(sx2);                   // even columns + odd columns
+                sy = hsum2(sy2);
             }
         } else {
             // this wave: up to kRows row slices (64 compacted rows each) of its group of kRows waves, column share `share`

@@ -1,0 +1,170 @@
+"""GPU: HostVectorEnv -- the SyncVectorEnv-shaped host face -- under the reference trainer's OWN rollout
+lines.  `_ReferenceRolloutLoop.learn` holds /root/reference/src/agents/rpo_agent.py:168-170 and :193-203 character for
+character (same indentation: a method body with the `for update` / `for step` nesting of the reference), so what the
+unmodified trainer does with the vector env's return values -- `action.cpu().numpy()` in, `np.logical_or`, `torch.tensor(reward)`,
+`torch.Tensor(next_obs)`, `torch.Tensor(done)`, the `final_info` walk -- is executed against this env, with the trainer's
+wrapper chain (NormalizeObservation / NormalizeReward / ClipAction) on.  The numbers are checked against the device-tensor
+face (NormalizedVectorEnv) stepping a twin env with the same actions."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class _Writer:
+    def __init__(self):
+        self.scalars = []
+
+    def add_scalar(self, tag, value, step):
+        self.scalars.append((tag, value, step))
+
+
+class _Cfg:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class _ReferenceRolloutLoop:
+    """The env-facing lines of RPOAgent.learn (rpo_agent.py:158-203); everything between them that belongs to the policy
+    (network, log-probs, values) is replaced by a scripted action, which the env cannot tell from a policy's."""
+
+    def __init__(self, envs, cfg, device, script):
+        import torch
+        self.envs, self.cfg, self.device, self.script = envs, cfg, device, script
+        self.writer = _Writer()
+        self.obs_space = _Cfg(shape=(envs.obs_dim,))
+        self.action_space = envs.single_action_space
+        self.trace = []
+        self._torch = torch
+
+    def learn(self):
+        torch = self._torch
+        obs = torch.zeros((self.cfg.num_steps, self.cfg.num_envs) + self.obs_space.shape).to(self.device)
+        rewards = torch.zeros((self.cfg.num_steps, self.cfg.num_envs)).to(self.device)
+        dones = torch.zeros((self.cfg.num_steps, self.cfg.num_envs)).to(self.device)
+
+        # TRY NOT TO MODIFY: start the game
+        global_step = 0
+        next_obs, _ = self.envs.reset(seed=self.cfg.seed)
+        next_obs = torch.Tensor(next_obs).to(self.device)
+        next_done = torch.zeros(self.cfg.num_envs).to(self.device)
+
+        for update in range(1, self.cfg.num_updates + 1):
+            for step in range(0, self.cfg.num_steps):
+                global_step += 1 * self.cfg.num_envs
+                obs[step] = next_obs                                                # mem
+                dones[step] = next_done                                             # mem
+                action = self.script[(update - 1) * self.cfg.num_steps + step].to(self.device)
+
+                # TRY NOT TO MODIFY: execute the game and log data.
+                next_obs, reward, terminations, truncations, infos = self.envs.step(action.cpu().numpy())
+                done = np.logical_or(terminations, truncations)
+                rewards[step] = torch.tensor(reward).to(self.device).view(-1)       # mem
+                next_obs, next_done = torch.Tensor(next_obs).to(self.device), torch.Tensor(done).to(self.device)
+
+                if "final_info" in infos:
+                    for info in infos["final_info"]:
+                        if info and "episode" in info:
+                            print(f"global_step={global_step}, episodic_return={info['episode']['r']}")
+                            self.writer.add_scalar("charts/episodic_return", info["episode"]["r"], global_step)
+                            self.writer.add_scalar("charts/episodic_length", info["episode"]["l"], global_step)
+                self.trace.append((next_obs.clone(), rewards[step].clone(), next_done.clone(), reward.dtype, terminations.dtype,
+                                   truncations.dtype, type(next_obs)))
+        return obs, rewards, dones
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+def test_the_reference_trainers_rollout_lines_run_verbatim(normalize, capsys):
+    import dataclasses
+    import torch
+    import evacuation_amd as ea
+
+    E, n, L, gamma, seed = 5, 24, 9, 0.97, 77
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=L, is_new_exiting_reward=True, is_new_followers_reward=True)
+    wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
+    envs = ea.HostVectorEnv.make(cfg, wrap, num_envs=E, gamma=gamma, normalize=normalize, seed=seed)
+    tcfg = _Cfg(num_steps=8, num_envs=E, num_updates=3, seed=1)
+    rng = np.random.default_rng(5)
+    T = tcfg.num_steps * tcfg.num_updates
+    script = [torch.as_tensor(rng.uniform(-1.5, 1.5, (E, 2)).astype(np.float32)) for _ in range(T)]     # (exercises ClipAction)
+    loop = _ReferenceRolloutLoop(envs, tcfg, torch.device("cuda:0"), script)
+    obs_buf, rewards, dones = loop.learn()
+    out = capsys.readouterr().out
+    # ... against the device-tensor face stepping a twin env
+    if normalize:
+        twin = ea.NormalizedVectorEnv.make(cfg, wrap, num_envs=E, gamma=gamma, seed=seed)
+    else:
+        twin = ea.BatchedEvacuationEnv(dataclasses.replace(cfg, clip_action=True), wrap, num_envs=E, seed=seed)
+    o, _ = twin.reset(seed=1)
+    assert torch.equal(obs_buf[0], o), "reset observation"
+    n_final = 0
+    for t in range(T):
+        o, r, te, tr, infos = twin.step(script[t].cuda())
+        nobs, rew, ndone, rdt, tedt, trdt, typ = loop.trace[t]
+        assert rdt == np.float64 and tedt == np.bool_ and trdt == np.bool_            # SyncVectorEnv's buffer dtypes
+        assert typ is torch.Tensor and nobs.dtype == torch.float32 and nobs.device.type == "cuda"
+        assert torch.equal(nobs, o), f"step {t} obs"
+        assert torch.equal(rew, r), f"step {t} reward"
+        assert torch.equal(ndone.bool(), (te | tr).bool()), f"step {t} done"
+        n_final += int((te | tr).sum())
+    assert n_final == E * (T // L)                                                     # every env truncates every L steps
+    # the trainer logged one return and one length per finished episode, with the reference's global_step
+    rets = [s for s in loop.writer.scalars if s[0] == "charts/episodic_return"]
+    lens = [s for s in loop.writer.scalars if s[0] == "charts/episodic_length"]
+    assert len(rets) == len(lens) == n_final and all(l[1] == L for l in lens)
+    assert {s[2] for s in rets} == {E * L * k for k in range(1, T // L + 1)}
+    assert out.count("episodic_return=") == n_final
+    envs.close()
+    twin.close()
+
+
+def test_host_env_hands_out_copies_or_live_buffers():
+    import evacuation_amd as ea
+    cfg = ea.EnvConfig(number_of_pedestrians=12, max_timesteps=50)
+    acts = np.zeros((3, 2), dtype=np.float32)
+    a = ea.HostVectorEnv.make(cfg, ea.EnvWrappersConfig(positions="grav"), num_envs=3, seed=2)                 # copy=True: SyncVectorEnv's default
+    o0, _ = a.reset()
+    o1 = a.step(acts)[0]
+    assert o1 is not o0 and not np.shares_memory(o0, o1)
+    b = ea.HostVectorEnv.make(cfg, ea.EnvWrappersConfig(positions="grav"), num_envs=3, seed=2, copy=False)
+    p0, _ = b.reset()
+    p1 = b.step(acts)[0]
+    assert p1 is p0                                                       # the env's buffer, overwritten by the next step
+    np.testing.assert_array_equal(o1, p1)
+    with pytest.raises(ValueError):
+        a.step(np.zeros((4, 2), dtype=np.float32))
+    a.close(); b.close()
+
+
+def test_step_cache_revalidates_shapes_and_returns_the_callers_tensors():
+    """BatchedEvacuationEnv.step binds its ctypes call per set of buffer addresses: a second call with the same storage rows
+    takes the cached path (same results as a fresh env stepping uncached), a tensor of another shape at a cached address is
+    still refused."""
+    import torch
+    import evacuation_amd as ea
+    E, n = 7, 20
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=6)
+    wrap = ea.EnvWrappersConfig(positions="grav")
+    env = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=4)
+    ref = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=4)
+    env.reset(); ref.reset()
+    store = torch.zeros((4, E, env.obs_dim), device=env.device)
+    rew = torch.zeros((4, E), device=env.device)
+    acts = torch.rand((E, 2), device=env.device) * 2 - 1
+    for t in range(12):                       # rows revisited: cached from the second visit on; autoresets at t = 5, 11
+        row = t % 4
+        o, r, te, tr, infos = env.step(acts, out_obs=store[row], out_reward=rew[row])
+        assert o.data_ptr() == store[row].data_ptr() and r.data_ptr() == rew[row].data_ptr()
+        o2, r2, te2, tr2, infos2 = ref.step(acts.clone())          # a fresh tensor every call: never cached
+        assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(te, te2) and torch.equal(tr, tr2)
+        assert ("final_info" in infos) == ("final_info" in infos2) == (t in (5, 11))
+    assert len(env._step_cache) == 4 and len(ref._step_cache) >= 1
+    wide = torch.zeros((E, 4), device=env.device)
+    wide[:, :2] = acts
+    o, *_ = env.step(wide[:, :2])             # a strided view: copied by the uncached path, never bound
+    o2, *_ = ref.step(acts)
+    assert torch.equal(o, o2) and wide.data_ptr() not in {k[0] for k in env._step_cache}
+    flat = acts.view(-1)
+    with pytest.raises(ValueError):
+        env.step(flat)                        # same address as a cached entry, wrong shape
+    env.close(); ref.close()
