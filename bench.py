@@ -14,17 +14,16 @@ same-step autoreset.  One "step" = one env step of every env of the batch: leade
 update, statuses, rewards, flags, observation, autoreset -- all written to HBM every step.
 
 What is timed.  The cost of a step depends on the episode phase (the all-pairs loop runs over the
-pedestrians that still move: all N after a reset, a third of them late in the episode), so a single
-K-step block measures whichever phase it lands on.  The timed region is therefore a sequence of BLOCKS of
-exactly K steps.  Every block opens with barrier + torch.cuda.synchronize() (device idle, all ranks present);
-then, per rank, t0 -> the launches of the K steps (and, N > 1, the all-gather of observations, see below) ->
-the rank drains its own streams -> t1.  The barrier that closes a block is the one that opens the next, OUTSIDE
-the timed region (a dist.barrier() is a collective plus a host sync -- tens of microseconds next to a 70 us
-block); the per-block MAX over ranks is taken after the loop.  Consecutive blocks tile whole episodes
-(R = 2000/K blocks per sweep, --sweeps sweeps, at least 20 blocks).  `ms_per_step` = mean over episode phases
-of the per-phase median block time / K, i.e. the EPISODE-AVERAGE cost; `value` = total envs / that.  Steps are
-issued as launches of min(--inner, K) steps (evac_rollout: the state stays in registers between the steps of a
-launch, every step still writes its outputs to HBM).
+pedestrians that still move: all N after a reset, a third of them late in the episode), so the timed region is
+whole EPISODE SWEEPS: R = 2000/K launches of exactly K steps each (evac_rollout: the state stays in registers between
+the steps of a launch, every step still writes its outputs to HBM), issued back to back -- no host sync and no
+collective between the launches, the queue more than one launch deep; with N > 1 the gather of chunk j-1 runs under
+chunk j (below).  A sweep is bracketed by barrier + torch.cuda.synchronize() on both sides and timed twice: by the
+host clock (t1 after this rank's compute AND comm streams have drained) and by two HIP events on the launching
+stream.  `ms_per_step` = median over --sweeps sweeps of (sweep wall time, MAX over ranks) / 2000 = the EPISODE-AVERAGE
+cost of a step; `value` = total envs / that ("hipEvents around the step loop with no host sync
+inside").  `blocks` keeps the per-block view of rounds 1-3 as a diagnostic: every K-step block bracketed by a device-idle
+sync of its own (what a caller pays who waits for every launch), with the dense and mid-episode figures.
 
 The gather (N > 1).  The only collective of the path is the all-gather of the returned observation batch.
 `--gather-schedule pipelined` (default): the outputs are double-buffered and the gather of chunk j-1 is issued
@@ -93,6 +92,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-api", action="store_true", help="skip the one-launch-per-step side measurement")
     ap.add_argument("--no-gather", action="store_true", help="skip the all-gather of the outputs (N>1)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="run the gather path -- process group, collective on the comm stream, double-buffered pipeline -- with "
+                         "whatever world size there is, also 1 (a one-rank RCCL communicator): exercises the multi-GPU code on one GPU")
     ap.add_argument("--gather", default="obs", choices=["obs", "slab", "direct", "peer"],
                     help="what the ranks all-gather per chunk and how: the observation batch (north_star) or the whole packed "
                          "record through RCCL; or the observation batch written into the peers' hipIpc-mapped buffers by one "
@@ -161,6 +163,47 @@ def spawn_ranks(args, argv) -> int:
     return rc
 
 
+CSRC_FILES = ("evac_api.hip", "evac_common.h", "evac_device.h", "evac_families.h", "evac_gather.h", "evac_subwave.h", "evac_team.h")
+
+
+def csrc_sha16(root: str = ROOT) -> str:
+    """First 16 hex digits of the SHA-256 over the kernel sources + the C ABI header: what profiles/traffic.json's counters
+    were measured on must be what this run has built (tools/make_traffic_json.py stores the same figure)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in CSRC_FILES:
+        with open(os.path.join(root, "evacuation_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    with open(os.path.join(root, "include", "evac.h"), "rb") as f:
+        h.update(b"evac.h\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(path: str, key: str, kernel_variant: str, sources_sha16: str):
+    """The counter-measured figures of `key` ("c2:rollout", ...) from profiles/traffic.json -- or None fields with a note when
+    the entry was measured on other kernels than the ones loaded now (another kernel variant, or kernel sources that have
+    changed since): stale counters must not ride along with a fresh timing."""
+    out = {"hbm_bytes_per_env_step": None, "valu": None, "salu": None, "lds": None, "source": None, "note": None}
+    try:
+        with open(path) as f:
+            ent = json.load(f).get(key)
+    except Exception as exc:  # noqa: BLE001
+        out["note"] = f"no counter file ({type(exc).__name__})"
+        return out
+    if not ent:
+        out["note"] = f"no entry {key!r} in {os.path.basename(path)}"
+        return out
+    if ent.get("kernel_variant") != kernel_variant or ent.get("csrc_sha16") != sources_sha16:
+        out["note"] = (f"profiles/traffic.json[{key!r}] was measured on kernel {ent.get('kernel_variant')!r} built from sources "
+                       f"{ent.get('csrc_sha16')}; this run has {kernel_variant!r} from {sources_sha16}: counters withheld "
+                       f"(re-run tools/profile_pmc.sh + tools/make_traffic_json.py)")
+        return out
+    out.update(hbm_bytes_per_env_step=ent["hbm_bytes_per_env_step"], valu=ent.get("valu_wave_insts_per_env_step"),
+               salu=ent.get("salu_wave_insts_per_env_step"), lds=ent.get("lds_wave_insts_per_env_step"),
+               source=f'{ent.get("source")} ({ent.get("envs")} envs x {ent.get("steps_per_launch")} steps per launch)')
+    return out
+
+
 def cpu_baseline(n_ped: int, seconds: float, procs: int):
     """The NumPy oracle (a port of the reference's EvacuationEnv.step + GravityEncoding) stepped in a
     single-env RandomAgent loop on one host core, as the reference's README loop does; plus, as
@@ -172,7 +215,14 @@ def cpu_baseline(n_ped: int, seconds: float, procs: int):
     out = {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
            "sample": f"{n} single-env steps (n={n_ped}, gravity obs, RandomAgent loop) of the NumPy oracle in {dt:.1f} s "
                      f"on 1 core ({allowed} usable of {os.cpu_count()} host cores)",
-           "agent_updates_per_s": n * n_ped / dt}
+           "agent_updates_per_s": n * n_ped / dt,
+           # (the port stands in for the reference, which may not travel to the GPU box; its own step() as the survey timed it:)
+           "reference_measured": {"value": 3177, "unit": "env-steps/s", "where": "BASELINE.md section 2: the reference's step() with gravity "
+                                  "obs at n=60, survey container (Xeon 2.1 GHz), 1 thread", "port_vs_reference": None},
+           "survey_row_8d_ii": "re-scoped: N independent single-env worker processes (many_core) instead of a batched [E, N] NumPy "
+                               "restatement split over the cores -- one env per process is how the reference itself uses many cores "
+                               "(run_scripts/run.sh:65-68), and a second, batched oracle would be unpinned against the reference"}
+    out["reference_measured"]["port_vs_reference"] = out["value"] / 3177.0
     if procs > 1:
         try:
             out["many_core"] = cpu_bench.many_core_report(n_ped, min(seconds, 6.0), procs, n / dt)
@@ -335,8 +385,11 @@ def main(argv=None):
     dev_index = int(os.environ.get("EVAC_BENCH_FORCE_DEVICE", local_rank))   # testing aid: several ranks on one GPU
     torch.cuda.set_device(dev_index)
     device = torch.device(f"cuda:{dev_index}")
-    if world > 1:
+    use_dist = world > 1 or args.force_gather                                  # (--force-gather: a one-rank communicator)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         backend = os.environ.get("EVAC_BENCH_BACKEND", "nccl")                 # "nccl" IS RCCL on ROCm; gloo = testing aid
         import datetime
         limit = datetime.timedelta(seconds=300)       # a stuck collective must surface as an error, not hang the run
@@ -358,7 +411,7 @@ def main(argv=None):
     loc = env.local
     E, D = loc.num_envs, loc.obs_dim
     env.reset()
-    do_gather = world > 1 and not args.no_gather
+    do_gather = use_dist and not args.no_gather
     gather_rollout = do_gather and args.mode == "rollout"
     sizes = chunk_sizes(K, inner, args.gather_schedule, gather_rollout)
     inner = sizes[0]                                           # the launch shape the roofline block describes
@@ -437,15 +490,22 @@ def main(argv=None):
     pipe = ChunkPipeline(launch, gather if do_gather else None, wait_gather, drain_compute, drain_gather if do_gather else None, lag=lag)
 
     def barrier():
-        """Opens a timed block (and, being the next block's opening, closes the previous one outside its timed region)."""
-        if world > 1:
+        """Opens a timed region (and, being the next one's opening, closes the previous one outside its timed region)."""
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Exercise the collective once before anything is timed.  A collective that fails is a hard error: an N-GPU value
+    # Every (chunk size, parity) buffer set is created HERE, on all ranks in the same order: the peer-mapped gathers rendezvous
+    # (hipIpc handles through all_gather_object, a barrier) when they are built, which must not happen inside a timed region.
+    # Then the collective is exercised once before anything is timed.  A collective that fails is a hard error: an N-GPU value
     # without the gather traffic is not the benchmark (use --no-gather to measure independent shards on purpose).
-    if gather_rollout:
-        try:
+    all_sizes = sorted(set(sizes) | ({min(inner, W - d) for d in range(0, W, inner)} if W > 0 else set()))
+    try:
+        if args.mode == "rollout":
+            for t_ in all_sizes:
+                for par_ in (0, 1):
+                    chunk_bufs(t_, par_)
+        if gather_rollout:
             b0 = chunk_bufs(sizes[0], 0)
             if args.gather == "direct":
                 b0["direct"].issue(torch.cuda.current_stream())
@@ -455,11 +515,13 @@ def main(argv=None):
             else:
                 all_gather_envs(b0["slab"] if args.gather == "slab" else b0["gsrc"], out=b0["gathered"])
             torch.cuda.synchronize()
-        except Exception as exc:  # noqa: BLE001
-            raise SystemExit(f"bench.py: rank {rank}: the all-gather failed ({type(exc).__name__}: {exc}); no {world}-GPU result "
-                             f"(--no-gather measures independent shards)") from exc
+    except Exception as exc:  # noqa: BLE001
+        if not gather_rollout:
+            raise
+        raise SystemExit(f"bench.py: rank {rank}: the all-gather failed ({type(exc).__name__}: {exc}); no {world}-GPU result "
+                         f"(--no-gather measures independent shards)") from exc
 
-    # W untimed warm-up steps through the same pipeline (so that, pipelined, the first timed block has a gather to carry)
+    # W untimed warm-up steps through the same pipeline (so that, pipelined, the first timed launch has a gather to carry)
     w_done = 0
     while w_done < W:
         t = min(inner, W - w_done)
@@ -467,48 +529,72 @@ def main(argv=None):
         w_done += t
     pipe.drain()
     barrier()
-    state0 = [t.clone() for t in (loc.ped, loc.status, loc.agent, loc.clock, loc.acc)]   # for the kernel-timing replay below
+    state0 = [t.clone() for t in (loc.ped, loc.status, loc.agent, loc.clock, loc.acc)]   # for the per-launch replay below
     ws0 = loc.workspace.clone() if loc.workspace is not None else None
-    n_blocks = per_sweep * sweeps
-    wall, phases, t_call = [], [], []
-    # one launch per block and nothing to gather: issue it without the pipeline's bookkeeping (a few us of Python next to a 50 us kernel)
-    one_launch = chunk_bufs(K, 0)["launch"] if (args.mode == "rollout" and sizes == [K] and not do_gather) else None
-    for b in range(n_blocks):
-        phases.append((W + b * K) % EPISODE)                  # RandomAgent episodes end by truncation at 2000
+    phase0 = W % EPISODE
+
+    # ---- the headline: whole episode sweeps, launches back to back, no host sync inside ----
+    import statistics
+    uniform = all(t == inner for t in sizes)
+    launches_per_sweep = per_sweep * len(sizes)
+    sweep_wall, sweep_dev = [], []
+    for sw in range(sweeps):
         barrier()                                             # opening bracket: all ranks present, device idle
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for b in range(per_sweep):
+            pipe.run_block(sizes)                             # EXACTLY K steps (+ one gather per launch), nothing waited for
+        e1.record()
+        pipe.drain()                                          # this rank's compute AND gathers are done
+        sweep_wall.append(time.perf_counter() - t0)           # local t1; no collective inside the timed region
+        sweep_dev.append(e0.elapsed_time(e1) * 1e-3)
+    pipe.flush()
+    barrier()
+    if use_dist:
+        tt = torch.tensor(sweep_wall, dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)             # per sweep: the slowest rank
+        sweep_wall = [float(x) for x in tt.tolist()]
+    steps_per_sweep = per_sweep * K
+    sweep_s = statistics.median(sweep_wall)
+    kernel_s = statistics.median(sweep_dev) / launches_per_sweep      # mean launch of a sweep (kernel + the ~1.5 us launch boundary)
+
+    # ---- diagnostic 1: one sweep of blocks, each bracketed by a device-idle sync of its own (the headline of rounds 1-3) ----
+    wall, phases, t_call = [], [], []
+    one_launch = chunk_bufs(K, 0)["launch"] if (args.mode == "rollout" and sizes == [K] and not do_gather) else None
+    for b in range(per_sweep):
+        phases.append((phase0 + (sweeps * per_sweep + b) * K) % EPISODE)     # RandomAgent episodes end by truncation at 2000
+        barrier()
         t0 = time.perf_counter()
         if one_launch is not None:
-            one_launch()                                      # EXACTLY K steps
+            one_launch()
             t_call.append(time.perf_counter() - t0)           # (the launch call alone: reported, not subtracted)
             drain_compute()
         else:
-            pipe.run_block(sizes)                             # EXACTLY K steps (+ one gather per launch)
-            pipe.drain()                                      # this rank's compute AND gathers are done
-        wall.append(time.perf_counter() - t0)                 # local t1; no collective inside the timed region
+            pipe.run_block(sizes)
+            pipe.drain()
+        wall.append(time.perf_counter() - t0)
     pipe.flush()
     barrier()
-    if world > 1:
+    if use_dist:
         tt = torch.tensor(wall, dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)             # per block: the slowest rank
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = [float(x) for x in tt.tolist()]
     block_s, blocks_info = summarize_blocks(wall, phases, per_sweep, K)
+    blocks_info["note"] = ("diagnostic: ONE sweep of K-step blocks, each opened by barrier + synchronize and closed by the rank's own "
+                           "drain (launch call + start / completion latency of a lone launch included); not the headline")
     if t_call:
         blocks_info["launch_call_us_median"] = sorted(t_call)[len(t_call) // 2] * 1e6
-    if os.environ.get("EVAC_BENCH_DUMP") and rank == 0:      # diagnostic: the raw blocks
+    if os.environ.get("EVAC_BENCH_DUMP") and rank == 0:      # diagnostic: the raw sweeps and blocks
         with open(os.environ["EVAC_BENCH_DUMP"], "w") as f:
-            json.dump({"wall_s": wall, "phase": phases, "launch_call_s": t_call}, f)
+            json.dump({"sweep_wall_s": sweep_wall, "sweep_dev_s": sweep_dev, "wall_s": wall, "phase": phases, "launch_call_s": t_call}, f)
 
-    # Duration of the dominant kernel's launches, from HIP events on the launching stream.  An event pair around ONE
-    # short launch also times the ~7 us between the markers and the kernel (11 % of a 20-step launch), so the average
-    # launch duration is taken over a replay of the first sweep's blocks (state restored, no gathers) issued back to back
-    # between two events (elapsed / launches: kernel + the ~1.5 us launch boundary) -- this is the figure a
-    # `rocprofv3 --kernel-trace --stats` of this command reproduces; the per-launch pairs give the dense (all N moving)
-    # launch, corrected by the mean difference between the two measurements.
+    # ---- diagnostic 2: an event pair around every launch of one sweep (state restored, no gathers): the dense launch ----
     def restore():
         barrier()
         for dst, src in zip((loc.ped, loc.status, loc.agent, loc.clock, loc.acc), state0):   # same phases as the first sweep
             dst.copy_(src)
-        if ws0 is not None:                                   # ... and the same load schedule: loads as they were, re-sorted at the first launch
+        if ws0 is not None:                                   # ... and the same load schedule: loads as they were, dealt again
             loc.workspace.copy_(ws0)
             loc.rebind_workspace()
         barrier()
@@ -520,8 +606,8 @@ def main(argv=None):
             loc.step(step_actions)
 
     restore()
-    per_launch, dense_l = [], []
-    for b in range(per_sweep):                                # replay 1: an event pair around every launch
+    per_launch = []
+    for b in range(per_sweep):
         for t in sizes:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -529,23 +615,16 @@ def main(argv=None):
             ev1.record()
             per_launch.append((b, t, ev0, ev1))
     barrier()
-    dense_b = min(range(min(per_sweep, n_blocks)), key=lambda k: phases[k])
+    dense_b = min(range(per_sweep), key=lambda k: (phase0 + k * K) % EPISODE)
     full = [a.elapsed_time(z) * 1e-3 for b, t, a, z in per_launch if t == inner]
     dense_l = [a.elapsed_time(z) * 1e-3 for b, t, a, z in per_launch if t == inner and b == dense_b]
-    restore()                                                 # replay 2: back to back between two events
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    back_to_back = 0
-    uniform = all(t == inner for t in sizes)
-    e0.record()
-    for b in range(per_sweep):
-        for t in sizes:
-            replay_launch(t)
-            back_to_back += 1
-    e1.record()
-    barrier()
-    kernel_s = e0.elapsed_time(e1) * 1e-3 / max(1, back_to_back) if uniform else sum(full) / max(1, len(full))
+    if not uniform:
+        kernel_s = sum(full) / max(1, len(full))
+    # (an event pair around ONE short launch also times the few us between the markers and the kernel: corrected by the mean
+    # difference between the pairs and the back-to-back sweep)
     event_overhead_s = max(0.0, sum(full) / max(1, len(full)) - kernel_s) if uniform else 0.0
     kernel_dense_s = (sorted(dense_l)[len(dense_l) // 2] - event_overhead_s) if dense_l else kernel_s
+    back_to_back = launches_per_sweep * sweeps
     if loc.team_error():                                      # a team barrier timed out somewhere above: the numbers are void
         raise SystemExit("bench.py: evac_team_error is set (a team rollout lost a member); results discarded")
     bytes_per_env_step = loc.algorithmic_bytes_per_env_step
@@ -600,17 +679,11 @@ def main(argv=None):
             step_api["hipgraph_error"] = f"{type(exc).__name__}: {exc}"[:160]
 
     if rank == 0:
-        traffic = traffic_src = valu_insts = None
-        try:
-            with open(args.traffic_json) as f:
-                ent = json.load(f).get(f"{args.workload}:{args.mode}")
-            if ent:
-                traffic = ent["hbm_bytes_per_env_step"] * E * inner      # measured per env-step, scaled to one launch
-                traffic_src = f'{ent.get("source")} ({ent.get("envs")} envs x {ent.get("steps_per_launch")} steps per launch)'
-                valu_insts = ent.get("valu_wave_insts_per_env_step")
-        except Exception:  # noqa: BLE001
-            pass
-        value = total_envs / (block_s / K)
+        tr = load_traffic(args.traffic_json, f"{args.workload}:{args.mode}", loc.kernel_variant(args.mode), csrc_sha16())
+        traffic = tr["hbm_bytes_per_env_step"] * E * inner if tr["hbm_bytes_per_env_step"] is not None else None   # per env-step, scaled to one launch
+        traffic_src, valu_insts = tr["source"], tr["valu"]
+        step_s = sweep_s / steps_per_sweep                         # the episode-average cost of one step of the whole batch
+        value = total_envs / step_s
         if not do_gather:
             gather_desc = ""
         elif args.mode == "step":
@@ -626,23 +699,28 @@ def main(argv=None):
         out = {
             "metric": "env-steps/s (agent-updates/s) at n=60x4096 envs" if args.workload == "c2" else f"env-steps/s ({args.workload})",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": block_s / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "n_pedestrians": n_ped, "envs_per_gpu": E, "total_envs": total_envs,
                        "obs": wrap_kw, "actions": "RandomAgent U(-1,1)^2 drawn on device (Philox4x32-10)",
                        "mode": args.mode, "steps_per_launch": inner, "launches_per_block": len(sizes),
-                       "timing": "blocks of exactly K steps tiling whole episodes; per block: barrier + synchronize (all ranks, device "
-                                 "idle) -> t0 -> launches (+ gathers) -> the rank drains its compute and comm streams -> t1; the "
-                                 "closing barrier is the next block's opening, outside the timed region; max over ranks per block; "
-                                 "ms_per_step = episode average of the per-phase median block",
+                       "timing": "whole episode sweeps of 2000/K launches of exactly K steps each, issued back to back (no host sync, no "
+                                 "collective inside; N > 1: the gather of chunk j-1 under chunk j); per sweep: barrier + synchronize (all "
+                                 "ranks, device idle) -> t0 -> the launches (+ gathers) -> the rank drains its compute and comm streams "
+                                 "-> t1, max over ranks; ms_per_step = median sweep / 2000 = the episode-average step; `blocks`: the "
+                                 "per-block view (a device-idle sync around every K-step launch) as a diagnostic",
+                       "sweeps": {"timed": sweeps, "launches_per_sweep": launches_per_sweep, "steps_per_sweep": steps_per_sweep,
+                                  "wall_ms": [x * 1e3 for x in sweep_wall], "hip_event_ms": [x * 1e3 for x in sweep_dev]},
                        "gather_schedule": (args.gather_schedule if gather_rollout else None),
-                       "ranks_joined": dist.get_world_size() if world > 1 else 1,
+                       "ranks_joined": dist.get_world_size() if use_dist else 1,
+                       "collective_backend": (dist.get_backend() if use_dist else None),
                        "parallelism": f"env-sharded x{world}" + gather_desc,
                        "max_timesteps": EPISODE, "autoreset": True},
             "agent_updates_per_s": value * n_ped,
             "blocks": blocks_info,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": tr["note"],
+                         "salu_wave_insts_per_env_step": tr["salu"], "lds_wave_insts_per_env_step": tr["lds"],
                          "kernel": loc.kernel_variant(args.mode),
                          "kernel_ms_per_launch": kernel_s * 1e3, "kernel_launches_timed": back_to_back if uniform else len(full),
                          "kernel_ms_per_launch_event_pairs": sum(full) / max(1, len(full)) * 1e3,
@@ -671,7 +749,7 @@ def main(argv=None):
         out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)
     env.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return 0

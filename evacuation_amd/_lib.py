@@ -15,7 +15,7 @@ POS = {"abs": 0, "rel": 1, "grav": 2}
 STAT = {"no": 0, "ohe": 1, "cat": 2}
 TYPE = {"Dict": 0, "Box": 1}
 MAX_PEDESTRIANS = 1024
-VERSION = 131
+VERSION = 140
 EPISODE_STATS_WORDS = 10       # evac_episode_stats_t: 8 floats + 2 int32
 
 
@@ -55,6 +55,7 @@ SIGNATURES = {
     "evac_workspace_bytes": (C.c_int64, [_P]),
     "evac_bind_workspace": (C.c_int, [_P, _P, C.c_int64]),
     "evac_reschedule": (C.c_int, [_P, _P]),
+    "evac_schedule_generation": (C.c_int32, [_P]),
     "evac_team_error": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "evac_team_clear_error": (C.c_int, [_P]),
     "evac_peer_gather": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
@@ -86,7 +87,11 @@ def load() -> C.CDLL:
             "evacuation_amd has no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError if the library does not export it
+        fn = getattr(lib, name, None)
+        if fn is None:
+            if os.environ.get("EVAC_LIB"):   # a profiling build of an older tree (A/B runs): entry points added since are absent
+                continue
+            raise AttributeError(f"{LIB_PATH} does not export {name}: stale build? (python -m evacuation_amd.build --force)")
         fn.restype = res
         fn.argtypes = args
     _lib = lib

@@ -69,8 +69,9 @@ struct evac_handle {
     bool cu_wide4;      // the same for four-wave envs (4 envs per CU-wide workgroup)
     bool default_cfg;   // the configuration the specialised rollout kernels assume (k_rollout_default_config)
     int team_k;         // rollouts of 513..1024-pedestrian envs by teams of 2 / 4 / 8 / 16 workgroups per env (0: one workgroup per env)
-    int32_t* sched;     // inside the caller's workspace (evac_bind_workspace): moving[E] | perm[E], or NULL
-    int sched_age;      // env steps rolled out since the schedule was last rebuilt (< 0: never built)
+    int32_t* sched;     // inside the caller's workspace (evac_bind_workspace): moving[2][E] | perm[2][E], or NULL
+    int sched_gen;      // rollout launches under the schedule so far (< 0: no deal yet): launch g reads perm[g & 1], leaves its loads
+                        // in moving[g & 1] and deals perm[(g + 1) & 1] from moving[(g - 1) & 1] (rollout_body)
     bool team_bound;    // the workspace holds the teams' exchange areas
     int team_fit;       // -1: not checked yet; 1 / 0: the team grid fits the device at once (occupancy x CUs >= workgroups) or not
     size_t team_xchg_bytes;   // the teams' exchange area (records + tile slots), reset to the sentinel before every team launch
@@ -319,7 +320,7 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
                          p.one_minus_ens == 0.0f &&
                          (p.flags & (evac::kFlagTermOnWall | evac::kFlagNanGuard)) == 0;
         h->sched = nullptr;
-        h->sched_age = -1;
+        h->sched_gen = -1;
         // teams: as many CUs per env as the batch leaves free -- all members must be resident together (one 1024-thread
         // workgroup per CU), teams are laid out in rows of 8 (one per XCD).  EVAC_TEAM=0 disables, 2 / 4 / 8 / 16 forces a size.
         h->team_k = 0;
@@ -429,7 +430,7 @@ WorkspaceLayout workspace_layout(const evac_handle* h) {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     WorkspaceLayout w{};
     size_t o = 0;
-    w.sched = o; o = up(o + 2 * E * sizeof(int32_t));
+    w.sched = o; o = up(o + 4 * E * sizeof(int32_t));          // moving[2][E] | perm[2][E]
     w.stats = o; o = up(o + 64);
     if (h->team_k) {
         w.team_rec = o; o = up(o + 3 * E * 32 * 16);          // (three slot sets: evac_team.h, exchange)
@@ -446,7 +447,7 @@ int64_t evac_workspace_bytes(evac_handle_t h) { return h ? (int64_t)workspace_la
 int evac_bind_workspace(evac_handle_t h, void* workspace, int64_t bytes) {
     if (!h) return EVAC_ERR_INVALID_ARGUMENT;
     h->sched = nullptr;
-    h->sched_age = -1;
+    h->sched_gen = -1;
     h->team_bound = false;
     if (!workspace) return EVAC_OK;
     const WorkspaceLayout w = workspace_layout(h);
@@ -464,15 +465,28 @@ int evac_bind_workspace(evac_handle_t h, void* workspace, int64_t bytes) {
     return EVAC_OK;
 }
 
+namespace {
+// the explicit deal (k_schedule): the permutation launch `gen` will read, from the loads launch gen - 1 left; `both`: the other
+// permutation buffer too
+void deal_now(evac_handle_t h, hipStream_t s, bool both) {
+    const int E = h->p.n_envs;
+    if (h->sched_gen < 0) h->sched_gen = 0;
+    const int g = h->sched_gen;
+    hipLaunchKernelGGL(evac::k_schedule, dim3(1), dim3(1024), 0, s, E, (const int*)(h->sched + ((g + 1) & 1) * E),
+                       h->sched + (2 + (g & 1)) * E, both ? h->sched + (2 + ((g + 1) & 1)) * E : (int32_t*)nullptr,
+                       h->cu_wide4 ? 4 : 16, h->cu_wide4 ? 4 : 1);
+}
+}  // namespace
+
 int evac_reschedule(evac_handle_t h, void* stream) {
     if (!h) return EVAC_ERR_INVALID_ARGUMENT;
     if (!h->sched || !(h->cu_wide || h->cu_wide4)) return EVAC_OK;       // nothing to deal
     DeviceGuard g(h->device);
-    hipLaunchKernelGGL(evac::k_schedule, dim3(1), dim3(1024), 0, (hipStream_t)stream, h->p.n_envs, (const int*)h->sched, h->sched + h->p.n_envs,
-                       h->cu_wide4 ? 4 : 16, h->cu_wide4 ? 4 : 1);
-    h->sched_age = 0;
+    deal_now(h, (hipStream_t)stream, true);
     return check_launch(h, "evac_reschedule");
 }
+
+int32_t evac_schedule_generation(evac_handle_t h) { return (h && h->sched && (h->cu_wide || h->cu_wide4)) ? h->sched_gen : -1; }
 
 int evac_peer_gather(const float* src, int64_t rows, int32_t row_words, int32_t take_words, float* const* peer_dst, int32_t world,
                      int32_t my_rank, int32_t wgs_per_peer, void* stream) {
@@ -596,7 +610,8 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
         const float2* actions_ = (const float2*)actions;
         const int* perm_ = nullptr;
         int* moving_ = nullptr;
-        void* argv[] = {(void*)&h->p, (void*)&n_steps_, (void*)&actions_, (void*)&slab_out, (void*)&final_stats, (void*)&perm_, (void*)&moving_};
+        void* argv[] = {(void*)&h->p, (void*)&n_steps_, (void*)&actions_, (void*)&slab_out, (void*)&final_stats, (void*)&perm_, (void*)&moving_,
+                        (void*)&perm_, (void*)&moving_};
         const void* fn = team_kernel(h);
         hipError_t le = h->team_coop ? hipLaunchCooperativeKernel(fn, grid, block, argv, 0, s_) : hipLaunchKernel(fn, grid, block, argv, 0, s_);
         if (le != hipSuccess && h->team_coop) {      // (e.g. under stream capture): the occupancy check still holds for a plain launch
@@ -606,63 +621,63 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
         }
         if (le != hipSuccess) return fail(h, EVAC_ERR_HIP, std::string("evac_rollout (team launch): ") + hipGetErrorString(le));
     } else if (h->cu_wide || h->cu_wide4) {
-        // one-wave envs, batch >= 16 envs per CU: CU-wide workgroups, envs dealt to the SIMDs by load when a schedule scratch
-        // is bound (rebuilt every 50..200 env steps: the loads drift slowly)
-        // (short launches re-sort less often: the sort is a launch of its own, ~4 us next to a 20-step launch of ~55 us)
-        const int kScheduleEvery = n_steps >= 50 ? 50 : (8 * n_steps < 200 ? (8 * n_steps > 50 ? 8 * n_steps : 50) : 200);
+        // one-wave envs, batch >= 16 envs per CU (or four-wave envs, >= 4 per CU): CU-wide workgroups, envs dealt to the SIMDs by
+        // load when a schedule scratch is bound.  Launch g reads perm[g & 1], leaves its loads in moving[g & 1] and -- workgroup 0,
+        // which carries the lightest envs, before it starts stepping (rollout_body) -- deals perm[(g + 1) & 1] for the next launch
+        // from the loads launch g - 1 left in moving[(g - 1) & 1]: no launch is spent on sorting, and no buffer is read and
+        // written by the same launch.
         using FW = evac::Wave<1, 1024>;
         using FW4 = evac::Wave<4, 1024>;
         hipStream_t s_ = (hipStream_t)stream;
         const int E = h->p.n_envs;
-        int32_t* moving = h->sched;
-        // (while the stream is being captured into a hipGraph the host-side age must not decide what the graph contains: a
-        // captured launch never re-sorts and does not age the schedule -- any permutation gives the same results, call
-        // evac_reschedule outside the graph to refresh the deal)
+        // (while the stream is being captured into a hipGraph the host-side generation must not decide what the graph contains:
+        // a captured launch runs under the deal at hand, deals nothing and does not advance the generation -- any permutation
+        // gives the same results; call evac_reschedule outside the graph to refresh the deal)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s_, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
         const bool capturing = cap != hipStreamCaptureStatusNone;
-        if (h->sched && !capturing && (h->sched_age < 0 || h->sched_age >= kScheduleEvery)) {
-            hipLaunchKernelGGL(evac::k_schedule, dim3(1), dim3(1024), 0, s_, E, (const int*)moving, h->sched + E,
-                               h->cu_wide4 ? 4 : 16, h->cu_wide4 ? 4 : 1);
-            h->sched_age = 0;
-        }
-        if (h->sched && !capturing) h->sched_age += n_steps;
-        const int32_t* perm = (h->sched && h->sched_age >= 0) ? h->sched + E : nullptr;     // (never dealt yet, e.g. a first launch under capture: identity)
+        // Long launches (>= 50 steps): the deal as a launch of its own in front of every rollout launch -- 6.5 us next to >= 100,
+        // by the loads the previous launch has just left.  Short launches (the driver's 20 steps): the deal of the NEXT launch is
+        // made inside this one (rollout_body: workgroup 0, before it starts stepping), by the loads of the launch before.
+        const bool in_kernel = n_steps < 50 && E >= (h->cu_wide4 ? 4 : 16);     // (workgroup 0 sorts: it must be a full one)
+        if (h->sched && !capturing && (h->sched_gen < 0 || !in_kernel)) deal_now(h, s_, h->sched_gen < 0);
+        const int g_ = h->sched_gen;
+        const bool dealt = h->sched && g_ >= 0;                                // (never dealt yet, e.g. a first launch under capture: identity)
+        const bool deals = dealt && !capturing && in_kernel;
+        const int32_t* perm = dealt ? h->sched + (2 + (g_ & 1)) * E : nullptr;
+        int32_t* moving = h->sched ? h->sched + (dealt ? (g_ & 1) : 0) * E : nullptr;
+        const int32_t* deal_loads = deals ? h->sched + ((g_ + 1) & 1) * E : nullptr;
+        int32_t* deal_perm = deals ? h->sched + (2 + ((g_ + 1) & 1)) * E : nullptr;
+        if (dealt && !capturing) h->sched_gen = g_ + 1;
+#define EVAC_CUWIDE_ARGS h->p, (int)n_steps, (const float2*)actions, slab_out, final_stats, (const int*)perm, (int*)moving, (const int*)deal_loads, (int*)deal_perm
         if (h->cu_wide4) {
             const dim3 grid4((unsigned)((E + FW4::kEnvsPerBlock - 1) / FW4::kEnvsPerBlock));
             if (h->default_cfg && h->p.obs_pos == EVAC_POS_GRAV)
-                hipLaunchKernelGGL((evac::k_rollout_default_config<FW4, true>), grid4, dim3(FW4::kBlock), 0, s_, h->p, (int)n_steps,
-                                   (const float2*)actions, slab_out, final_stats, (const int*)perm, (int*)moving);
+                hipLaunchKernelGGL((evac::k_rollout_default_config<FW4, true>), grid4, dim3(FW4::kBlock), 0, s_, EVAC_CUWIDE_ARGS);
             else if (h->default_cfg)
-                hipLaunchKernelGGL((evac::k_rollout_default_config<FW4, false>), grid4, dim3(FW4::kBlock), 0, s_, h->p, (int)n_steps,
-                                   (const float2*)actions, slab_out, final_stats, (const int*)perm, (int*)moving);
+                hipLaunchKernelGGL((evac::k_rollout_default_config<FW4, false>), grid4, dim3(FW4::kBlock), 0, s_, EVAC_CUWIDE_ARGS);
             else if (h->p.obs_pos == EVAC_POS_GRAV)
-                hipLaunchKernelGGL((evac::k_rollout<FW4, true>), grid4, dim3(FW4::kBlock), 0, s_, h->p, (int)n_steps, (const float2*)actions,
-                                   slab_out, final_stats, (const int*)perm, (int*)moving);
+                hipLaunchKernelGGL((evac::k_rollout<FW4, true>), grid4, dim3(FW4::kBlock), 0, s_, EVAC_CUWIDE_ARGS);
             else
-                hipLaunchKernelGGL((evac::k_rollout<FW4, false>), grid4, dim3(FW4::kBlock), 0, s_, h->p, (int)n_steps, (const float2*)actions,
-                                   slab_out, final_stats, (const int*)perm, (int*)moving);
+                hipLaunchKernelGGL((evac::k_rollout<FW4, false>), grid4, dim3(FW4::kBlock), 0, s_, EVAC_CUWIDE_ARGS);
             return check_launch(h, "evac_rollout");
         }
         const dim3 grid((unsigned)((E + FW::kEnvsPerBlock - 1) / FW::kEnvsPerBlock));
         if (h->default_cfg && h->p.obs_pos == EVAC_POS_GRAV)
-            hipLaunchKernelGGL((evac::k_rollout_default_config<FW, true>), grid, dim3(FW::kBlock), 0, s_, h->p, (int)n_steps,
-                               (const float2*)actions, slab_out, final_stats, (const int*)perm, (int*)moving);
+            hipLaunchKernelGGL((evac::k_rollout_default_config<FW, true>), grid, dim3(FW::kBlock), 0, s_, EVAC_CUWIDE_ARGS);
         else if (h->default_cfg)
-            hipLaunchKernelGGL((evac::k_rollout_default_config<FW, false>), grid, dim3(FW::kBlock), 0, s_, h->p, (int)n_steps,
-                               (const float2*)actions, slab_out, final_stats, (const int*)perm, (int*)moving);
+            hipLaunchKernelGGL((evac::k_rollout_default_config<FW, false>), grid, dim3(FW::kBlock), 0, s_, EVAC_CUWIDE_ARGS);
         else if (h->p.obs_pos == EVAC_POS_GRAV)
-            hipLaunchKernelGGL((evac::k_rollout<FW, true>), grid, dim3(FW::kBlock), 0, s_, h->p, (int)n_steps, (const float2*)actions,
-                               slab_out, final_stats, (const int*)perm, (int*)moving);
+            hipLaunchKernelGGL((evac::k_rollout<FW, true>), grid, dim3(FW::kBlock), 0, s_, EVAC_CUWIDE_ARGS);
         else
-            hipLaunchKernelGGL((evac::k_rollout<FW, false>), grid, dim3(FW::kBlock), 0, s_, h->p, (int)n_steps, (const float2*)actions,
-                               slab_out, final_stats, (const int*)perm, (int*)moving);
+            hipLaunchKernelGGL((evac::k_rollout<FW, false>), grid, dim3(FW::kBlock), 0, s_, EVAC_CUWIDE_ARGS);
+#undef EVAC_CUWIDE_ARGS
     } else if (h->default_cfg)
         EVAC_DISPATCH(h, k_rollout_default_config, stream, h->p, (int)n_steps, (const float2*)actions, slab_out, final_stats,
-                      (const int*)nullptr, (int*)nullptr);
+                      (const int*)nullptr, (int*)nullptr, (const int*)nullptr, (int*)nullptr);
     else
         EVAC_DISPATCH(h, k_rollout, stream, h->p, (int)n_steps, (const float2*)actions, slab_out, final_stats, (const int*)nullptr,
-                      (int*)nullptr);
+                      (int*)nullptr, (const int*)nullptr, (int*)nullptr);
     return check_launch(h, "evac_rollout");
 }
 

@@ -275,8 +275,13 @@ __device__ __forceinline__ void pair_accumulate(float XI, float YI, f4 t, float 
 // do for two columns -- the same operations per column (subtract, two FMAs for the 0/1 weight, one FMA per heading component),
 // with the heading sums kept as (even columns, odd columns) halves that the caller adds at the end.
 using f2 = float __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void pair2_accumulate(f2 XI2, f2 YI2, f4 xy, f4 uv, f2 r2b2, f2& sx2, f2& sy2) {
-    const f2 dx = XI2 - __builtin_shufflevector(xy, xy, 0, 1), dy = YI2 - __builtin_shufflevector(xy, xy, 2, 3);
+// `P` = (X_i, Y_i) of the lane's own row in ONE register pair: op_sel broadcasts its low half against (X_j, X_j+1) and its
+// high half against (Y_j, Y_j+1) -- no duplicated (X_i, X_i) / (Y_i, Y_i) pairs to build every step.
+__device__ __forceinline__ void pair2_accumulate(f2 P, f4 xy, f4 uv, f2 r2b2, f2& sx2, f2& sy2) {
+    const f2 xx = __builtin_shufflevector(xy, xy, 0, 1), yy = __builtin_shufflevector(xy, xy, 2, 3);
+    f2 dx, dy;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dx) : "v"(P), "v"(xx));                 // X_i - (X_j, X_j+1)
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dy) : "v"(P), "v"(yy));    // Y_i - (Y_j, Y_j+1)
     const f2 a = __builtin_elementwise_fma(-dy, dy, r2b2);
     f2 w;
     asm("v_pk_fma_f32 %0, %1, %1, %2 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(w) : "v"(dx), "v"(a));

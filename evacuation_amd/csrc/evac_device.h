@@ -266,17 +266,81 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
 // A hint only: results do not depend on it.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void set_wave_priority(int k) {   // k in 0..3, wave-uniform
-    switch (k & 3) {
-        case 0: __builtin_amdgcn_s_setprio(0); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
-    }
+    // (s_setprio takes an immediate: a two-level compare tree, four or five scalar instructions on every path -- the switch the
+    // compiler builds from the four builtin calls runs up to thirteen)
+    k &= 3;
+    asm volatile(
+        "s_cmp_lt_u32 %0, 2\n\t"
+        "s_cbranch_scc1 1f\n\t"
+        "s_cmp_eq_u32 %0, 3\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "s_setprio 2\n\t"
+        "s_branch 9f\n"
+        "3:\n\t"
+        "s_setprio 3\n\t"
+        "s_branch 9f\n"
+        "1:\n\t"
+        "s_cmp_eq_u32 %0, 0\n\t"
+        "s_cbranch_scc1 0f\n\t"
+        "s_setprio 1\n\t"
+        "s_branch 9f\n"
+        "0:\n\t"
+        "s_setprio 0\n"
+        "9:"
+        :
+        : "s"(k)
+        : "scc");
 }
 __device__ __forceinline__ int simd_wave_slot() {   // slot of this wave among the waves of its SIMD (HW_ID bits 3:0)
     unsigned hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     return (int)(hw & 3u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The schedule of the CU-wide rollout workgroups: envs sorted by the pedestrians still moving (the length of their pair
+// loop, as a launch left it in `moving`) and dealt to the SIMDs in snake order, so that the four envs of every SIMD -- and
+// the sixteen of every CU -- carry about the same load.  A launch lasts as long as its slowest SIMD; with random placement
+// that is 1.25-1.35x the mean load for most of an episode (tools/moving_distribution.py).
+// perm[slot] = env.  per_wg = 16: one-wave envs (slot = workgroup * 16 + wave, SIMD = wave % 4); per_wg = 4: four-wave envs
+// (slot = workgroup * 4 + env of the workgroup; every SIMD runs one wave of each of the four) -- one env of each load quartile
+// per SIMD / per workgroup, the heaviest in the SIMD's first (oldest) wave.  Loads are binned in 65 steps of `unit` pedestrians;
+// ties are placed in arrival order (LDS atomics): the permutation may differ from run to run, the results cannot.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int schedule_bin(int load, int unit) { return min(max(load / unit, 0), kWave); }
+// rank by load (ascending) -> slot.  Workgroup 0 takes the per_wg LIGHTEST envs of the batch (it deals the next launch's envs
+// before it starts stepping -- rollout_body -- and must still be done before the others); the rest is dealt in snake order.
+__device__ __forceinline__ int schedule_slot(int r, int n_envs, int per_wg) {
+    const int e16 = n_envs & ~(per_wg - 1);  // the last, partial workgroup: as ranked
+    if (r < per_wg || r >= e16) return r;
+    r -= per_wg;
+    const int G = (e16 - per_wg) >> 2;       // groups of four (one SIMD / one workgroup each) among the other full workgroups
+    const int k = r / G, j = r - k * G;
+    const int g = (k & 1) ? G - 1 - j : j;   // snake: quarters 0 and 2 ascending, 1 and 3 descending
+    const int kk = 3 - k;                    // (the heaviest quartile goes to the SIMDs' first -- oldest -- waves, see rollout_body)
+    return per_wg + (per_wg == 16 ? (g >> 2) * 16 + kk * 4 + (g & 3)      // workgroup 1 + g / 4, SIMD g % 4, the SIMD's kk-th wave
+                                  : g * 4 + kk);                          // workgroup 1 + g, its kk-th env (its waves 4 kk .. 4 kk + 3: one per SIMD)
+}
+// The counting sort by ONE workgroup of 1024 threads (hist: kWave + 2 ints of LDS; all 16 waves call it together): as a launch
+// of its own (k_schedule) and at the start of workgroup 0 of a rollout launch (rollout_body).
+__device__ __forceinline__ void schedule_envs_by_workgroup(int* hist, int tid, int n_envs, const int* __restrict__ loads,
+                                                           int* __restrict__ perm, int per_wg, int unit) {
+    if (tid < kWave + 2) hist[tid] = 0;
+    __syncthreads();
+    for (int e = tid; e < n_envs; e += 1024) atomicAdd(&hist[schedule_bin(loads[e], unit)], 1);
+    __syncthreads();
+    if (tid < kWave) {                       // exclusive prefix over the 65 bins (bin 64 = everything at or above 64)
+        const int v = hist[tid];
+        const int incl = wave_inclusive_scan(v);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        hist[tid] = incl - v;
+        if (tid == kWave - 1) hist[kWave] = incl;
+    }
+    __syncthreads();
+    for (int e = tid; e < n_envs; e += 1024) {
+        const int r = atomicAdd(&hist[schedule_bin(loads[e], unit)], 1);   // rank by load, ascending
+        perm[schedule_slot(r, n_envs, per_wg)] = e;
+    }
 }
 
 // Pace keeping of the CU-wide workgroups: a wave publishes its step counter and takes as priority the number of its
@@ -466,16 +530,34 @@ __device__ __forceinline__ void rollout_body(
     typename F::Smem& sm, const Params& p, int n_steps, const float2* __restrict__ actions, float2* __restrict__ actions_out,
     float* __restrict__ slab_out, evac_episode_stats_t* __restrict__ final_stats, int capture_envs,
     float* __restrict__ capture, const float* __restrict__ noise_in, const int* __restrict__ perm = nullptr,
-    int* __restrict__ moving_out = nullptr) {
+    int* __restrict__ moving_out = nullptr, const int* __restrict__ deal_loads = nullptr, int* __restrict__ deal_perm = nullptr) {
     typename F::Ctx w(sm);
     if (w.env >= p.n_envs) return;
-    // the schedule of the CU-wide workgroups (k_schedule): which env this wave carries; any permutation gives the same results
+    // the schedule of the CU-wide workgroups: which env this wave carries; any permutation gives the same results
+    const int my_slot = w.env;
     if (perm) w.env = __builtin_amdgcn_readfirstlane(perm[w.env]);
     F::init(w);
     const bool active = w.i < p.n_ped;
     Ped q;
     Env e;
     load_env(p, w.env, w.i, active, q, e);
+    // THE DEAL OF THE NEXT LAUNCH IS MADE INSIDE THIS ONE, by workgroup 0 before it starts stepping: it carries the lightest
+    // envs of the batch (schedule_slot), which are done 20-30 % before the launch ends (tools/step_times.py) -- the ~3 us of the
+    // sort disappear in that slack.  It sorts by the loads the PREVIOUS launch left (complete, unlike this launch's) into the
+    // permutation buffer this launch does not read.  A launch of its own for the sort costs 6.5 us next to a 45 us rollout
+    // launch, so rounds 2-3 dealt only every 50-200 env steps; a fresh deal is worth 3 us per launch late in an episode
+    // (profiles/r04_b_c2_schedule_frequency.txt).  (Tried and dropped: one light wave sorting at the END of the launch -- 6 us
+    // on every launch's tail; every env drawing a ticket with a global atomic -- 4096 atomics on a handful of addresses, 48 us.)
+    // Right after a reset every env is as heavy as every other: workgroup 0 has no slack to hide the sort in (+3.5 us on those
+    // launches), and no deal is better than another -- so it deals only once its lightest env (slot 0 of the deal at hand) is
+    // down to three quarters of the pedestrians, and otherwise leaves the other buffer's older permutation in place.
+    if constexpr (F::kPace) {
+        if (deal_perm && blockIdx.x == 0) {    // (workgroup-uniform; the host passes deal_perm only for batches of >= one full workgroup)
+            const int lightest = deal_loads[perm[0]];
+            if (4 * lightest <= 3 * p.n_ped)
+                schedule_envs_by_workgroup(sm.deal_hist, (int)threadIdx.x, p.n_envs, deal_loads, deal_perm, F::kEnvsPerBlock, F::WPE == 1 ? 1 : 4);
+        }
+    }
     const uint32_t gid = p.env_id_offset + (uint32_t)w.env;
     const size_t E = (size_t)p.n_envs;
     const int row = p.obs_dim + 3;
@@ -704,7 +786,7 @@ __device__ __forceinline__ void rollout_body(
     if constexpr (F::kEnvBarrier) {               // (multi-wave envs: the load is the column count the last reduction delivered)
         if (moving_out && w.owner) moving_out[w.env] = w.have_next ? w.next_cols : p.n_ped;
     }
-    if constexpr (F::kThreadsPerEnv == kWave) {   // what k_schedule sorts the envs of the next launches by
+    if constexpr (F::kThreadsPerEnv == kWave) {   // what the envs of the next launches are dealt by
         if (moving_out) {   // the length of the env's pair loop: its moving pedestrians, or 0 if no row needs evaluating
             const int nm = ballot(needs_row(p, q.st)) != 0ull ? wave_count((unsigned)(q.st - kViscek) < 3u) : 0;
             if (w.owner) moving_out[w.env] = nm;
@@ -719,9 +801,11 @@ __device__ __forceinline__ void rollout_body(
 template <class F, bool GRAV>
 __global__ __launch_bounds__(F::kBlock, 4) void k_rollout(
     Params p, int n_steps, const float2* __restrict__ actions, float* __restrict__ slab_out,
-    evac_episode_stats_t* __restrict__ final_stats, const int* __restrict__ perm, int* __restrict__ moving_out) {
+    evac_episode_stats_t* __restrict__ final_stats, const int* __restrict__ perm, int* __restrict__ moving_out,
+    const int* __restrict__ deal_loads, int* __restrict__ deal_perm) {
     __shared__ typename F::Smem sm;
-    rollout_body<F, GRAV, false>(sm, p, n_steps, actions, nullptr, slab_out, final_stats, 0, nullptr, nullptr, perm, moving_out);
+    rollout_body<F, GRAV, false>(sm, p, n_steps, actions, nullptr, slab_out, final_stats, 0, nullptr, nullptr, perm, moving_out,
+                                 deal_loads, deal_perm);
 }
 
 // The same kernel specialised for the reference's default configuration (what its training scripts and the benchmark run):
@@ -733,49 +817,24 @@ __global__ __launch_bounds__(F::kBlock, 4) void k_rollout(
 template <class F, bool GRAV>
 __global__ __launch_bounds__(F::kBlock, 4) void k_rollout_default_config(
     Params p, int n_steps, const float2* __restrict__ actions, float* __restrict__ slab_out,
-    evac_episode_stats_t* __restrict__ final_stats, const int* __restrict__ perm, int* __restrict__ moving_out) {
+    evac_episode_stats_t* __restrict__ final_stats, const int* __restrict__ perm, int* __restrict__ moving_out,
+    const int* __restrict__ deal_loads, int* __restrict__ deal_perm) {
     __shared__ typename F::Smem sm;
     const Params q = default_config_constants<GRAV>(p);
-    rollout_body<F, GRAV, false>(sm, q, n_steps, actions, nullptr, slab_out, final_stats, 0, nullptr, nullptr, perm, moving_out);
+    rollout_body<F, GRAV, false>(sm, q, n_steps, actions, nullptr, slab_out, final_stats, 0, nullptr, nullptr, perm, moving_out,
+                                 deal_loads, deal_perm);
 }
 
-// The schedule of the CU-wide rollout workgroups: envs sorted by the pedestrians still moving (the length of their pair
-// loop, as the previous launch left it in `moving`) and dealt to the SIMDs in snake order, so that the four envs of every
-// SIMD -- and the sixteen of every CU -- carry about the same load.  A launch lasts as long as its slowest SIMD; with
-// random placement that is 1.25-1.35x the mean load for most of an episode (tools/moving_distribution.py).
-// One workgroup; perm[slot] = env, slot = workgroup * 16 + wave.  Ties are placed in arrival order (LDS atomics): the
-// permutation may differ from run to run, the results cannot.
-// per_wg = 16: one-wave envs (slot = workgroup * 16 + wave, SIMD = wave % 4); per_wg = 4: four-wave envs (slot = workgroup * 4 +
-// env of the workgroup; every SIMD runs one wave of each of the four) -- one env of each load quartile per workgroup.  Loads
-// are binned in 65 steps of `unit` pedestrians.
-__global__ __launch_bounds__(1024) void k_schedule(int n_envs, const int* __restrict__ moving, int* __restrict__ perm, int per_wg, int unit) {
+// The same deal as a launch of its own (one workgroup): the first deal of a handle, and evac_reschedule.
+// (perm_other: the second permutation buffer of the schedule, brought to the same deal -- a rollout launch that skips its own
+// deal leaves whatever that buffer holds to the launch after it)
+__global__ __launch_bounds__(1024) void k_schedule(int n_envs, const int* __restrict__ moving, int* __restrict__ perm, int* __restrict__ perm_other,
+                                                   int per_wg, int unit) {
     __shared__ int hist[kWave + 2];
-    const int tid = threadIdx.x;
-    if (tid < kWave + 2) hist[tid] = 0;
-    __syncthreads();
-    for (int e = tid; e < n_envs; e += 1024) atomicAdd(&hist[min(max(moving[e] / unit, 0), kWave)], 1);
-    __syncthreads();
-    if (tid < kWave) {                       // exclusive prefix over the 65 bins (bin 64 = everything at or above 64)
-        const int v = hist[tid];
-        const int incl = wave_inclusive_scan(v);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        hist[tid] = incl - v;
-        if (tid == kWave - 1) hist[kWave] = incl;
-    }
-    __syncthreads();
-    const int e16 = n_envs & ~(per_wg - 1), G = e16 >> 2;      // groups of four (one SIMD / one workgroup each) among the full workgroups
-    for (int e = tid; e < n_envs; e += 1024) {
-        const int r = atomicAdd(&hist[min(max(moving[e] / unit, 0), kWave)], 1);   // rank by load, ascending
-        int slot = r;
-        if (r < e16) {
-            const int k = r / G, j = r - k * G;
-            const int g = (k & 1) ? G - 1 - j : j;   // snake: quarters 0 and 2 ascending, 1 and 3 descending
-            // (the heaviest quartile goes to the SIMDs' first -- oldest -- waves, see rollout_body)
-            const int kk = 3 - k;
-            slot = per_wg == 16 ? (g >> 2) * 16 + kk * 4 + (g & 3)  // workgroup g / 4, SIMD g % 4, the SIMD's kk-th wave
-                                : g * 4 + kk;                       // workgroup g, its kk-th env (its waves 4 kk .. 4 kk + 3: one per SIMD)
-        }
-        perm[slot] = e;
+    schedule_envs_by_workgroup(hist, (int)threadIdx.x, n_envs, moving, perm, per_wg, unit);
+    if (perm_other) {
+        __syncthreads();                     // (this workgroup's own global stores are visible to it after the barrier)
+        for (int e = threadIdx.x; e < n_envs; e += 1024) perm_other[e] = perm[e];
     }
 }
 template <class F, bool GRAV>

@@ -70,6 +70,7 @@ struct Wave {
         alignas(16) float stage[kEnvsPerBlock][kStageSteps][12];   // rows written as two 16-byte vectors + 1 word
         alignas(16) int progress[kPace ? 16 : 4];                  // kPace: step counter of every wave, [SIMD][wave of the SIMD]
         int pace_sink[kPace ? 16 : 1][kPace ? kWave : 1];           // kPace: where lanes 1..63 of a wave store when lane 0 publishes the counter
+        int deal_hist[kPace ? kWave + 2 : 1];                      // kPace: histogram of workgroup 0's sort of the next launch's envs (rollout_body)
     };
 
     struct Ctx {
@@ -324,7 +325,7 @@ struct Wave {
             constexpr int B = 16;
             if constexpr (!(EVAC_ABLATE & 1)) {
                 // two columns per packed instruction (pair2_accumulate): 3 vector instructions per column instead of 5
-                const f2 XI2 = f2{XI, XI}, YI2 = f2{YI, YI}, r2b2 = f2{r2b, r2b};
+                const f2 P = f2{XI, YI}, r2b2 = f2{r2b, r2b};
                 f2 sx2 = f2{0.0f, 0.0f}, sy2 = f2{0.0f, 0.0f};
                 const f4* __restrict__ txy = tile;             // pair m: (X, X', Y, Y')
                 const f4* __restrict__ tuv = tile + kPairs;    //         (ux, ux', uy, uy')
@@ -335,7 +336,7 @@ struct Wave {
 #pragma unroll
                     for (int k = 0; k < B / 2; ++k) { a[k] = txy[m + k]; u[k] = tuv[m + k]; }
 #pragma unroll
-                    for (int k = 0; k < B / 2; ++k) pair2_accumulate(XI2, YI2, a[k], u[k], r2b2, sx2, sy2);
+                    for (int k = 0; k < B / 2; ++k) pair2_accumulate(P, a[k], u[k], r2b2, sx2, sy2);
                 }
                 // the remainder (4, 8 or 12 columns: n8 is a multiple of 4) in at most two batches, 8 + 4 -- two LDS round trips,
                 // not one per group of 4 (the heaviest envs, 57..60 moving pedestrians, have 12 left: their wave ends the
@@ -345,7 +346,7 @@ struct Wave {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { a[k] = txy[m + k]; u[k] = tuv[m + k]; }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) pair2_accumulate(XI2, YI2, a[k], u[k], r2b2, sx2, sy2);
+                    for (int k = 0; k < 4; ++k) pair2_accumulate(P, a[k], u[k], r2b2, sx2, sy2);
                     m += 4;
                 }
                 if (m < mp) {
@@ -353,7 +354,7 @@ struct Wave {
 #pragma unroll
                     for (int k = 0; k < 2; ++k) { a[k] = txy[m + k]; u[k] = tuv[m + k]; }
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) pair2_accumulate(XI2, YI2, a[k], u[k], r2b2, sx2, sy2);
+                    for (int k = 0; k < 2; ++k) pair2_accumulate(P, a[k], u[k], r2b2, sx2, sy2);
                 }
                 sx = hsum2(sx2);                   // even columns + odd columns
                 sy = hsum2(sy2);
@@ -771,21 +772,21 @@ struct Sub {
         const float XI = q.x * kTileScale, YI = q.y * kTileScale;
         int j = 0;
         // (the same packed two-column form and the same even / odd partial sums as the one-wave-per-env loop: bit-identical dynamics)
-        const f2 XI2 = f2{XI, XI}, YI2 = f2{YI, YI}, r2b2 = f2{kRPed2Big, kRPed2Big};
+        const f2 P = f2{XI, YI}, r2b2 = f2{kRPed2Big, kRPed2Big};
         f2 sx2 = f2{0.0f, 0.0f}, sy2 = f2{0.0f, 0.0f};
         for (; j + 8 <= n4; j += 8) {
             f4 t[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) t[k] = tile[j + k];
 #pragma unroll
-            for (int k = 0; k < 8; k += 2) pair2_accumulate(XI2, YI2, t[k], t[k + 1], r2b2, sx2, sy2);
+            for (int k = 0; k < 8; k += 2) pair2_accumulate(P, t[k], t[k + 1], r2b2, sx2, sy2);
         }
         for (; j < n4; j += 4) {
             f4 t[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
 #pragma unroll
-            for (int k = 0; k < 4; k += 2) pair2_accumulate(XI2, YI2, t[k], t[k + 1], r2b2, sx2, sy2);
+            for (int k = 0; k < 4; k += 2) pair2_accumulate(P, t[k], t[k + 1], r2b2, sx2, sy2);
         }
         if (any_row) {
             sx = sx2.x + sx2.y;

@@ -228,14 +228,14 @@ __device__ __forceinline__ void rollout_body_sub(typename Sub<G>::Smem& sm, cons
 template <int G, bool GRAV>
 __global__ __launch_bounds__(256) void k_rollout_sub(Params p, int n_steps, const float2* __restrict__ actions,
                                                      float* __restrict__ slab_out,
-                                                     evac_episode_stats_t* __restrict__ final_stats, const int*, int*) {
+                                                     evac_episode_stats_t* __restrict__ final_stats, const int*, int*, const int*, int*) {
     __shared__ typename Sub<G>::Smem sm;
     rollout_body_sub<G, GRAV, false>(sm, p, n_steps, actions, nullptr, slab_out, final_stats, 0, nullptr, nullptr);
 }
 template <int G, bool GRAV>
 __global__ __launch_bounds__(256) void k_rollout_default_config_sub(Params p, int n_steps, const float2* __restrict__ actions,
                                                                     float* __restrict__ slab_out,
-                                                                    evac_episode_stats_t* __restrict__ final_stats, const int*, int*) {
+                                                                    evac_episode_stats_t* __restrict__ final_stats, const int*, int*, const int*, int*) {
     __shared__ typename Sub<G>::Smem sm;
     const Params q = default_config_constants<GRAV>(p);
     rollout_body_sub<G, GRAV, false>(sm, q, n_steps, actions, nullptr, slab_out, final_stats, 0, nullptr, nullptr);

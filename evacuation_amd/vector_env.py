@@ -182,7 +182,8 @@ class BatchedEvacuationEnv:
             self.workspace = torch.zeros((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=dev)
             assert self.workspace.data_ptr() % 256 == 0
             _lib.check(self.lib.evac_bind_workspace(self._h, _ptr(self.workspace), C.c_int64(nbytes)), self._h)
-            self.schedule = self.workspace[:8 * E].view(torch.int32).view(2, E)     # moving[E] | perm[E]
+            if nbytes >= 16 * E:
+                self.schedule = self.workspace[:16 * E].view(torch.int32).view(4, E)    # moving[2][E] | perm[2][E] (include/evac.h)
         # step outputs (reused every step; callers that keep them must clone, like the reference's
         # live-reference observations, env.py:98-104)
         self.obs = torch.zeros((E, self.obs_dim), dtype=torch.float32, device=dev)
@@ -225,6 +226,21 @@ class BatchedEvacuationEnv:
         snapshot of state + workspace before its kernel-time replays, so that they run under the deal the timed blocks had."""
         if self.workspace is not None:
             _lib.check(self.lib.evac_reschedule(self._h, self._stream()), self._h)
+
+    def schedule_generation(self) -> int:
+        """Rollout launches made under the load schedule so far (-1: none): launch g reads ``schedule[2 + (g & 1)]``, leaves its
+        loads in ``schedule[g & 1]`` and deals ``schedule[2 + ((g + 1) & 1)]`` for the next one."""
+        return int(self.lib.evac_schedule_generation(self._h))
+
+    def schedule_loads(self) -> Optional[torch.Tensor]:
+        """``moving[E]`` as the most recent rollout launch left it (pedestrians still moving per env), or None."""
+        g = self.schedule_generation()
+        return None if self.schedule is None or g < 1 else self.schedule[(g - 1) & 1]
+
+    def schedule_perm(self) -> Optional[torch.Tensor]:
+        """``perm[slot] = env`` that the NEXT rollout launch runs under, or None before the first deal."""
+        g = self.schedule_generation()
+        return None if self.schedule is None or g < 0 else self.schedule[2 + (g & 1)]
 
     def team_error(self) -> int:
         """Non-zero if a barrier of a team rollout (N > 512, few envs) timed out; synchronises."""

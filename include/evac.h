@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define EVAC_VERSION 131          /* 0.1.3 + evac_peer_gather */
+#define EVAC_VERSION 140          /* 0.1.4: the deal of the next launch made inside the rollout kernel, evac_schedule_generation */
 #define EVAC_MAX_PEDESTRIANS 1024 /* one workgroup (<=16 waves) per env */
 
 typedef enum evac_status {
@@ -186,9 +186,12 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions_or_null,
 /* Optional workspace of evac_rollout (no reference analogue: the reference steps its envs one after another,
  * rpo_agent.py:123-126).  `workspace`: evac_workspace_bytes(h) bytes on the device, 256-byte aligned, ZERO-INITIALISED by the
  * caller, alive and used on one stream at a time like the state buffers.  It holds
- *   - the rollout schedule of large batches of one-wave envs (>= 16 envs per CU): moving[E] | perm[E] int32 -- every launch
- *     leaves the pedestrians still moving of each env in moving[] and, every 50 to 200 env steps, the envs are re-dealt to the
- *     SIMDs by that load;
+ *   - the rollout schedule of large batches of one-wave envs (>= 16 envs per CU; four-wave envs: >= 4 per CU):
+ *     moving[2][E] | perm[2][E] int32 -- rollout launch g of the handle runs its envs in the order perm[g & 1], leaves the
+ *     pedestrians still moving of each env in moving[g & 1] and, inside the same launch (its first workgroup, which carries the
+ *     lightest envs, before it starts stepping), deals the envs to the SIMDs for launch g + 1 by the loads launch g - 1 left:
+ *     perm[(g + 1) & 1].  evac_schedule_generation returns g (the number of such launches so far; -1: no schedule, or no deal
+ *     yet).  A launch captured into a hipGraph runs under the deal at hand and deals nothing;
  *   - the exchange areas of the team kernels (513..1024 pedestrians, few envs: 2 / 4 / 8 / 16 workgroups per env).
  * Performance devices only: results are bit-identical with and without the workspace.  NULL unbinds.
  *
@@ -202,10 +205,11 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions_or_null,
  * evac_team_error: synchronises the device, then reports the error word (non-zero: the outputs of an earlier launch are void). */
 int64_t evac_workspace_bytes(evac_handle_t h);
 int evac_bind_workspace(evac_handle_t h, void* workspace_or_null, int64_t bytes);
-/* Deal the envs to the SIMDs NOW by the loads the workspace holds (what evac_rollout does by itself every 50 to 200 env steps):
- * for callers that restored a state + workspace snapshot and want the next launch to run under that deal.  No-op without a
- * schedule. */
+/* Deal the envs to the SIMDs NOW (a launch of its own) by the most recent loads the workspace holds, moving[(g - 1) & 1], into
+ * the permutation the next rollout launch reads: for callers that restored a state + workspace snapshot and want the next
+ * launch to run under that deal.  No-op without a schedule. */
 int evac_reschedule(evac_handle_t h, void* stream);
+int32_t evac_schedule_generation(evac_handle_t h);
 int evac_team_error(evac_handle_t h, int32_t* out);
 int evac_team_clear_error(evac_handle_t h);
 

@@ -48,6 +48,7 @@ class _ReferenceRolloutLoop:
         next_obs, _ = self.envs.reset(seed=self.cfg.seed)
         next_obs = torch.Tensor(next_obs).to(self.device)
         next_done = torch.zeros(self.cfg.num_envs).to(self.device)
+        self.reset_obs = next_obs.clone()
 
         for update in range(1, self.cfg.num_updates + 1):
             for step in range(0, self.cfg.num_steps):
@@ -96,7 +97,7 @@ def test_the_reference_trainers_rollout_lines_run_verbatim(normalize, capsys):
     else:
         twin = ea.BatchedEvacuationEnv(dataclasses.replace(cfg, clip_action=True), wrap, num_envs=E, seed=seed)
     o, _ = twin.reset(seed=1)
-    assert torch.equal(obs_buf[0], o), "reset observation"
+    assert torch.equal(loop.reset_obs, o), "reset observation"
     n_final = 0
     for t in range(T):
         o, r, te, tr, infos = twin.step(script[t].cuda())

@@ -1,4 +1,5 @@
-"""The CU-wide rollout workgroups and their load schedule (evac_bind_workspace, k_schedule) are performance devices:
+"""The CU-wide rollout workgroups and their load schedule (evac_bind_workspace; the deal of the next launch made inside
+the rollout kernel, k_schedule for the first one and for evac_reschedule) are performance devices:
 which wave carries which env, and with which issue priority, must not change a single bit of the results."""
 import os
 
@@ -50,7 +51,7 @@ def test_cu_wide_scheduled_rollout_is_bit_identical(ea, n, E, wrap_kw):
     for env in (ref, wide, sched):
         env.reset()
     outs = [[], [], []]
-    for chunk in (30, 60, 25, 60):                                        # the schedule is rebuilt every 50 env steps; episodes end inside
+    for chunk in (30, 60, 25, 60):                                        # every launch deals the next one's envs; episodes end inside
         for k, env in enumerate((ref, wide, sched)):
             r = env.rollout(chunk)
             outs[k].append({key: r[key].clone() for key in ("obs", "reward", "terminated", "truncated", "episode_stats")})
@@ -67,43 +68,59 @@ def test_cu_wide_scheduled_rollout_is_bit_identical(ea, n, E, wrap_kw):
         sb = env.get_state()
         for key in sa:
             assert torch.equal(sa[key], sb[key]), key
-    # the schedule is a permutation of the envs, heaviest and lightest envs sharing SIMDs
-    perm = sched.schedule[1].cpu().numpy()
-    assert sorted(perm.tolist()) == list(range(E))
-    moving = sched.schedule[0].cpu().numpy()
+    # the schedule is a permutation of the envs (both buffers: the one the last launch ran under, the one it dealt)
+    assert sched.schedule_generation() == 4
+    for buf in (2, 3):
+        assert sorted(sched.schedule[buf].cpu().numpy().tolist()) == list(range(E))
+    moving = sched.schedule_loads().cpu().numpy()
     st = sa["status"].cpu().numpy()
-    assert (moving == ((st >= 1) & (st <= 3)).sum(1)).all()               # what the last launch left behind
+    if n <= 64:     # (one-wave envs: the length of the pair loop -- the moving pedestrians, or 0 without a row to evaluate)
+        rows = ((st == 1) | ((st == 2) & (cfg.enslaving_degree != 1.0))).any(1)
+        assert (moving == np.where(rows, ((st >= 1) & (st <= 3)).sum(1), 0)).all()       # what the last launch left behind
+    else:
+        assert (moving == ((st >= 1) & (st <= 3)).sum(1)).all()
     for env in (ref, wide, sched):
         env.close()
 
 
 def test_schedule_balances_simd_groups(ea):
-    """k_schedule on the loads a real episode produces: every group of four SIMD-mates (waves w, w+4, w+8, w+12 of a
+    """The deal (made inside the rollout kernel, and by k_schedule) on the loads a real episode produces: every group of four SIMD-mates (waves w, w+4, w+8, w+12 of a
     workgroup) gets one env of each load quartile, and the heaviest SIMD is lighter than with random placement."""
     import torch
     E = 4096
     cfg = ea.EnvConfig(number_of_pedestrians=60)
     env = _make(ea, cfg, ea.EnvWrappersConfig(positions="grav"), E, 1, cu_wide=True, schedule=True)
     env.reset()
-    for _ in range(6):
-        env.rollout(100)
+    for _ in range(15):                                                    # launches of < 50 steps deal the next launch's envs themselves
+        env.rollout(40)
     torch.cuda.synchronize()
-    load = env.schedule[0].cpu().numpy().copy()                            # pedestrians still moving, per env, at t = 600
+    assert env.schedule_generation() == 15
+    load = env.schedule_loads().cpu().numpy().copy()                       # pedestrians still moving, per env, at t = 600
+    prev = env.schedule[(15 - 2) & 1].cpu().numpy().copy()                 # ... and at t = 560: what launch 14 dealt launch 15's envs by
     assert load.min() >= 0 and load.max() <= 60 and load.std() > 3
-    env.rollout(1)                                                         # >= 50 steps since the last schedule: re-sorted by `load`
+    dealt_in_kernel = env.schedule_perm().cpu().numpy().copy()             # the deal launch 14 made for launch 15 (workgroup 0, at its start)
+    _check_deal(dealt_in_kernel, prev, E)
+    env.rebind_workspace()                                                 # evac_reschedule: the same deal from the latest loads, now
     torch.cuda.synchronize()
-    perm = env.schedule[1].cpu().numpy()
+    perm = env.schedule_perm().cpu().numpy()
+    _check_deal(perm, load, E)
+    env.close()
+
+
+def _check_deal(perm, load, E):
     assert sorted(perm.tolist()) == list(range(E))
-    slot_load = load[perm].reshape(E // 16, 4, 4)                          # [workgroup][k-th wave of the SIMD][SIMD]
+    by_slot = load[perm]
+    q = np.sort(load)
+    assert by_slot[:16].max() <= q[15]                                     # workgroup 0 (it deals the next launch first): the 16 lightest envs
+    slot_load = by_slot[16:].reshape(E // 16 - 1, 4, 4)                    # the others: [workgroup][k-th wave of the SIMD][SIMD]
     sums = slot_load.sum(1)                                                # per SIMD
     rng = np.random.default_rng(0)
     rand = load[rng.permutation(E)].reshape(-1, 4).sum(1)
     assert sums.max() < rand.max() and sums.max() - sums.min() < 0.5 * (rand.max() - rand.min())
-    q = np.sort(load)
+    q, n = q[16:], E - 16
     for k in range(4):                                                     # one env per quartile in every SIMD ...
-        lo, hi = q[k * E // 4], q[(k + 1) * E // 4 - 1]
+        lo, hi = q[k * n // 4], q[(k + 1) * n // 4 - 1]
         assert ((slot_load[:, 3 - k, :] >= lo) & (slot_load[:, 3 - k, :] <= hi)).all()   # ... the heaviest in the SIMD's first (oldest) wave
-    env.close()
 
 
 @pytest.mark.parametrize("n,E,cu_wide,box", [(60, 333, False, False), (60, 333, True, False), (10, 500, False, False), (30, 200, False, True),
