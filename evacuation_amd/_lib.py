@@ -57,6 +57,7 @@ SIGNATURES = {
     "evac_reschedule": (C.c_int, [_P, _P]),
     "evac_schedule_generation": (C.c_int32, [_P]),
     "evac_team_error": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "evac_team_error_nosync": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "evac_team_clear_error": (C.c_int, [_P]),
     "evac_peer_gather": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "evac_reset": (C.c_int, [_P, _P, _P, _P, _P]),

@@ -15,7 +15,10 @@ DEPENDS = SOURCES + [os.path.join(CSRC, f) for f in ("evac_common.h", "evac_fami
 ARCH = "gfx950"
 # -ffp-contract=off: fused multiply-adds are written explicitly in the kernels, so the f32 arithmetic
 # is the same IEEE operation sequence as the NumPy f32 oracle wherever both use the same formula.
-FLAGS = ["-O3", f"--offload-arch={ARCH}", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"]
+# -fno-slp-vectorize: the packed-f32 arithmetic of the kernels is written explicitly (v_pk_* through vector types and inline
+# asm); what the SLP vectoriser adds on top are pairs built with v_mov shuffles around scalar code (-1 % at C2, A/B in
+# profiles/r04_a_c2_ab_tile_layout_salu_diet_driver_args.txt: lib_v1 / lib_v1n).
+FLAGS = ["-O3", f"--offload-arch={ARCH}", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared"]
 
 
 def hipcc_path() -> str:

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 
@@ -23,7 +24,7 @@ struct DeviceGuard {
     int prev = -1;
     bool switched = false;
     explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+        if (dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
     }
     ~DeviceGuard() {
         if (switched) (void)hipSetDevice(prev);
@@ -157,6 +158,17 @@ int waves_per_env(int n_ped) { return n_ped <= 64 ? 1 : (n_ped <= 128 ? 2 : (n_p
 
 
 // ---- team rollouts (evac_team.h): which kernel, how many workgroups, and do they all fit the device at once ----
+// ONE team grid at a time per device, process-wide.  The members of a team wait for each other, and team_grid_fits only
+// checks that ONE grid fits the device: two grids in flight (two handles on two streams -- train and eval envs --, a graph replay
+// beside a live launch) can each be dispatched in part, every resident member polling in place on a CU the other grid's missing
+// members need -- both time out.  So every team launch first waits (on the device, hipStreamWaitEvent) for the event the
+// previous team launch on that device recorded behind itself, whatever stream or handle it came from.  A launch under stream
+// capture cannot join the chain (an event recorded outside the capture); a graph holding team launches must not be replayed
+// beside another team launch.  Other PROCESSES on the same GPU are out of reach: they need EVAC_TEAM=0.
+constexpr int kMaxDevices = 64;
+std::mutex g_team_chain_lock;
+hipEvent_t g_team_chain[kMaxDevices] = {};
+
 const void* team_kernel(const evac_handle* h) {
     const bool grav = h->p.obs_pos == EVAC_POS_GRAV, dflt = h->default_cfg;
 #define EVAC_TEAM_FN(K_)                                                                                                          \
@@ -461,6 +473,8 @@ int evac_bind_workspace(evac_handle_t h, void* workspace, int64_t bytes) {
         h->p.team_tile = base + w.team_tile;
         h->team_xchg_bytes = w.team_xchg_end - w.team_rec;
         h->team_bound = true;
+        DeviceGuard g(h->device);
+        (void)team_grid_fits(h);                      // (so that evac_kernel_variant names the path the first rollout will take)
     }
     return EVAC_OK;
 }
@@ -499,6 +513,10 @@ int evac_peer_gather(const float* src, int64_t rows, int32_t row_words, int32_t 
         if (!peer_dst[r]) return EVAC_ERR_INVALID_ARGUMENT;
         pp.dst[r] = peer_dst[r];
     }
+    hipPointerAttribute_t attr;                       // (no handle: the kernel must run on the device that owns the slab)
+    int src_dev = -1;
+    if (hipPointerGetAttributes(&attr, src) == hipSuccess) src_dev = attr.device; else (void)hipGetLastError();
+    DeviceGuard g(src_dev);
     const unsigned n = (unsigned)(rows * take_words);
     int w = wgs_per_peer > 0 ? wgs_per_peer : 8;
     const int need = (int)((n + 1023u) / 1024u);                 // (no more workgroups than 1024-element pieces)
@@ -522,6 +540,12 @@ int evac_team_error(evac_handle_t h, int32_t* out) {
     DeviceGuard g(h->device);
     if (hipDeviceSynchronize() != hipSuccess) return fail(h, EVAC_ERR_HIP, "evac_team_error: hipDeviceSynchronize failed");
     *out = (int32_t)*h->team_flag_host;
+    return EVAC_OK;
+}
+
+int evac_team_error_nosync(evac_handle_t h, int32_t* out) {
+    if (!h || !out) return EVAC_ERR_INVALID_ARGUMENT;
+    *out = h->team_flag_host ? (int32_t)*h->team_flag_host : 0;
     return EVAC_OK;
 }
 
@@ -613,12 +637,24 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
         void* argv[] = {(void*)&h->p, (void*)&n_steps_, (void*)&actions_, (void*)&slab_out, (void*)&final_stats, (void*)&perm_, (void*)&moving_,
                         (void*)&perm_, (void*)&moving_};
         const void* fn = team_kernel(h);
+        hipStreamCaptureStatus tcap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s_, &tcap) != hipSuccess) { (void)hipGetLastError(); tcap = hipStreamCaptureStatusNone; }
+        const bool chained = tcap == hipStreamCaptureStatusNone && h->device >= 0 && h->device < kMaxDevices;
+        std::unique_lock<std::mutex> chain(g_team_chain_lock, std::defer_lock);
+        if (chained) {                               // (see g_team_chain: the previous team grid of this device has drained)
+            chain.lock();
+            hipEvent_t& ev = g_team_chain[h->device];
+            if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev = nullptr; }
+            if (ev && hipStreamWaitEvent(s_, ev, 0) != hipSuccess) (void)hipGetLastError();      // (a never-recorded event: no wait)
+        }
         hipError_t le = h->team_coop ? hipLaunchCooperativeKernel(fn, grid, block, argv, 0, s_) : hipLaunchKernel(fn, grid, block, argv, 0, s_);
         if (le != hipSuccess && h->team_coop) {      // (e.g. under stream capture): the occupancy check still holds for a plain launch
             (void)hipGetLastError();
             h->team_coop = false;
             le = hipLaunchKernel(fn, grid, block, argv, 0, s_);
         }
+        if (chained && g_team_chain[h->device] && le == hipSuccess && hipEventRecord(g_team_chain[h->device], s_) != hipSuccess) (void)hipGetLastError();
+        if (chained) chain.unlock();
         if (le != hipSuccess) return fail(h, EVAC_ERR_HIP, std::string("evac_rollout (team launch): ") + hipGetErrorString(le));
     } else if (h->cu_wide || h->cu_wide4) {
         // one-wave envs, batch >= 16 envs per CU (or four-wave envs, >= 4 per CU): CU-wide workgroups, envs dealt to the SIMDs by

@@ -173,26 +173,34 @@ class PeerStoreGather:
         self._C = C
 
     def _enable_peer_access(self) -> None:
-        """The stores come from THIS device's kernel: it needs access to the devices that own the mapped buffers (best effort:
-        'already enabled' and single-device test setups are fine; a missing link shows up in self_test)."""
+        """The stores come from THIS device's kernel: it needs access to the devices that own the mapped buffers.
+        hipDeviceEnablePeerAccess must succeed (or report that access is enabled already) for every such device -- a store to a
+        peer without access faults the GPU, so anything else is an error here, not something for self_test to find."""
         import ctypes as C
         mine = self.slab.device.index
         others = sorted({p.device.index for p in self.peers} - {mine})
         if not others:
             return
-        try:
-            hip = C.CDLL("libamdhip64.so")
-            with torch.cuda.device(mine):
-                for d in others:
-                    hip.hipDeviceEnablePeerAccess(C.c_int(d), C.c_uint(0))
-                hip.hipGetLastError()
-        except OSError:
-            pass
+        hip = C.CDLL("libamdhip64.so")               # (OSError propagates: PyTorch-ROCm has loaded this library already)
+        hip.hipDeviceEnablePeerAccess.restype = C.c_int
+        hip.hipGetErrorString.restype = C.c_char_p
+        HIP_SUCCESS, HIP_ERROR_PEER_ACCESS_ALREADY_ENABLED = 0, 704
+        with torch.cuda.device(mine):
+            for d in others:
+                rc = hip.hipDeviceEnablePeerAccess(C.c_int(d), C.c_uint(0))
+                if rc == HIP_ERROR_PEER_ACCESS_ALREADY_ENABLED:
+                    hip.hipGetLastError()            # (clear the sticky error)
+                elif rc != HIP_SUCCESS:
+                    msg = hip.hipGetErrorString(C.c_int(rc))
+                    raise RuntimeError(f"PeerStoreGather: hipDeviceEnablePeerAccess(device {d}) from device {mine} failed with "
+                                       f"{rc} ({msg.decode() if msg else '?'}): no peer stores to that rank")
 
     def issue(self, stream=None) -> None:
-        st = stream if stream is not None else torch.cuda.current_stream(self.slab.device)
-        rc = self._lib.evac_peer_gather(self._src, self.rows, self.row_words, self.take, self._ptrs, self.world, self.rank, self.wgs,
-                                        self._C.c_void_p(st.cuda_stream))
+        # (evac_peer_gather takes no handle and launches on the CURRENT device: make it the slab's, whatever the caller has current)
+        with torch.cuda.device(self.slab.device):
+            st = stream if stream is not None else torch.cuda.current_stream(self.slab.device)
+            rc = self._lib.evac_peer_gather(self._src, self.rows, self.row_words, self.take, self._ptrs, self.world, self.rank, self.wgs,
+                                            self._C.c_void_p(st.cuda_stream))
         if rc != 0:
             raise RuntimeError(f"evac_peer_gather failed with status {rc}")
 
@@ -231,11 +239,14 @@ class ShardedEvacuationEnv:
     shard with a BatchedEvacuationEnv and the packed outputs are all-gathered."""
 
     def __init__(self, env_config, wrap_config=None, total_envs: int = 1, device=None, seed: int = 0, group=None,
-                 autoreset: bool = True):
+                 autoreset: bool = True, force_collective: bool = False):
+        """``force_collective``: run the collective (comm stream, event hand-off, ``all_gather_into_tensor``) also in a group of
+        ONE rank -- the multi-GPU code path exercised on a single GPU (tests/test_gpu_rccl_world1.py)."""
         from .vector_env import BatchedEvacuationEnv
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.collective = self.world_size > 1 or (bool(force_collective) and dist.is_initialized())
         self.total_envs = int(total_envs)
         self.offset, self.local_envs = shard_range(self.total_envs, self.rank, self.world_size)
         if device is None:
@@ -243,7 +254,7 @@ class ShardedEvacuationEnv:
         self.local = BatchedEvacuationEnv(env_config, wrap_config, num_envs=self.local_envs, device=device, seed=seed,
                                           env_id_offset=self.offset, autoreset=autoreset)
         self.obs_dim = self.local.obs_dim
-        self.comm_stream = torch.cuda.Stream(device=self.local.device) if self.world_size > 1 else None
+        self.comm_stream = torch.cuda.Stream(device=self.local.device) if self.collective else None
 
     def reset(self, **kw):
         return self.local.reset(**kw)
@@ -255,7 +266,7 @@ class ShardedEvacuationEnv:
         if not gather:
             return obs, rew, term, trunc, info, None
         slab = pack_outputs(obs, rew, term, trunc)
-        if self.world_size == 1:
+        if not self.collective:
             return obs, rew, term, trunc, info, slab
         g, _ = all_gather_envs(slab, group=self.group)
         return obs, rew, term, trunc, info, gathered_view(g)
@@ -267,7 +278,7 @@ class ShardedEvacuationEnv:
         ``wait``) before reading it.  The gather of chunk k overlaps the compute of chunk k+1."""
         ro = self.local.rollout(n_steps, actions=actions)
         slab = ro["slab"]            # the kernel already wrote the packed [obs | reward | flags] record
-        if self.world_size == 1:
+        if not self.collective:
             return ro, (slab.unsqueeze(0), None)
         compute = torch.cuda.current_stream(self.local.device)
         # the gathered buffer is allocated on the COMPUTE stream (where wait() / gathered_view consume it) and lent to

@@ -242,10 +242,14 @@ class BatchedEvacuationEnv:
         g = self.schedule_generation()
         return None if self.schedule is None or g < 0 else self.schedule[2 + (g & 1)]
 
-    def team_error(self) -> int:
-        """Non-zero if a barrier of a team rollout (N > 512, few envs) timed out; synchronises."""
+    def team_error(self, sync: bool = True) -> int:
+        """Non-zero if a barrier of a team rollout (N > 512, few envs) timed out: the outputs of that launch -- and of the
+        launches queued behind it -- are void.  ``sync=True`` synchronises the device first; ``sync=False`` reads the word as it
+        stands, for a caller that has just waited for its own stream (the pipelined consumer of ``rollout_launcher`` slabs, a
+        hipGraph replay: the enqueueing calls cannot know -- poll this BEFORE trusting a slab)."""
         v = C.c_int32(0)
-        _lib.check(self.lib.evac_team_error(self._h, C.byref(v)), self._h)
+        fn = self.lib.evac_team_error if sync else self.lib.evac_team_error_nosync
+        _lib.check(fn(self._h, C.byref(v)), self._h)
         return int(v.value)
 
     def team_clear_error(self) -> None:
@@ -412,7 +416,9 @@ class BatchedEvacuationEnv:
     def rollout_launcher(self, n_steps: int, out: TDict, stream=None):
         """A zero-argument callable that enqueues ``rollout(n_steps, out=out)`` (RandomAgent actions) with all ctypes
         arguments prepared once: for loops that launch the same shape many times.  On the stream that is current at
-        each call, or always on ``stream`` (a torch stream) if one is given -- which saves the lookup, ~1.5 us per call."""
+        each call, or always on ``stream`` (a torch stream) if one is given -- which saves the lookup, ~1.5 us per call.
+        The call only ENQUEUES: for rooms of more than 512 pedestrians (team kernels) poll ``team_error(sync=False)`` after waiting
+        for the launch and before consuming its slab -- a launch that lost a team member still returns success here."""
         T, E, D = int(n_steps), self.num_envs, self.obs_dim
         slab = self._check_tensor(out["slab"], (T, E, D + 3), torch.float32, "slab")
         stats = out.get("episode_stats")

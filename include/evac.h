@@ -202,7 +202,15 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions_or_null,
  * host-mapped memory, the one thing besides the config the library allocates -- is raised.  Every later call on the handle
  * (evac_reset / evac_step* / evac_rollout / evac_observe / evac_get_state / evac_set_state) then returns EVAC_ERR_TEAM_ABORTED
  * without touching the device, until evac_team_clear_error(); the handle uses one workgroup per env from then on.
- * evac_team_error: synchronises the device, then reports the error word (non-zero: the outputs of an earlier launch are void). */
+ * evac_team_error: synchronises the device, then reports the error word (non-zero: the outputs of an earlier launch are void).
+ * evac_team_error_nosync: the same word as it stands, without synchronising -- for a caller that has just waited for its
+ * stream itself (a pipelined consumer of rollout slabs: wait for the launch, read the word, THEN trust the slab; a launch
+ * that aborts returns EVAC_OK when it is enqueued, and so do the launches queued behind it, and a hipGraph replay goes past
+ * every host-side check).
+ * Team grids of one device run ONE AT A TIME, whatever handles and streams they come from (a device-side wait on the previous
+ * team launch's event): two grids in flight could each be resident in part and wait for CUs the other holds.  Launches under
+ * stream capture cannot join that chain -- do not replay a graph with team launches beside another team launch; and another
+ * PROCESS sharing the GPU is out of reach: run it with EVAC_TEAM=0. */
 int64_t evac_workspace_bytes(evac_handle_t h);
 int evac_bind_workspace(evac_handle_t h, void* workspace_or_null, int64_t bytes);
 /* Deal the envs to the SIMDs NOW (a launch of its own) by the most recent loads the workspace holds, moving[(g - 1) & 1], into
@@ -211,6 +219,7 @@ int evac_bind_workspace(evac_handle_t h, void* workspace_or_null, int64_t bytes)
 int evac_reschedule(evac_handle_t h, void* stream);
 int32_t evac_schedule_generation(evac_handle_t h);
 int evac_team_error(evac_handle_t h, int32_t* out);
+int evac_team_error_nosync(evac_handle_t h, int32_t* out);
 int evac_team_clear_error(evac_handle_t h);
 
 /* The all-gather of the returned observation batch across the ranks of an env-sharded run (BASELINE.json north_star; the

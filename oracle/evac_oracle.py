@@ -405,3 +405,25 @@ def threshold_margin(pos: np.ndarray, agent_pos: np.ndarray, pre_pos: Optional[n
         if len(iu[0]):
             m = min(m, float(np.min(np.abs(dm[iu] - R_PEDESTRIAN))))
     return m
+
+
+def threshold_margins_per_pedestrian(pos: np.ndarray, agent_pos: np.ndarray, pre_pos: np.ndarray, width: float = 1.0,
+                                     height: float = 1.0, status: Optional[np.ndarray] = None) -> np.ndarray:
+    """`threshold_margin` resolved per pedestrian: the smallest |distance - radius| over the comparisons that involve pedestrian
+    i (its status and wall tests on the post-step position, its pairs in the neighbour test on the pre-step positions).  In a
+    teacher-forced single step a comparison of pedestrian i can only change i's own row, position and status -- and, through
+    the status counts, the env-level outputs (rewards, gravity observation)."""
+    p64 = np.asarray(pos, dtype=np.float64)
+    n = p64.shape[0]
+    m = np.full(n, np.inf)
+    for dest, rad in ((agent_pos, R_LEADER), (EXIT_POSITION, R_EXIT), (EXIT_POSITION, R_ESCAPE)):
+        d = pairwise_distance(p64, np.asarray(dest, dtype=np.float64)[None, :], np.float64)[:, 0]
+        m = np.minimum(m, np.abs(d - rad))
+    free = np.ones(n, bool) if status is None else (np.asarray(status) != ESCAPED)
+    wall = np.minimum(np.abs(np.abs(p64[:, 0]) - width), np.abs(np.abs(p64[:, 1]) - height))
+    m = np.where(free, np.minimum(m, wall), m)
+    q = np.asarray(pre_pos, dtype=np.float64)
+    dm = np.abs(pairwise_distance(q, q, np.float64) - R_PEDESTRIAN)
+    np.fill_diagonal(dm, np.inf)
+    return np.minimum(m, dm.min(axis=1)) if n > 1 else m
+

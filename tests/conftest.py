@@ -17,3 +17,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_terminal_summary(terminalreporter):
+    """The near-tie exclusions of the teacher-forced parity test, per fixture (a silent growth must be visible)."""
+    import sys
+    mod = sys.modules.get("test_gpu_parity") or sys.modules.get("tests.test_gpu_parity")
+    log = getattr(mod, "TIE_LOG", None)
+    if log:
+        terminalreporter.write_sep("-", "near-tie exclusions (steps of a fixture whose env-level outputs were skipped; pedestrians left out)")
+        for label, n, ties, peds in log:
+            terminalreporter.write_line(f"  {label:34s} steps {n:4d}  with a near-tie {ties:3d}  pedestrians excluded {peds:3d}")
+

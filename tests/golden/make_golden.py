@@ -295,32 +295,38 @@ def make_crafted(ref):
     print(f"crafted: {len(names)} cases, {os.path.getsize(path)/1024:.0f} KiB")
 
 
-def main():
+def main(argv=None):
+    """`make_golden.py` regenerates every fixture; `make_golden.py NAME [NAME ...]` only the named trajectories / "crafted"."""
+    only = set(sys.argv[1:] if argv is None else argv)
     if not L.reference_available():
         raise SystemExit("reference not found at " + L.REFERENCE_ROOT)
     ref = L.load_full()
+
+    def traj(name, *a, **kw):
+        if not only or name in only:
+            make_trajectory(ref, name, *a, **kw)
     # free-running episodes -- the hyper-parameter values are the ones the reference's sweeps use
-    # (run_scripts: n=60, noise .2/.5, enslaving 1/.5/.1, alpha 2..5)
-    make_trajectory(ref, "traj_n60_s0", 0, 64, obs_every=2, number_of_pedestrians=60, is_new_exiting_reward=True)
-    make_trajectory(ref, "traj_n60_s1_noise05_ens05", 1, 64, obs_every=4, number_of_pedestrians=60, noise_coef=0.5,
-                    enslaving_degree=0.5, intrinsic_reward_coef=1.0)
-    make_trajectory(ref, "traj_n60_s2_ens01", 2, 64, obs_every=4, number_of_pedestrians=60, enslaving_degree=0.1,
-                    is_new_followers_reward=False, init_reward_each_step=0.0)
-    make_trajectory(ref, "traj_n60_s3_step05_trunc", 3, 40, obs_every=4, number_of_pedestrians=60, step_size=0.05,
-                    max_timesteps=40, is_new_exiting_reward=True, intrinsic_reward_coef=1.0)
-    make_trajectory(ref, "traj_n10_s4_long", 4, 400, obs_every=16, number_of_pedestrians=10,
-                    is_new_exiting_reward=True)
-    make_trajectory(ref, "traj_n256_s5", 5, 24, obs_every=4, number_of_pedestrians=256, is_new_exiting_reward=True)
-    make_trajectory(ref, "traj_n256_s6_noise05", 6, 24, obs_every=4, number_of_pedestrians=256, noise_coef=0.5,
-                    enslaving_degree=0.5)
-    make_trajectory(ref, "traj_n1024_s7", 7, 3, obs_every=3, number_of_pedestrians=1024, is_new_exiting_reward=True)
-    make_trajectory(ref, "traj_n1024_s8_noise05_ens05", 8, 2, obs_every=2, number_of_pedestrians=1024, noise_coef=0.5,
-                    enslaving_degree=0.5, intrinsic_reward_coef=1.0)
-    make_trajectory(ref, "traj_n256_s9_ens01_step05", 9, 20, obs_every=10, number_of_pedestrians=256, enslaving_degree=0.1,
-                    step_size=0.05, is_new_exiting_reward=True, intrinsic_reward_coef=1.0)
-    make_trajectory(ref, "traj_n256_s10_noreward", 10, 20, obs_every=10, number_of_pedestrians=256,
-                    is_new_followers_reward=False, init_reward_each_step=0.0, noise_coef=0.05)
-    make_crafted(ref)
+    # (run_scripts: n=60, noise .2/.5, enslaving 1/.5/.1, alpha 2..5); sizes per SURVEY.md 8(c): N in {60, 256} x 64 steps x 4
+    # seeds, N = 1024 x 4 steps x 2 seeds
+    traj("traj_n60_s0", 0, 64, obs_every=2, number_of_pedestrians=60, is_new_exiting_reward=True)
+    traj("traj_n60_s1_noise05_ens05", 1, 64, obs_every=4, number_of_pedestrians=60, noise_coef=0.5,
+         enslaving_degree=0.5, intrinsic_reward_coef=1.0)
+    traj("traj_n60_s2_ens01", 2, 64, obs_every=4, number_of_pedestrians=60, enslaving_degree=0.1,
+         is_new_followers_reward=False, init_reward_each_step=0.0)
+    traj("traj_n60_s3_step05_trunc", 3, 40, obs_every=4, number_of_pedestrians=60, step_size=0.05,
+         max_timesteps=40, is_new_exiting_reward=True, intrinsic_reward_coef=1.0)
+    traj("traj_n10_s4_long", 4, 400, obs_every=16, number_of_pedestrians=10, is_new_exiting_reward=True)
+    traj("traj_n256_s5", 5, 64, obs_every=8, number_of_pedestrians=256, is_new_exiting_reward=True)
+    traj("traj_n256_s6_noise05", 6, 64, obs_every=8, number_of_pedestrians=256, noise_coef=0.5, enslaving_degree=0.5)
+    traj("traj_n1024_s7", 7, 4, obs_every=4, number_of_pedestrians=1024, is_new_exiting_reward=True)
+    traj("traj_n1024_s8_noise05_ens05", 8, 4, obs_every=4, number_of_pedestrians=1024, noise_coef=0.5,
+         enslaving_degree=0.5, intrinsic_reward_coef=1.0)
+    traj("traj_n256_s9_ens01_step05", 9, 64, obs_every=16, number_of_pedestrians=256, enslaving_degree=0.1,
+         step_size=0.05, is_new_exiting_reward=True, intrinsic_reward_coef=1.0)
+    traj("traj_n256_s10_noreward", 10, 64, obs_every=16, number_of_pedestrians=256,
+         is_new_followers_reward=False, init_reward_each_step=0.0, noise_coef=0.05)
+    if not only or "crafted" in only:
+        make_crafted(ref)
 
 
 if __name__ == "__main__":

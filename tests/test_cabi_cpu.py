@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert s in _lib.SIGNATURES, f"{s} declared in evac.h but not bound in _lib.py"
         getattr(lib, s)
     assert set(_lib.SIGNATURES) == set(syms)
-    assert lib.evac_version() == _lib.VERSION == 131
+    assert lib.evac_version() == _lib.VERSION == 140
 
 
 def test_code_object_targets_gfx950(lib):

@@ -93,31 +93,42 @@ def grav_tolerance(st, alpha, eps):
     return 1e-5 * scale, 1e-5 * scale_exit
 
 
-def compare_step(p, wrap, pre_states, actions, noise, got, min_checked=1):
-    """Oracle (reference precision) from the same f32-representable inputs vs the GPU outputs."""
-    checked = ties = 0
+TIE_LOG = []      # (fixture or case, envs, envs with a near-tie, pedestrians excluded): printed at the end of the session (conftest)
+
+
+def compare_step(p, wrap, pre_states, actions, noise, got, min_checked=1, label=None):
+    """Oracle (reference precision) from the same f32-representable inputs vs the GPU outputs.  A comparison whose f64 margin is
+    below TIE may legitimately flip in f32: the pedestrians it involves are left out of the element-wise comparison (positions,
+    directions, statuses of every OTHER pedestrian of that env are still compared), and the env-level outputs of such an env
+    (rewards, flags, observation sums -- they depend on every status) are skipped.  Both counts are returned and logged."""
+    checked = ties = peds_out = 0
     worst = 0.0
     for e, pre in enumerate(pre_states):
         st = f32_state(pre)
         pre_pos = st.pos.copy()
         with np.errstate(all="ignore"):
             out = O.env_step(p, st, np.asarray(actions[e], dtype=np.float32), np.asarray(noise[e], dtype=np.float32).astype(np.float64))
-        margin = O.threshold_margin(st.pos, st.agent_pos, pre_pos, p.width, p.height, st.status)
-        if np.isfinite(st.pos).all() and margin < TIE:
-            ties += 1
-            continue
-        checked += 1
-        np.testing.assert_array_equal(got["status"][e], st.status, err_msg=f"env {e} status")
-        np.testing.assert_allclose(got["pos"][e], st.pos, rtol=0, atol=ATOL, equal_nan=True, err_msg=f"env {e} pos")
-        np.testing.assert_allclose(got["dir"][e], st.dir, rtol=0, atol=ATOL, equal_nan=True, err_msg=f"env {e} dir")
+        finite = np.isfinite(st.pos).all()
+        tied = np.zeros(len(st.status), bool)
+        if finite:
+            tied = O.threshold_margins_per_pedestrian(st.pos, st.agent_pos, pre_pos, p.width, p.height, st.status) < TIE
+        ok = ~tied
+        np.testing.assert_array_equal(got["status"][e][ok], st.status[ok], err_msg=f"env {e} status")
+        np.testing.assert_allclose(got["pos"][e][ok], st.pos[ok], rtol=0, atol=ATOL, equal_nan=True, err_msg=f"env {e} pos")
+        np.testing.assert_allclose(got["dir"][e][ok], st.dir[ok], rtol=0, atol=ATOL, equal_nan=True, err_msg=f"env {e} dir")
         np.testing.assert_allclose(got["agent_pos"][e], st.agent_pos, rtol=0, atol=1e-7)
         np.testing.assert_allclose(got["agent_dir"][e], st.agent_dir, rtol=0, atol=1e-8)
         assert got["now"][e] == st.now
+        assert bool(got["truncated"][e]) == out["truncated"], f"env {e} truncated"
+        if finite and ok.any():
+            worst = max(worst, float(np.abs(got["pos"][e][ok] - st.pos[ok]).max()), float(np.abs(got["dir"][e][ok] - st.dir[ok]).max()))
+        if tied.any():
+            ties += 1
+            peds_out += int(tied.sum())
+            continue
+        checked += 1
         np.testing.assert_allclose(got["reward"][e], out["reward"], rtol=1e-5, atol=1e-5, equal_nan=True, err_msg=f"env {e} reward")
         assert bool(got["terminated"][e]) == out["terminated"], f"env {e} terminated"
-        assert bool(got["truncated"][e]) == out["truncated"], f"env {e} truncated"
-        if np.isfinite(st.pos).all():
-            worst = max(worst, float(np.abs(got["pos"][e] - st.pos).max()), float(np.abs(got["dir"][e] - st.dir).max()))
         ref_obs = flat_oracle_obs(st, wrap, p.eps)
         if wrap.positions == "grav":
             tol_p, tol_e = grav_tolerance(st, wrap.alpha, p.eps)
@@ -127,6 +138,8 @@ def compare_step(p, wrap, pre_states, actions, noise, got, min_checked=1):
         else:
             np.testing.assert_allclose(got["obs"][e], ref_obs, rtol=0, atol=ATOL, equal_nan=True, err_msg=f"env {e} obs")
     assert checked >= min_checked, (checked, ties)
+    if label is not None:
+        TIE_LOG.append((label, len(pre_states), ties, peds_out))
     return checked, ties, worst
 
 
@@ -144,14 +157,18 @@ def test_teacher_forced_steps_match_reference_fixtures(ea, path):
     p = H.load_params(d["params_json"])
     K = len(d["action"])
     pre = [H.state_at(d, k) for k in range(K)]
+    # Steps with a near-tie somewhere: their env-level outputs are skipped (compare_step).  A follower that keeps its distance to
+    # the leader (enslaving_degree 1) carries the same near-tie from step to step, so the bound scales with the fixture's length;
+    # the count is printed at the end of the session (TIE_LOG), so that a silent growth is visible.
     total_ties = 0
     for i, w in enumerate(WRAPS if p.number_of_pedestrians <= 256 else WRAPS[:1] + WRAPS[8:9]):
         wrap = ea.EnvWrappersConfig(**w)
         got = gpu_step_batch(ea, p, wrap, pre, d["action"], d["noise"])
-        checked, ties, worst = compare_step(p, wrap, pre, d["action"], d["noise"], got, min_checked=max(1, K - 4))
+        checked, ties, worst = compare_step(p, wrap, pre, d["action"], d["noise"], got, min_checked=max(1, K - max(4, K // 5)),
+                                            label=os.path.basename(path)[:-4] if i == 0 else None)
         total_ties = max(total_ties, ties)
         assert worst < 2e-6, worst          # in practice a few f32 ulp
-    assert total_ties <= 4
+    assert total_ties <= max(4, K // 5)
 
 
 @pytest.mark.parametrize("name,c", list(H.crafted_cases()), ids=[n for n, _ in H.crafted_cases()])

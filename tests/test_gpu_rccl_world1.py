@@ -1,0 +1,40 @@
+"""GPU: RCCL runs under this code before a multi-GPU box does it for the first time.  backend "nccl" IS
+RCCL on ROCm; a communicator of ONE rank executes the same calls as one of eight -- init_process_group(device_id=),
+all_gather_into_tensor on the comm stream, the events between the streams, record_stream -- only the wire is missing."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env():
+    e = dict(os.environ)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        e.pop(k, None)
+    return e
+
+
+def test_sharded_env_gathers_through_a_one_rank_rccl_communicator():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_world1_worker.py")], capture_output=True, text=True,
+                       timeout=300, env=_env())
+    assert p.returncode == 0 and "RCCL_WORLD1_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+@pytest.mark.parametrize("extra", [[], ["--gather", "slab"], ["--gather", "peer"], ["--gather-schedule", "split"]])
+def test_bench_force_gather_runs_the_pipeline_with_rccl(extra):
+    """bench.py --force-gather: world size 1, backend nccl, the SAME ChunkPipeline as an N-GPU run -- the gather of chunk j - 1
+    on the comm stream under chunk j, buffer-reuse waits, the drain of both streams -- and a bench line that says so."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-gather", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+           "--no-step-api", "--sweeps", "1"] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_env())
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["collective_backend"] == "nccl" and line["config"]["ranks_joined"] == 1
+    assert "all-gather" in line["config"]["parallelism"] and line["value"] > 1e8
+    assert line["config"]["gather_schedule"] == ("split" if "split" in extra else "pipelined")

@@ -235,3 +235,34 @@ def test_team_rollout_with_another_stream_busy(ea, coop):
     for a, b in zip(outs, got):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     ref.close(); tm.close()
+
+
+def test_two_team_grids_on_two_streams_take_turns(ea):
+    """two team-capable handles on one device, each on a stream of its own (train and eval envs) -- each
+    grid alone fits the device (16 envs x 16 CUs = every CU), both at once do not, and members polling on the CUs the other
+    grid's missing members need would time out on both sides.  evac_rollout chains the team launches of a device (a device-side
+    wait on the previous team launch's event): no team error on either handle, same bits as the one-workgroup kernels."""
+    import torch
+    n, E = 1024, 16
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=45, is_new_exiting_reward=True)
+    wrap = ea.EnvWrappersConfig(positions="rel", statuses="ohe", type="Box")
+    refs = [_make(ea, cfg, wrap, E, 31 + k, team=0) for k in range(2)]
+    tms = [_make(ea, cfg, wrap, E, 31 + k, team=16) for k in range(2)]
+    assert all("16 CUs/env" in t.kernel_variant("rollout") for t in tms)        # (known at bind time: evac_bind_workspace checks the fit)
+    for e in refs + tms:
+        e.reset()
+    want = [[r.rollout(20)["slab"].clone() for _ in range(5)] for r in refs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = [[], []]
+    for k in range(5):                                  # launches of the two handles alternate, nothing waited for in between
+        for j in (0, 1):
+            with torch.cuda.stream(streams[j]):
+                got[j].append(tms[j].rollout(20)["slab"].clone())
+    torch.cuda.synchronize()
+    for j in (0, 1):
+        assert tms[j].team_error(sync=False) == 0 and tms[j].team_error() == 0
+        for a, b in zip(want[j], got[j]):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    for e in refs + tms:
+        e.close()

@@ -7,7 +7,7 @@ MASKS="0 1 2 4 8 16 3 6 7 15 31"
 if [ "${1:-build}" = "build" ]; then
   mkdir -p "$ROOT/tools/ablate_libs"
   for m in $MASKS; do
-    hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -fPIC -shared -DEVAC_ABLATE=$m \
+    hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -std=c++17 -fPIC -shared -DEVAC_ABLATE=$m \
       "$ROOT/evacuation_amd/csrc/evac_api.hip" -o "$ROOT/tools/ablate_libs/libevac_ablate_$m.so" &
   done
   wait

@@ -4,10 +4,33 @@ HBM bytes per launch = FETCH_SIZE[KiB] * 1024 * 2  (gfx950 reports half of a coa
 MI355X_MICROARCH.md 'HBM') + WRITE_SIZE[KiB] * 1024; separate --pmc passes, mean over the dispatches
 of the timed kernel, divided by the env-steps of one launch: bench.py scales it back to whatever launch shape it
 runs (`roofline.traffic`).
+Every entry also records WHAT it was measured on -- the kernel variant string of the handle (evac_kernel_variant, asked on the
+GPU box: run this script there) and the hash of the kernel sources (bench.csrc_sha16) -- and bench.py withholds the counters when
+either differs from what it runs (bench.load_traffic).
 usage: make_traffic_json.py <pmc_dir> <workload:mode> <envs> <steps_per_launch> [...]"""
 import csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def kernel_variant(key, envs):
+    """The variant string bench.py will see for this workload (needs the GPU: the team / CU-wide choice depends on the device)."""
+    import evacuation_amd as ea
+    workload, mode = key.split(":")
+    n_ped, _, wrap_kw, _ = bench.WORKLOADS[workload]
+    cfg = ea.EnvConfig(number_of_pedestrians=n_ped, is_new_exiting_reward=True, is_new_followers_reward=True,
+                       intrinsic_reward_coef=0.0, max_timesteps=bench.EPISODE)
+    env = ea.BatchedEvacuationEnv(cfg, ea.EnvWrappersConfig(**wrap_kw), num_envs=int(envs))
+    env.reset()
+    if mode == "rollout":
+        env.rollout(2)                      # (the team kernels' residency check runs at the first rollout)
+    v = env.kernel_variant(mode)
+    env.close()
+    return v
+
+
 out_path = os.path.join(ROOT, "profiles", "traffic.json")
 data = json.load(open(out_path)) if os.path.exists(out_path) else {}
 data = {k: v for k, v in data.items() if "hbm_bytes_per_env_step" in v}     # drop entries of the round-1 format
@@ -30,6 +53,6 @@ for d, key, envs, inner in zip(args[0::4], args[1::4], args[2::4], args[3::4]):
                  "valu_wave_insts_per_env_step": (sum(vals["SQ_INSTS_VALU"]) / len(vals["SQ_INSTS_VALU"]) / (int(envs) * int(inner))) if vals["SQ_INSTS_VALU"] else None,
                  "salu_wave_insts_per_env_step": (sum(vals["SQ_INSTS_SALU"]) / len(vals["SQ_INSTS_SALU"]) / (int(envs) * int(inner))) if vals["SQ_INSTS_SALU"] else None,
                  "lds_wave_insts_per_env_step": (sum(vals["SQ_INSTS_LDS"]) / len(vals["SQ_INSTS_LDS"]) / (int(envs) * int(inner))) if vals["SQ_INSTS_LDS"] else None,
-                 "source": os.path.relpath(d, ROOT)}
+                 "source": os.path.relpath(d, ROOT), "kernel_variant": kernel_variant(key, envs), "csrc_sha16": bench.csrc_sha16()}
     print(key, data[key])
 json.dump(data, open(out_path, "w"), indent=1, sort_keys=True)

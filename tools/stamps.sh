@@ -4,7 +4,7 @@
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 if [ "${1:-build}" = "build" ]; then
   mkdir -p "$ROOT/tools/ablate_libs"
-  hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -fPIC -shared -DEVAC_STAMP \
+  hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -std=c++17 -fPIC -shared -DEVAC_STAMP \
     "$ROOT/evacuation_amd/csrc/evac_api.hip" -o "$ROOT/tools/ablate_libs/libevac_stamp.so" && echo built
 else
   EVAC_LIB="$ROOT/tools/ablate_libs/libevac_stamp.so" python3 - <<PY
