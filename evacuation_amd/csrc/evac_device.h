@@ -153,6 +153,8 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     }
     {   // area.py:148-152.  med3 of a NaN is not NaN, but then miss = NaN - finite = NaN, so the position,
         // the `miss != 0` test and the flipped direction come out exactly as with np.clip.
+        // (a uniform branch around the block for the steps on which no pedestrian of the wave is outside: measured, no gain --
+        // profiles/r04_f_c2_ab_tail12_reflect_skip_no_gain.txt)
         const float cx = __builtin_amdgcn_fmed3f(q.x, -p.width, p.width);
         const float cy = __builtin_amdgcn_fmed3f(q.y, -p.height, p.height);
         const float mx = q.x - cx, my = q.y - cy;
@@ -325,9 +327,20 @@ __device__ __forceinline__ int schedule_slot(int r, int n_envs, int per_wg) {
 // of its own (k_schedule) and at the start of workgroup 0 of a rollout launch (rollout_body).
 __device__ __forceinline__ void schedule_envs_by_workgroup(int* hist, int tid, int n_envs, const int* __restrict__ loads,
                                                            int* __restrict__ perm, int per_wg, int unit) {
+    constexpr int kPer = 4;                  // envs per thread and pass: their loads are fetched back to back (one memory latency, not four)
     if (tid < kWave + 2) hist[tid] = 0;
     __syncthreads();
-    for (int e = tid; e < n_envs; e += 1024) atomicAdd(&hist[schedule_bin(loads[e], unit)], 1);
+    for (int base = 0; base < n_envs; base += kPer * 1024) {
+        int b[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int e = base + k * 1024 + tid;
+            b[k] = e < n_envs ? loads[e] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k)
+            if (b[k] >= 0) atomicAdd(&hist[schedule_bin(b[k], unit)], 1);
+    }
     __syncthreads();
     if (tid < kWave) {                       // exclusive prefix over the 65 bins (bin 64 = everything at or above 64)
         const int v = hist[tid];
@@ -337,9 +350,21 @@ __device__ __forceinline__ void schedule_envs_by_workgroup(int* hist, int tid, i
         if (tid == kWave - 1) hist[kWave] = incl;
     }
     __syncthreads();
-    for (int e = tid; e < n_envs; e += 1024) {
-        const int r = atomicAdd(&hist[schedule_bin(loads[e], unit)], 1);   // rank by load, ascending
-        perm[schedule_slot(r, n_envs, per_wg)] = e;
+    for (int base = 0; base < n_envs; base += kPer * 1024) {
+        int r[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int e = base + k * 1024 + tid;
+            r[k] = e < n_envs ? loads[e] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k)
+            if (r[k] >= 0) r[k] = atomicAdd(&hist[schedule_bin(r[k], unit)], 1);            // rank by load, ascending
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int e = base + k * 1024 + tid;
+            if (e < n_envs) perm[schedule_slot(r[k], n_envs, per_wg)] = e;
+        }
     }
 }
 

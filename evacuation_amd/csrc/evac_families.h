@@ -340,7 +340,7 @@ struct Wave {
                 }
                 // the remainder (4, 8 or 12 columns: n8 is a multiple of 4) in at most two batches, 8 + 4 -- two LDS round trips,
                 // not one per group of 4 (the heaviest envs, 57..60 moving pedestrians, have 12 left: their wave ends the
-                // launch; a 12-column batch would be one trip, but costs the generic kernel two spilled registers)
+                // launch; a 12-column batch -- one trip -- was measured in round 4: no gain, profiles/r04_f_c2_ab_tail12_reflect_skip_no_gain.txt)
                 if (mp - m >= 4) {
                     f4 a[4], u[4];
 #pragma unroll
