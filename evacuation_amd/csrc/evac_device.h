@@ -671,6 +671,7 @@ __device__ __forceinline__ void rollout_body(
             }
         }
         if constexpr (F::kPace) pace_step(pace_slot, &sm.progress[EVAC_PACE_SIMD * 4], w.lane, t, pace_seen, pace_prio);
+        EVAC_T(w, 12);  // (sub-phase of the diagnostic build: loop top + pace keeping)
 #undef EVAC_PACE_SIMD
 #undef EVAC_PACE_K
         const int slot64 = t & 63;
@@ -753,6 +754,7 @@ __device__ __forceinline__ void rollout_body(
                     st[8] = f_trunc;
                 }
                 stage_off += kStageRowBytes;
+                EVAC_T(w, 14);  // (sub-phase: end-of-episode check, staging of the step's row)
                 if (t == flush_t) {
                     if (w.wave_in_env == 0) {   // the wave that staged them: in-order LDS, no barrier needed
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

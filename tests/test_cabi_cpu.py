@@ -143,8 +143,8 @@ def test_kernel_resource_budgets():
     src = os.path.join(ROOT, "evacuation_amd", "csrc", "evac_api.hip")
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "evac.s")
-        subprocess.run([build.hipcc_path(), "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-S",
-                        "--cuda-device-only", src, "-o", out], check=True, capture_output=True)
+        flags = [f for f in build.FLAGS if f not in ("-fPIC", "-shared")]       # the product's own flags
+        subprocess.run([build.hipcc_path()] + flags + ["-S", "--cuda-device-only", src, "-o", out], check=True, capture_output=True)
         text = open(out).read()
     meta = text[text.index("amdhsa.kernels:"):]
     kernels = {}
