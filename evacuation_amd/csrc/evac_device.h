@@ -712,9 +712,11 @@ __device__ __forceinline__ void rollout_body(
         if constexpr (DIAG) {
             if (noise_in) nz = active ? noise_in[((size_t)t * E + w.env) * p.n_ped + w.i] : 0.0f;   // injection mode
         }
-        StepOut o;
+        StepOut o{};
         EVAC_T(w, 0);   // action fetch + noise Philox
-        step_env<F, GRAV>(p, w, active, q, e, adir, nz, o);
+        // (EVAC_ABLATE & 32, timing experiment only: a wave without a row to evaluate skips its step -- what the heavy waves would
+        // gain if the light ones cost nothing: 46.5 -> 36.4 us per 20-step C2 launch, profiles/r04_h_c2_light_waves_cost.txt)
+        if (!((EVAC_ABLATE & 32) && !wants_noise)) step_env<F, GRAV>(p, w, active, q, e, adir, nz, o);
         // trajectory capture for rendering (Pedestrians.save / Agent.save, pedestrians.py:33-35, area.py:32-33):
         // the post-step, pre-reset state of the first `capture_envs` envs; row N holds the leader.
         if (DIAG && capture && w.env < capture_envs) {   // wave-/workgroup-uniform; compiled out of the default kernel
