@@ -95,6 +95,12 @@ def parse_args(argv=None):
     ap.add_argument("--force-gather", action="store_true",
                     help="run the gather path -- process group, collective on the comm stream, double-buffered pipeline -- with "
                          "whatever world size there is, also 1 (a one-rank RCCL communicator): exercises the multi-GPU code on one GPU")
+    ap.add_argument("--buffers", type=int, default=0,
+                    help="output buffers the chunks rotate through (0: 4 with the pipelined gather -- the host may then run three "
+                         "chunks ahead of the device before it has to wait for a gather --, else 2)")
+    ap.add_argument("--device-wait", action="store_true",
+                    help="order a buffer's reuse behind its gather with a device-side stream wait (a barrier packet in front of the "
+                         "launch) instead of the host-side check")
     ap.add_argument("--gather", default="obs", choices=["obs", "slab", "direct", "peer"],
                     help="what the ranks all-gather per chunk and how: the observation batch (north_star) or the whole packed "
                          "record through RCCL; or the observation batch written into the peers' hipIpc-mapped buffers by one "
@@ -285,20 +291,24 @@ class ChunkPipeline:
     structure, used with HIP streams by main() and with CPU stand-ins by dry_run() (tests/test_bench_launcher_cpu.py reads
     its trace).
 
-    Chunks are numbered across blocks; chunk j computes into buffer j & 1.  lag = 1 (pipelined): after the launch of chunk j
-    the gather of chunk j-1 is issued (it reads buffer (j-1) & 1 while chunk j writes the other).  lag = 0 (split): chunk j's
-    own gather is issued right after its launch.  Before chunk j+1 reuses a buffer the compute stream waits for the gather
-    that read it.  `drain()` = everything issued so far, compute and gathers, has completed on this rank."""
+    Chunks are numbered across blocks; chunk j computes into buffer j % nbuf.  lag = 1 (pipelined): after the launch of chunk j
+    the gather of chunk j-1 is issued (it reads buffer (j-1) % nbuf while chunk j writes another).  lag = 0 (split): chunk j's
+    own gather is issued right after its launch.  Before a chunk reuses a buffer the compute stream waits for the gather
+    that read it: with nbuf = 2 launch j+1 waits for gather j-1, which was issued only after launch j -- on a device that the
+    rollout fills, the gather's kernels find no free CU under launch j and the two serialise; with nbuf = 3 (the default of the
+    pipelined schedule) launch j+1 waits for gather j-2, which had launch j's whole duration.
+    `drain()` = everything issued so far, compute and gathers, has completed on this rank."""
 
-    def __init__(self, launch, gather, wait_gather, drain_compute, drain_gather, lag=1, trace=None):
+    def __init__(self, launch, gather, wait_gather, drain_compute, drain_gather, lag=1, trace=None, nbuf=2):
         self.launch, self.gather, self.wait_gather = launch, gather, wait_gather
         self.drain_compute, self.drain_gather = drain_compute, drain_gather
         self.lag = lag
+        self.nbuf = nbuf
         self.trace = trace
         self.next = 0                   # next chunk number
         self.sizes = {}                 # chunk -> steps (for its gather)
         self.ungathered = None          # the chunk whose gather has not been issued yet (lag = 1)
-        self.inflight = {}              # buffer parity -> gather token of the last gather that read it
+        self.inflight = {}              # buffer -> gather token of the last gather that read it
 
     def _log(self, *ev):
         if self.trace is not None:
@@ -306,16 +316,16 @@ class ChunkPipeline:
 
     def _issue_gather(self, j):
         self._log("gather", j)
-        self.inflight[j & 1] = self.gather(j, self.sizes.pop(j))
+        self.inflight[j % self.nbuf] = self.gather(j, self.sizes.pop(j))
 
     def run_block(self, sizes):
         """Issue one block: exactly sum(sizes) env steps."""
         for t in sizes:
             j = self.next
             self.next += 1
-            tok = self.inflight.pop(j & 1, None)
-            if tok is not None:                       # buffer reuse: the gather that read buffer j & 1 must be finished
-                self._log("wait_gather_of_buffer", j & 1)
+            tok = self.inflight.pop(j % self.nbuf, None)
+            if tok is not None:                       # buffer reuse: the gather that read buffer j % nbuf must be finished
+                self._log("wait_gather_of_buffer", j % self.nbuf)
                 self.wait_gather(tok)
             self._log("launch", j)
             self.launch(j, t)
@@ -401,7 +411,7 @@ def main(argv=None):
             raise SystemExit(f"bench.py: {dist.get_world_size()} ranks joined, --gpus {args.gpus} requested")
 
     import evacuation_amd as ea
-    from evacuation_amd.distributed import DirectGather, PeerStoreGather, ShardedEvacuationEnv, all_gather_envs, pack_outputs
+    from evacuation_amd.distributed import DirectGather, PeerStoreGather, ShardedEvacuationEnv, all_gather_envs, pack_outputs, side_stream
 
     cfg = ea.EnvConfig(number_of_pedestrians=n_ped, is_new_exiting_reward=True, is_new_followers_reward=True,
                        intrinsic_reward_coef=0.0, max_timesteps=EPISODE)       # SURVEY.md 8(d) synthetic inputs
@@ -418,9 +428,10 @@ def main(argv=None):
     lag = 0 if (args.gather_schedule == "split") else 1
 
     # Preallocated, reused output chunks (the trainer's rollout buffer, rpo_agent.py:158-163): the kernel writes one packed
-    # slab [T, E, D+3] = [obs | reward | terminated | truncated] per launch shape and buffer parity.
+    # slab [T, E, D+3] = [obs | reward | terminated | truncated] per launch shape and buffer of the ring.
     compute = torch.cuda.current_stream(device)               # every launch of this benchmark goes to this stream
-    comm = torch.cuda.Stream(device=device) if do_gather else None
+    comm = side_stream(device, beside=compute) if do_gather else None      # (a stream on ANOTHER hardware queue than `compute`)
+    nbuf = args.buffers if args.buffers > 0 else (4 if (gather_rollout and lag == 1) else 2)
     GW = D + 3 if args.gather == "slab" else D                # gathered words per env-step (obs, direct: the observation columns)
     chunks = {}
 
@@ -432,6 +443,7 @@ def main(argv=None):
                  "episode_stats": torch.zeros((t, E, loc.stats_words), dtype=torch.float32, device=device)}
             b["launch"] = loc.rollout_launcher(t, b, stream=compute)   # pre-bound ctypes call: no per-launch Python argument work
             if gather_rollout:
+                b["ready"], b["fin"] = torch.cuda.Event(), torch.cuda.Event()   # (reused: creating two events per gather cost 5 us of host time)
                 b["gathered"] = torch.empty((world, t, E, GW), dtype=torch.float32, device=device)
                 if args.gather in ("obs", "direct"):
                     b["gsrc"] = torch.empty((t, E, GW), dtype=torch.float32, device=device)
@@ -446,7 +458,13 @@ def main(argv=None):
 
     def launch(j, t):
         if args.mode == "rollout":
-            chunk_bufs(t, j & 1)["launch"]()
+            b = chunk_bufs(t, j % nbuf)
+            b["launch"]()
+            if gather_rollout:
+                # the chunk's outputs are complete HERE on the compute stream.  (Rounds 2-3 recorded this event inside gather(),
+                # i.e. after the NEXT launch had been enqueued: the gather of chunk j-1 then waited for launch j to finish and
+                # never ran under it -- tools/gather_cost.py, profiles/r04_h_force_gather_world1.txt.)
+                b["ready"].record(compute)
         else:
             loc.step(step_actions)
 
@@ -456,28 +474,36 @@ def main(argv=None):
             msg = loc.obs if args.gather == "obs" else pack_outputs(loc.obs, loc.reward, loc.terminated, loc.truncated)
             all_gather_envs(msg)                              # (per-step API: one small collective per step, on the compute stream)
             return None
-        b = chunk_bufs(t, j & 1)
-        ready = torch.cuda.Event()
-        ready.record()                                        # chunk j (and everything before it) on the compute stream
-        with torch.cuda.stream(comm):
-            comm.wait_event(ready)
-            if args.gather == "slab":
-                all_gather_envs(b["slab"], out=b["gathered"])
-            elif args.gather == "peer":
-                b["peer"].issue(comm)                         # one launch: the observation columns to every peer
-            else:                                             # the observation columns, copied out on the comm stream
-                b["gsrc"].copy_(b["slab"][..., :D])
-                if args.gather == "direct":
-                    b["direct"].issue(comm)                   # world copy-engine writes into the peers' buffers
-                else:
-                    all_gather_envs(b["gsrc"], out=b["gathered"])
-            fin = torch.cuda.Event()
-            fin.record(comm)
+        # (the comm stream is torch's CURRENT stream for the whole pipeline -- see run_pipeline_on_comm below --, so that no
+        # stream switch is paid per gather: the collective and the column copy go to the current stream, the launches are bound
+        # to `compute`.  Host cost of one gather: tools/gather_cost.py.)
+        b = chunk_bufs(t, j % nbuf)
+        fin = b["fin"]
+        comm.wait_event(b["ready"])                           # recorded right behind chunk j's launch (launch())
+        if args.gather == "slab":
+            all_gather_envs(b["slab"], out=b["gathered"])
+        elif args.gather == "peer":
+            b["peer"].issue(comm)                             # one launch: the observation columns to every peer
+        else:                                                 # the observation columns, copied out on the comm stream
+            b["gsrc"].copy_(b["slab"][..., :D])
+            if args.gather == "direct":
+                b["direct"].issue(comm)                       # world copy-engine writes into the peers' buffers
+            else:
+                all_gather_envs(b["gsrc"], out=b["gathered"])
+        fin.record(comm)
         return fin
 
     def wait_gather(fin):
-        if fin is not None:
-            torch.cuda.current_stream().wait_event(fin)
+        """Before a chunk reuses a buffer: the gather that read it is done.  Checked on the HOST (a query; a host-side wait only
+        if the host has run `nbuf - 1` chunks ahead of the device) -- a device-side `compute.wait_event(fin)` puts a barrier
+        packet between two rollout launches and costs 7-10 us per chunk on this runtime whether or not the event has fired
+        (profiles/r04_h_force_gather_world1.txt: 58.6 -> 48.2 us per chunk).  --device-wait restores it."""
+        if fin is None:
+            return
+        if args.device_wait:
+            compute.wait_event(fin)
+        elif not fin.query():
+            fin.synchronize()
 
     def drain_compute():
         """Everything issued to the device so far is done.  (hipDeviceSynchronize spins here; a hipStreamQuery loop costs the
@@ -487,7 +513,8 @@ def main(argv=None):
     def drain_gather():
         comm.synchronize()
 
-    pipe = ChunkPipeline(launch, gather if do_gather else None, wait_gather, drain_compute, drain_gather if do_gather else None, lag=lag)
+    pipe = ChunkPipeline(launch, gather if do_gather else None, wait_gather, drain_compute, drain_gather if do_gather else None, lag=lag,
+                         nbuf=nbuf)
 
     def barrier():
         """Opens a timed region (and, being the next one's opening, closes the previous one outside its timed region)."""
@@ -503,7 +530,7 @@ def main(argv=None):
     try:
         if args.mode == "rollout":
             for t_ in all_sizes:
-                for par_ in (0, 1):
+                for par_ in range(nbuf):
                     chunk_bufs(t_, par_)
         if gather_rollout:
             b0 = chunk_bufs(sizes[0], 0)
@@ -521,6 +548,10 @@ def main(argv=None):
         raise SystemExit(f"bench.py: rank {rank}: the all-gather failed ({type(exc).__name__}: {exc}); no {world}-GPU result "
                          f"(--no-gather measures independent shards)") from exc
 
+    # With gathers the COMM stream is torch's current stream from here to the end of the timed parts (the launches are bound to
+    # `compute`): the collectives and the column copies then need no stream switch per chunk.
+    if do_gather:
+        torch.cuda.set_stream(comm)
     # W untimed warm-up steps through the same pipeline (so that, pipelined, the first timed launch has a gather to carry)
     w_done = 0
     while w_done < W:
@@ -542,10 +573,10 @@ def main(argv=None):
         barrier()                                             # opening bracket: all ranks present, device idle
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        e0.record()
+        e0.record(compute)
         for b in range(per_sweep):
             pipe.run_block(sizes)                             # EXACTLY K steps (+ one gather per launch), nothing waited for
-        e1.record()
+        e1.record(compute)
         pipe.drain()                                          # this rank's compute AND gathers are done
         sweep_wall.append(time.perf_counter() - t0)           # local t1; no collective inside the timed region
         sweep_dev.append(e0.elapsed_time(e1) * 1e-3)
@@ -589,6 +620,8 @@ def main(argv=None):
         with open(os.environ["EVAC_BENCH_DUMP"], "w") as f:
             json.dump({"sweep_wall_s": sweep_wall, "sweep_dev_s": sweep_dev, "wall_s": wall, "phase": phases, "launch_call_s": t_call}, f)
 
+    if do_gather:
+        torch.cuda.set_stream(compute)
     # ---- diagnostic 2: an event pair around every launch of one sweep (state restored, no gathers): the dense launch ----
     def restore():
         barrier()
@@ -705,13 +738,16 @@ def main(argv=None):
                        "obs": wrap_kw, "actions": "RandomAgent U(-1,1)^2 drawn on device (Philox4x32-10)",
                        "mode": args.mode, "steps_per_launch": inner, "launches_per_block": len(sizes),
                        "timing": "whole episode sweeps of 2000/K launches of exactly K steps each, issued back to back (no host sync, no "
-                                 "collective inside; N > 1: the gather of chunk j-1 under chunk j); per sweep: barrier + synchronize (all "
+                                 "barrier collective inside; N > 1: the gather of chunk j-1 on a second hardware queue under chunk j, a "
+                                 "chunk's buffer reused only once the host has seen its gather finished -- a query, the host at most "
+                                 "gather_buffers - 1 chunks ahead of the device); per sweep: barrier + synchronize (all "
                                  "ranks, device idle) -> t0 -> the launches (+ gathers) -> the rank drains its compute and comm streams "
                                  "-> t1, max over ranks; ms_per_step = median sweep / 2000 = the episode-average step; `blocks`: the "
                                  "per-block view (a device-idle sync around every K-step launch) as a diagnostic",
                        "sweeps": {"timed": sweeps, "launches_per_sweep": launches_per_sweep, "steps_per_sweep": steps_per_sweep,
                                   "wall_ms": [x * 1e3 for x in sweep_wall], "hip_event_ms": [x * 1e3 for x in sweep_dev]},
                        "gather_schedule": (args.gather_schedule if gather_rollout else None),
+                       "gather_buffers": (nbuf if gather_rollout else None),
                        "ranks_joined": dist.get_world_size() if use_dist else 1,
                        "collective_backend": (dist.get_backend() if use_dist else None),
                        "parallelism": f"env-sharded x{world}" + gather_desc,
@@ -781,17 +817,19 @@ def dry_run(args, rank, world, total_envs, envs_per_gpu, K, W, inner, per_sweep,
     bufs = {}
     trace, state = [], {"ok": True, "gathers": 0}
 
+    nbuf = args.buffers if args.buffers > 0 else (4 if (do_gather and lag == 1) else 2)
+
     def launch(j, t):
-        bufs[j & 1] = gid[None, :, None] + 1000.0 * j + torch.zeros((min(t, 4), n_local, 9))   # chunk j's "outputs"
+        bufs[j % nbuf] = gid[None, :, None] + 1000.0 * j + torch.zeros((min(t, 4), n_local, 9))   # chunk j's "outputs"
 
     def gather(j, t):
-        g, _ = all_gather_envs(bufs[j & 1])
+        g, _ = all_gather_envs(bufs[j % nbuf])
         full = gathered_view(g)
         state["ok"] = state["ok"] and bool((full[0, :, 0] == torch.arange(total_envs, dtype=torch.float32) + 1000.0 * j).all())
         state["gathers"] += 1
         return j
 
-    pipe = ChunkPipeline(launch, gather if do_gather else None, lambda tok: None, lambda: None, lambda: None, lag=lag, trace=trace)
+    pipe = ChunkPipeline(launch, gather if do_gather else None, lambda tok: None, lambda: None, lambda: None, lag=lag, trace=trace, nbuf=nbuf)
     w_done = 0
     while w_done < W:
         t = min(sizes[0], W - w_done)

@@ -47,6 +47,49 @@ def unpack_outputs(slab: torch.Tensor):
     return slab[..., :d], slab[..., d], slab[..., d + 1] != 0, slab[..., d + 2] != 0
 
 
+def side_stream(device, beside=None, candidates: int = 8) -> "torch.cuda.Stream":
+    """A stream of ``device`` whose kernels really run BESIDE those of ``beside`` (default: the current stream).  HIP maps its
+    streams onto a handful of hardware queues (4 by default) in the order in which they are first used, and two streams that share
+    a queue execute strictly one after the other -- with the process group's and the allocator's streams created first, a fresh
+    ``torch.cuda.Stream()`` landed on the compute stream's own queue in bench.py's forced-gather runs of round 4 and the gather never
+    ran under the rollout (profiles/r04_h_force_gather_world1.txt).  So: time two one-thread spin kernels (``torch.cuda._sleep``),
+    one on each stream; a pair that takes as long as one of them overlaps.  The first candidate that does is returned (the others are
+    dropped; their queue assignments stay used up, which is what moves the next candidate on).  Falls back to the last candidate."""
+    device = torch.device(device)
+    beside = beside if beside is not None else torch.cuda.current_stream(device)
+    spin = 400_000                                   # cycles: ~0.2 ms
+    def pair_ms(cand):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(device)
+        e0.record(beside)
+        with torch.cuda.stream(beside):
+            torch.cuda._sleep(spin)
+        with torch.cuda.stream(cand):
+            torch.cuda._sleep(spin)
+        beside.wait_stream(cand)
+        e1.record(beside)
+        torch.cuda.synchronize(device)
+        return e0.elapsed_time(e1)
+    with torch.cuda.device(device):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(beside):
+            torch.cuda._sleep(spin)                  # (warm-up: the kernel's first launch loads its code object)
+        torch.cuda.synchronize(device)
+        e0.record(beside)
+        with torch.cuda.stream(beside):
+            torch.cuda._sleep(spin)
+        e1.record(beside)
+        torch.cuda.synchronize(device)
+        one = e0.elapsed_time(e1)
+        cand = None
+        for _ in range(max(1, candidates)):
+            cand = torch.cuda.Stream(device=device)
+            pair_ms(cand)                            # (first use: the stream gets its queue here)
+            if pair_ms(cand) < 1.5 * one:
+                break
+    return cand
+
+
 def all_gather_envs(local: torch.Tensor, env_dim: int = -2, group=None, out: Optional[torch.Tensor] = None,
                     async_op: bool = False):
     """All-gather ``local`` ([..., E_local, C]) along its env dimension into global env order.
@@ -254,7 +297,7 @@ class ShardedEvacuationEnv:
         self.local = BatchedEvacuationEnv(env_config, wrap_config, num_envs=self.local_envs, device=device, seed=seed,
                                           env_id_offset=self.offset, autoreset=autoreset)
         self.obs_dim = self.local.obs_dim
-        self.comm_stream = torch.cuda.Stream(device=self.local.device) if self.collective else None
+        self.comm_stream = side_stream(self.local.device) if self.collective else None      # (one that overlaps the compute stream)
 
     def reset(self, **kw):
         return self.local.reset(**kw)

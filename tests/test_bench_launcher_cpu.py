@@ -116,6 +116,15 @@ def test_chunk_pipeline_orders_buffer_reuse_after_the_gather_that_read_it():
     # chunk 2 reuses buffer 0, which gather 0 read: the compute stream waits for it first
     assert log == [("L", 0, 5), ("L", 1, 5), ("G", 0, 5), ("W", "tok", 0), ("L", 2, 3), ("G", 1, 5), ("DC",), ("DG",),
                    ("G", 2, 3), ("DC",), ("DG",)]
+    # three buffers: launch 3 reuses buffer 0 and waits for gather 0 -- which had launch 2's whole duration, not launch 1's tail
+    log.clear()
+    pipe = bench.ChunkPipeline(launch=lambda j, t: log.append(("L", j, t)), gather=lambda j, t: log.append(("G", j, t)) or ("tok", j),
+                               wait_gather=lambda tok: log.append(("W",) + tok), drain_compute=lambda: log.append(("DC",)),
+                               drain_gather=lambda: log.append(("DG",)), lag=1, nbuf=3)
+    pipe.run_block([5, 5, 5, 5, 5])
+    pipe.flush()
+    assert log == [("L", 0, 5), ("L", 1, 5), ("G", 0, 5), ("L", 2, 5), ("G", 1, 5), ("W", "tok", 0), ("L", 3, 5), ("G", 2, 5),
+                   ("W", "tok", 1), ("L", 4, 5), ("G", 3, 5), ("G", 4, 5), ("DC",), ("DG",)]
     assert bench.chunk_sizes(20, 100, "pipelined", True) == [20] and bench.chunk_sizes(2000, 100, "pipelined", True) == [100] * 20
     assert bench.chunk_sizes(20, 100, "split", True) == [10, 10] and bench.chunk_sizes(20, 100, "split", False) == [20]
     assert bench.chunk_sizes(250, 100, "split", True) == [100, 100, 50]
