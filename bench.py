@@ -710,6 +710,22 @@ def main(argv=None):
             step_api["hipgraph_env_steps_per_s"] = E * (n_api // 10 * 10) / dt
         except Exception as exc:  # noqa: BLE001
             step_api["hipgraph_error"] = f"{type(exc).__name__}: {exc}"[:160]
+        # ... and through the SyncVectorEnv-shaped host face the reference's UNMODIFIED trainer would use (rpo_agent.py:193-196:
+        # NumPy actions up, NumPy observations / rewards / flags down, one stream synchronisation per step)
+        try:
+            host = ea.HostVectorEnv(loc, copy=True)
+            act_np = step_actions.cpu().numpy()
+            for _ in range(20):
+                host.step(act_np)
+            n_host = 200
+            t1 = time.perf_counter()
+            for _ in range(n_host):
+                host.step(act_np)
+            dt = time.perf_counter() - t1
+            step_api["host_vector_env_us_per_step"] = dt / n_host * 1e6
+            step_api["host_vector_env_env_steps_per_s"] = E * n_host / dt
+        except Exception as exc:  # noqa: BLE001
+            step_api["host_vector_env_error"] = f"{type(exc).__name__}: {exc}"[:160]
 
     if rank == 0:
         tr = load_traffic(args.traffic_json, f"{args.workload}:{args.mode}", loc.kernel_variant(args.mode), csrc_sha16())

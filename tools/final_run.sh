@@ -1,6 +1,6 @@
 # The round's measurements (run ON the GPU box: gpurun -- bash tools/final_run.sh <tag>): bench lines under gpurun_out/<tag>/,
 # rocprofv3 --stats + PMC passes under gpurun_out/<tag>_<workload>/ (tools/profile_pmc.sh), then profiles/traffic.json.
-TAG=${1:-r04_g}
+TAG=${1:-r04_h}
 mkdir -p gpurun_out/$TAG; cd gpurun_out/$TAG
 python ../../bench.py --steps 20 --warmup 5 > bench_c2_driver.json 2> bench_c2_driver.err
 python ../../bench.py --no-cpu-baseline > bench_c2_default.json 2>/dev/null
@@ -16,6 +16,8 @@ EVAC_WORKSPACE=0 python ../../bench.py --steps 20 --warmup 5 --no-cpu-baseline -
 EVAC_SPECIALIZE=0 python ../../bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-step-api > bench_c2_driver_generic_kernel.json 2>/dev/null
 python ../../bench.py --force-gather --steps 20 --warmup 5 --no-cpu-baseline --no-step-api > bench_c2_driver_force_gather_rccl_world1.json 2>/dev/null
 python ../../bench.py --force-gather --gather peer --steps 20 --warmup 5 --no-cpu-baseline --no-step-api > bench_c2_driver_force_gather_peer_world1.json 2>/dev/null
+python ../../bench.py --force-gather --device-wait --buffers 3 --steps 20 --warmup 5 --no-cpu-baseline --no-step-api > bench_c2_driver_force_gather_rccl_world1_device_side_wait.json 2>/dev/null
+python ../../tools/gather_cost.py 2>&1 | grep "us per gather\|bracket" > gather_cost.txt
 python ../../tools/subwave_bench.py > subwave.txt 2>&1
 python ../../examples/rollout_with_policy.py > policy_example.txt 2>&1
 python ../../tools/launch_intercept.py > launch_intercept.txt 2>&1
