@@ -26,7 +26,7 @@ def test_sharded_env_gathers_through_a_one_rank_rccl_communicator():
     assert p.returncode == 0 and "RCCL_WORLD1_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
-@pytest.mark.parametrize("extra", [[], ["--gather", "slab"], ["--gather", "peer"], ["--gather-schedule", "split"]])
+@pytest.mark.parametrize("extra", [[], ["--gather", "slab"], ["--gather", "peer"], ["--gather-schedule", "split"], ["--device-wait", "--buffers", "2"]])
 def test_bench_force_gather_runs_the_pipeline_with_rccl(extra):
     """bench.py --force-gather: world size 1, backend nccl, the SAME ChunkPipeline as an N-GPU run -- the gather of chunk j - 1
     on the comm stream under chunk j, buffer-reuse waits, the drain of both streams -- and a bench line that says so."""
@@ -38,3 +38,34 @@ def test_bench_force_gather_runs_the_pipeline_with_rccl(extra):
     assert line["n_gpus"] == 1 and line["config"]["collective_backend"] == "nccl" and line["config"]["ranks_joined"] == 1
     assert "all-gather" in line["config"]["parallelism"] and line["value"] > 1e8
     assert line["config"]["gather_schedule"] == ("split" if "split" in extra else "pipelined")
+
+
+def test_side_stream_really_runs_beside_the_compute_stream():
+    """HIP deals its streams onto a few hardware queues; two streams that share one serialise (round 4: every gather of the forced
+    one-rank run sat on the rollout's queue).  side_stream() hands out a stream that was timed against the compute stream."""
+    import torch
+    from evacuation_amd.distributed import side_stream
+    dev = torch.device("cuda:0")
+    for _ in range(6):                       # use up a few queue assignments first, as a process group would
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            torch.zeros(8, device=dev)
+    compute = torch.cuda.current_stream(dev)
+    comm = side_stream(dev, beside=compute)
+    assert comm.cuda_stream != compute.cuda_stream
+    spin = 400_000
+
+    def timed(second):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(compute)
+        torch.cuda._sleep(spin)
+        if second is not None:
+            with torch.cuda.stream(second):
+                torch.cuda._sleep(spin)
+            compute.wait_stream(second)
+        e1.record(compute)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+    timed(comm)
+    one, pair = min(timed(None) for _ in range(3)), min(timed(comm) for _ in range(3))
+    assert pair < 1.5 * one, (one, pair)
