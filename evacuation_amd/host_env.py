@@ -46,12 +46,22 @@ class HostVectorEnv:
         self.single_action_space, self.single_observation_space = base.single_action_space, base.single_observation_space
         self.action_space, self.observation_space = base.action_space, base.observation_space
         E, D = self.num_envs, self.obs_dim
-        # device-side packing of the step outputs: [obs(D) | reward | terminated | truncated] per env, one message down
-        self._d_out = torch.empty((E, D + 3), dtype=torch.float32, device=self.device)
-        self._h_out = torch.empty((E, D + 3), dtype=torch.float32, pin_memory=True)
+        # the step kernel writes its outputs straight into the planes of ONE device buffer -- obs [E, D] f32 | reward [E] f32 |
+        # terminated [E] u8 | truncated [E] u8 (step(out_*=)) -- which comes down as one message (round 4: four strided device
+        # copies into a packed [E, D + 3] buffer cost 30 us of host time per step)
+        n_f32 = E * D + E
+        self._d_out = torch.empty((n_f32 * 4 + 2 * E,), dtype=torch.uint8, device=self.device)
+        self._h_out = torch.empty((n_f32 * 4 + 2 * E,), dtype=torch.uint8, pin_memory=True)
+        f32 = self._d_out[:n_f32 * 4].view(torch.float32)
+        self._d_obs, self._d_reward = f32[:E * D].view(E, D), f32[E * D:]
+        self._d_term, self._d_trunc = self._d_out[n_f32 * 4:n_f32 * 4 + E], self._d_out[n_f32 * 4 + E:]
+        h = self._h_out.numpy()
+        hf = h[:n_f32 * 4].view(np.float32)
+        self._np_obs, self._np_reward = hf[:E * D].reshape(E, D), hf[E * D:]
+        self._np_term, self._np_trunc = h[n_f32 * 4:n_f32 * 4 + E], h[n_f32 * 4 + E:]
         self._h_act = torch.empty((E, 2), dtype=torch.float32, pin_memory=True)
         self._d_act = torch.empty((E, 2), dtype=torch.float32, device=self.device)
-        self._np_out, self._np_act = self._h_out.numpy(), self._h_act.numpy()
+        self._np_act = self._h_act.numpy()
         self._reward = np.zeros((E,), dtype=np.float64)            # SyncVectorEnv's buffer dtypes
         self._term = np.zeros((E,), dtype=np.bool_)
         self._trunc = np.zeros((E,), dtype=np.bool_)
@@ -66,26 +76,20 @@ class HostVectorEnv:
         return cls(BatchedEvacuationEnv(cfg, wrap_config, num_envs=num_envs, autoreset=True, **kw), copy=copy)
 
     # ------------------------------------------------------------------------------------------
-    def _download(self, obs, reward=None, term=None, trunc=None):
-        D = self.obs_dim
-        out = self._d_out
-        out[:, :D].copy_(obs)
-        if reward is not None:
-            out[:, D].copy_(reward)
-            out[:, D + 1].copy_(term)
-            out[:, D + 2].copy_(trunc)
-        self._h_out.copy_(out, non_blocking=True)
+    def _download(self, stepped: bool):
+        self._h_out.copy_(self._d_out, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
-        np.copyto(self._obs, self._np_out[:, :D])
-        if reward is not None:
-            np.copyto(self._reward, self._np_out[:, D])               # float32 -> float64, exact
-            np.not_equal(self._np_out[:, D + 1], 0.0, out=self._term)
-            np.not_equal(self._np_out[:, D + 2], 0.0, out=self._trunc)
+        np.copyto(self._obs, self._np_obs)
+        if stepped:
+            np.copyto(self._reward, self._np_reward)                  # float32 -> float64, exact
+            np.not_equal(self._np_term, 0, out=self._term)
+            np.not_equal(self._np_trunc, 0, out=self._trunc)
 
     def reset(self, seed: Optional[int] = None, options=None):
         """``SyncVectorEnv.reset(seed=)`` -> ``(obs [E, D] float32, {})``."""
         obs, infos = self.env.reset(seed=seed, options=options)
-        self._download(obs)
+        self._d_obs.copy_(obs)
+        self._download(False)
         return (self._obs.copy() if self.copy else self._obs), infos
 
     def step(self, actions):
@@ -95,8 +99,9 @@ class HostVectorEnv:
             raise ValueError(f"actions: expected shape {(self.num_envs, 2)}, got {a.shape}")
         np.copyto(self._np_act, a)
         self._d_act.copy_(self._h_act, non_blocking=True)
-        obs, reward, term, trunc, infos = self.env.step(self._d_act)
-        self._download(obs, reward, term, trunc)
+        _, _, _, _, infos = self.env.step(self._d_act, out_obs=self._d_obs, out_reward=self._d_reward, out_terminated=self._d_term,
+                                          out_truncated=self._d_trunc)
+        self._download(True)
         if hasattr(infos, "_done"):                                   # the lazy final_info list: the flags are on the host already
             infos._done = np.logical_or(self._term, self._trunc)
         if self.copy:
