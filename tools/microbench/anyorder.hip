@@ -9,6 +9,7 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 __global__ void k_spin(unsigned long long* out, int slot, unsigned long long ticks) {   // 100 MHz ticks
+    if (slot == 4 && (blockIdx.x & 1)) ticks >>= 1;      // (slot 4: every other workgroup takes half the time -- is the freed half of the chip backfilled?)
     unsigned long long t0, t1;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     do { asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory"); __builtin_amdgcn_s_sleep(8); } while (t1 - t0 < ticks);
@@ -60,7 +61,29 @@ static int train(int grid, int block, unsigned flags, const char* what) {
     return 0;
 }
 
+static int uneven(unsigned flags, const char* what) {
+    unsigned long long* d;
+    CHECK(hipMalloc(&d, 64));
+    hipStream_t s;
+    CHECK(hipStreamCreate(&s));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep) {
+        CHECK(hipEventRecord(e0, s));
+        for (int i = 0; i < 100; ++i) hipExtLaunchKernelGGL(k_spin, dim3(256), dim3(1024), 0, s, nullptr, nullptr, flags, d, 4, 4000ull);   // 40 / 20 us workgroups
+        CHECK(hipEventRecord(e1, s));
+        CHECK(hipStreamSynchronize(s));
+    }
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-44s 256 x 1024, workgroups of 40 and 20 us alternating: %.2f us per launch (backfilled: ~30 + boundary; not: ~40 + boundary)\n", what, ms * 10.0);
+    hipFree(d); hipStreamDestroy(s);
+    return 0;
+}
+
 int main() {
+    if (uneven(0, "default launches")) return 1;
+    if (uneven(hipExtAnyOrderLaunch, "hipExtAnyOrderLaunch")) return 1;
     if (train(256, 1024, 0, "default launches")) return 1;
     if (train(256, 1024, hipExtAnyOrderLaunch, "hipExtAnyOrderLaunch")) return 1;
     if (train(256, 1024, 0, "default launches")) return 1;
