@@ -304,6 +304,11 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         // (a unit-heading component can exceed 1 by a few ulp of v_rsq: 16 units of slack cover it)
         const int64_t cap = (int64_t)0x7fffffff / cfg->number_of_pedestrians - 16;
         p.head_scale = (float)(cap < 0x7ffff0 ? cap : (int64_t)0x7ffff0);     // exact in f32 (< 2^24)
+        // Rooms of 513..1024 pedestrians (team kernels and Cells<16>, which agree bit for bit): the team kernels sum up to
+        // kTeamExactBatch = 8 such headings at a time in packed f32 arithmetic before the partial sum goes to an integer accumulator
+        // (evac_team.h) -- exact below 2^24, so the scale is capped at 2^21 - 16 there (N = 1024 has 2^21 - 17 anyway).
+        if (cfg->number_of_pedestrians > 512 && p.head_scale > (float)((1 << 24) / evac::kTeamExactBatch - 16))
+            p.head_scale = (float)((1 << 24) / evac::kTeamExactBatch - 16);
     }
     {   // CU-wide rollout workgroups pay off once every CU gets its 16 one-wave envs, and as long as the launch is a few
         // rounds deep: a 16-wave workgroup needs a whole CU, so in a long launch every CU idles while the last waves of its

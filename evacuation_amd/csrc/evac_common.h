@@ -64,6 +64,7 @@ constexpr float kExitX = 0.0f, kExitY = -1.0f;                           // area
 // constants.py:35-38 (not configurable in the reference either).  Squared radii are rounded from the double
 // product.
 constexpr float kRLeader2 = (float)(0.2 * 0.2), kRPed2 = (float)(0.1 * 0.1), kRExit = 0.4f, kREscape = 0.01f;
+constexpr int kTeamExactBatch = 8;                       // integer headings of a room with 513..1024 pedestrians (|h| <= 2^31 / N < 2^22) that sum exactly in f32
 constexpr float kTileScale = 0x1.0p40f;                 // tile coordinates are stored times 2^40 (exact)
 constexpr float kRPed2Big = kRPed2 * 0x1.0p80f;        // r_ped^2 * 2^80, exact: the pair test in scaled units
 // boolean options packed into Params::flags (one SGPR instead of seven)

@@ -269,7 +269,7 @@ struct Team {
         if (f.valid) {
             const float ez = f.ev.z, ew = f.ev.w;
             const int hx = (__builtin_bit_cast(int, ez) << 8) >> 8, hy = (__builtin_bit_cast(int, ew) << 8) >> 8;   // (flag byte off, sign back)
-            sm.tile[off + f.rank] = f4{f.ev.x, f.ev.y, __builtin_bit_cast(float, hx), __builtin_bit_cast(float, hy)};
+            sm.tile[off + f.rank] = f4{f.ev.x, f.ev.y, (float)hx, (float)hy};       // integer headings AS FLOATS (|h| < 2^22: exact)
         }
         if (threadIdx.x < kPad) sm.tile[n_cols + threadIdx.x] = f4{__builtin_inff(), 0.0f, 0.0f, 0.0f};
         c.n_cols = n_cols;
@@ -346,22 +346,75 @@ struct Team {
             // pass, the row's position uniform: r * ceil(n_cols / 64) passes of 7 instructions in all instead of n_cols * 14 per
             // sixteenth, whatever r is (6 rows against 200 columns: 24 passes instead of 200 column visits).  The lanes' shares
             // are folded with DPP and lane 63 adds the total to the row's accumulator (integers: the order does not matter).
+            // Round 4: the rows are taken in PAIRS (pair_accumulate_rows2: the two rows' positions uniform in the halves of a
+            // register pair, the column per lane) and the heading sums in packed f32 -- the tile holds the integer headings as
+            // floats (|h| < 2^22) and a lane adds at most kTeamExactBatch = 8 of them before the partial sum goes to its integer
+            // accumulator: exact, the same bits as the integer multiply-adds gave.  6 packed instructions per pass and PAIR of
+            // rows where shift + integer multiply-adds took 7 plain ones per row.
             const f4* __restrict__ tile = sm.tile;
-            int before = 0;                                   // rows of the ped waves before this one: the deal goes on across them
+            const f2 r2b2 = f2{kRPed2Big, kRPed2Big};
+            // the member's rows numbered across its ped waves: row g of the member = (ped wave, slot); pair k = rows 2k, 2k + 1
+            auto row_of = [&](int g, int& pw_out) {      // (compile-time indices into n_rows: it lives in scalar registers)
+                int pw = 0;
 #pragma unroll
-            for (int pw = 0; pw < PW; ++pw) {
-                for (int r = (c.wave - PW - before) & (WPE - 1); r < n_rows[pw]; r += WPE) {   // (the helper waves first: the ped waves come late)
-                    const float2 rp = sm.rowpos[pw][r];       // (uniform address: a broadcast)
-                    int ax = 0, ay = 0;
-                    for (int j0 = 0; j0 < n_cols; j0 += kWave)
-                        pair_accumulate_int(rp.x, rp.y, tile[min(j0 + c.lane, n_cols)], kRPed2Big, ax, ay);   // entry n_cols: padding, weight 0
-                    wave_sum2_int_lane63(ax, ay);             // (64 lanes adding to ONE LDS word would be serialised: fold in registers first)
-                    if (c.lane == kWave - 1) {
-                        lds_add(&sm.acc[pw][r][0], ax);
-                        lds_add(&sm.acc[pw][r][1], ay);
+                for (int q2 = 0; q2 + 1 < PW; ++q2) {
+                    const bool next = pw == q2 && g >= n_rows[q2];
+                    g -= next ? n_rows[q2] : 0;
+                    pw += next ? 1 : 0;
+                }
+                pw_out = pw;
+                return g;
+            };
+            if (n_rows_all <= WPE) {
+                // at most one row per wave (late in an episode: 2-3 VISCEK rows per member): nothing to pair -- one row, one wave
+                int before = 0;                               // rows of the ped waves before this one: the deal goes on across them
+#pragma unroll
+                for (int pw = 0; pw < PW; ++pw) {
+                    for (int r = (c.wave - PW - before) & (WPE - 1); r < n_rows[pw]; r += WPE) {   // (the helper waves first: the ped waves come late)
+                        const float2 rp = sm.rowpos[pw][r];   // (uniform address: a broadcast)
+                        int ax = 0, ay = 0;
+                        for (int j1 = 0; j1 < n_cols; j1 += kTeamExactBatch * kWave) {
+                            float fx = 0.0f, fy = 0.0f;
+                            const int jn = min(n_cols, j1 + kTeamExactBatch * kWave);
+                            for (int j0 = j1; j0 < jn; j0 += kWave)
+                                pair_accumulate(rp.x, rp.y, tile[min(j0 + c.lane, n_cols)], kRPed2Big, fx, fy);   // entry n_cols: padding, weight 0
+                            ax += (int)fx; ay += (int)fy;
+                        }
+                        wave_sum2_int_lane63(ax, ay);         // (64 lanes adding to ONE LDS word would be serialised: fold in registers first)
+                        if (c.lane == kWave - 1) {
+                            lds_add(&sm.acc[pw][r][0], ax);
+                            lds_add(&sm.acc[pw][r][1], ay);
+                        }
+                    }
+                    before += n_rows[pw];
+                }
+            }
+            const int n_pairs = n_rows_all <= WPE ? 0 : (n_rows_all + 1) >> 1;
+            for (int k = (c.wave - PW) & (WPE - 1); k < n_pairs; k += WPE) {      // (the helper waves first: the ped waves come late)
+                int pwa, pwb;
+                const int ra = row_of(2 * k, pwa);
+                const bool two = 2 * k + 1 < n_rows_all;
+                const int rb = two ? row_of(2 * k + 1, pwb) : (pwb = pwa, ra);
+                const float2 pa = sm.rowpos[pwa][ra], pb = sm.rowpos[pwb][rb];     // (uniform addresses: broadcasts)
+                const f2 X2 = f2{pa.x, pb.x}, Y2 = f2{pa.y, pb.y};
+                int ax = 0, ay = 0, bx = 0, by = 0;
+                for (int j1 = 0; j1 < n_cols; j1 += kTeamExactBatch * kWave) {            // (one trip unless the tile has more than 512 columns)
+                    f2 ax2 = f2{0.0f, 0.0f}, ay2 = f2{0.0f, 0.0f};
+                    const int jn = min(n_cols, j1 + kTeamExactBatch * kWave);
+                    for (int j0 = j1; j0 < jn; j0 += kWave)
+                        pair_accumulate_rows2(X2, Y2, tile[min(j0 + c.lane, n_cols)], r2b2, ax2, ay2);   // entry n_cols: padding, weight 0
+                    ax += (int)ax2.x; ay += (int)ay2.x; bx += (int)ax2.y; by += (int)ay2.y;
+                }
+                wave_sum2_int_lane63(ax, ay);                 // (64 lanes adding to ONE LDS word would be serialised: fold in registers first)
+                wave_sum2_int_lane63(bx, by);
+                if (c.lane == kWave - 1) {
+                    lds_add(&sm.acc[pwa][ra][0], ax);
+                    lds_add(&sm.acc[pwa][ra][1], ay);
+                    if (two) {
+                        lds_add(&sm.acc[pwb][rb][0], bx);
+                        lds_add(&sm.acc[pwb][rb][1], by);
                     }
                 }
-                before += n_rows[pw];
             }
           } else {
             // ---- the member's rows against the tile: two ped waves (two rows per lane) per pass, 1/16 of the columns per wave ----
@@ -376,10 +429,12 @@ struct Team {
                     int ax = 0, ay = 0;
                     for (int j = jbeg; j < jend; j += 4) {
                         f4 t[4];
+                        float fx = 0.0f, fy = 0.0f;          // (four integer headings: the float sums are exact)
 #pragma unroll
                         for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) pair_accumulate_int(rr.x, rr.y, t[k], kRPed2Big, ax, ay);
+                        for (int k = 0; k < 4; ++k) pair_accumulate(rr.x, rr.y, t[k], kRPed2Big, fx, fy);
+                        ax += (int)fx; ay += (int)fy;
                     }
                     lds_add(&sm.acc[0][c.lane][0], ax);
                     lds_add(&sm.acc[0][c.lane][1], ay);
@@ -392,25 +447,48 @@ struct Team {
                 const float2 ra = sm.rowpos[pw][c.lane], rb = sm.rowpos[pw + 1][c.lane];   // slots beyond the counts hold stale rows: computed, never read
                 int ax0 = 0, ay0 = 0, ax1 = 0, ay1 = 0;
                 if (na != 0 && nb != 0) {
+                    // (round 4: weights AND sums in packed f32 -- kTeamExactBatch = 8 integer headings sum exactly, then the partial
+                    // sum goes to the integer accumulator: the same bits as before --: 6 packed instructions per column + 10 per
+                    // batch where the integer multiply-adds made it 10 per column)
                     const f2 X2 = f2{ra.x, rb.x}, Y2 = f2{ra.y, rb.y}, r2b2 = f2{kRPed2Big, kRPed2Big};
-                    for (int j = jbeg; j < jend; j += 4) {
-                        f4 t[4];
+                    // (software-pipelined: the four columns after the ones at hand are on their way from LDS while these are
+                    // evaluated -- the asm fences keep the compiler from sinking the loads to their uses; reading up to four
+                    // entries past the wave's share is harmless, the tile is padded)
+                    int j = jbeg;
+                    f4 ta[4], tb[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+                    for (int k = 0; k < 4; ++k) ta[k] = tile[j + k];
+                    for (; j + 8 <= jend; j += 8) {             // (the wave's share is a multiple of 4 columns)
+                        f2 ax2 = f2{0.0f, 0.0f}, ay2 = f2{0.0f, 0.0f};
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            pair_accumulate_int_rows2(X2, Y2, t[k], r2b2, ax0, ay0, ax1, ay1);      // (the two weights in packed arithmetic: 10 instead of 14 instructions)
-                        }
+                        for (int k = 0; k < 4; ++k) tb[k] = tile[j + 4 + k];
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) pair_accumulate_rows2(X2, Y2, ta[k], r2b2, ax2, ay2);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) ta[k] = tile[j + 8 + k];
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) pair_accumulate_rows2(X2, Y2, tb[k], r2b2, ax2, ay2);
+                        ax0 += (int)ax2.x; ax1 += (int)ax2.y; ay0 += (int)ay2.x; ay1 += (int)ay2.y;
+                    }
+                    if (j < jend) {
+                        f2 ax2 = f2{0.0f, 0.0f}, ay2 = f2{0.0f, 0.0f};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) pair_accumulate_rows2(X2, Y2, ta[k], r2b2, ax2, ay2);
+                        ax0 += (int)ax2.x; ax1 += (int)ax2.y; ay0 += (int)ay2.x; ay1 += (int)ay2.y;
                     }
                 } else {
                     const float2 rr = na != 0 ? ra : rb;
                     int ax = 0, ay = 0;
                     for (int j = jbeg; j < jend; j += 4) {
                         f4 t[4];
+                        float fx = 0.0f, fy = 0.0f;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) pair_accumulate_int(rr.x, rr.y, t[k], kRPed2Big, ax, ay);
+                        for (int k = 0; k < 4; ++k) pair_accumulate(rr.x, rr.y, t[k], kRPed2Big, fx, fy);
+                        ax += (int)fx; ay += (int)fy;
                     }
                     ax0 = ax1 = ax;
                     ay0 = ay1 = ay;
