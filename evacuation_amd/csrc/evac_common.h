@@ -314,6 +314,19 @@ __device__ __forceinline__ void pair_accumulate_rows2(f2 X2, f2 Y2, f4 t, f2 r2b
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(ay2) : "v"(w), "v"(tzw));                      // += w * t.w
 }
 
+// ... the first column of a batch: the sums START at w * heading (two packed multiplies where zeroed accumulators and two FMAs
+// would be four instructions)
+__device__ __forceinline__ void pair_start_rows2(f2 X2, f2 Y2, f4 t, f2 r2b2, f2& ax2, f2& ay2) {
+    const f2 txy = __builtin_shufflevector(t, t, 0, 1), tzw = __builtin_shufflevector(t, t, 2, 3);
+    f2 dx, dy, w;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dx) : "v"(X2), "v"(txy));                 // X - t.x
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dy) : "v"(Y2), "v"(txy));    // Y - t.y
+    const f2 a = __builtin_elementwise_fma(-dy, dy, r2b2);
+    asm("v_pk_fma_f32 %0, %1, %1, %2 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(w) : "v"(dx), "v"(a));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(ax2) : "v"(w), "v"(tzw));                                           // = w * t.z
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(ay2) : "v"(w), "v"(tzw));                              // = w * t.w
+}
+
 // The same pair with the unit heading stored as integers (heading * Params::head_scale, rounded): the weight's
 // bit pattern (0x3f800000 or 0) shifted down is the integer 1 or 0, and the sums are integer multiply-adds
 // (v_mad_i32_i24: |heading| < 2^23; N of them fit an int32).  Integer addition is exact, so the sum does not depend on the order in

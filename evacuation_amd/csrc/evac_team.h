@@ -459,12 +459,13 @@ struct Team {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) ta[k] = tile[j + k];
                     for (; j + 8 <= jend; j += 8) {             // (the wave's share is a multiple of 4 columns)
-                        f2 ax2 = f2{0.0f, 0.0f}, ay2 = f2{0.0f, 0.0f};
+                        f2 ax2, ay2;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) tb[k] = tile[j + 4 + k];
                         asm volatile("" ::: "memory");
+                        pair_start_rows2(X2, Y2, ta[0], r2b2, ax2, ay2);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) pair_accumulate_rows2(X2, Y2, ta[k], r2b2, ax2, ay2);
+                        for (int k = 1; k < 4; ++k) pair_accumulate_rows2(X2, Y2, ta[k], r2b2, ax2, ay2);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) ta[k] = tile[j + 8 + k];
                         asm volatile("" ::: "memory");
@@ -473,9 +474,10 @@ struct Team {
                         ax0 += (int)ax2.x; ax1 += (int)ax2.y; ay0 += (int)ay2.x; ay1 += (int)ay2.y;
                     }
                     if (j < jend) {
-                        f2 ax2 = f2{0.0f, 0.0f}, ay2 = f2{0.0f, 0.0f};
+                        f2 ax2, ay2;
+                        pair_start_rows2(X2, Y2, ta[0], r2b2, ax2, ay2);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) pair_accumulate_rows2(X2, Y2, ta[k], r2b2, ax2, ay2);
+                        for (int k = 1; k < 4; ++k) pair_accumulate_rows2(X2, Y2, ta[k], r2b2, ax2, ay2);
                         ax0 += (int)ax2.x; ax1 += (int)ax2.y; ay0 += (int)ay2.x; ay1 += (int)ay2.y;
                     }
                 } else {
