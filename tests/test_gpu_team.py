@@ -266,3 +266,41 @@ def test_two_team_grids_on_two_streams_take_turns(ea):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     for e in refs + tms:
         e.close()
+
+
+@pytest.mark.parametrize("n,team", [(1024, 8), (1024, 16), (1024, 2), (513, 8), (640, 4)])
+def test_packed_f32_heading_sums_are_exact_at_their_limit(ea, n, team):
+    """The team sweeps add the integer headings eight at a time in packed f32 before the partial sum goes to an integer
+    accumulator (evac_team.h, kTeamExactBatch): exact only below 2^24.  The worst case -- every pedestrian of the room inside one
+    interaction radius, all headings along one axis, so that every partial sum is eight times the scale (2^21 - 17 for N = 1024,
+    capped at 2^21 - 16 for smaller rooms) -- must still reproduce the cell-list kernels' integer sums bit for bit."""
+    import torch
+    E = 8 if team != 16 else 4
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=1000, is_new_exiting_reward=True, enslaving_degree=1.0, noise_coef=0.0)
+    wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
+    ref = _make(ea, cfg, wrap, E, 3, team=0)
+    tm = _make(ea, cfg, wrap, E, 3, team=team)
+    assert "CUs/env" in tm.kernel_variant("rollout") and "CUs/env" not in ref.kernel_variant("rollout")
+    ref.reset(); tm.reset()
+    g = torch.Generator().manual_seed(n + team)
+    for axis in range(8):                                       # +x, -x, +y, -y; then the same with few rows (the transposed sweep)
+        few_rows = axis >= 4
+        axis %= 4
+        d = torch.zeros((E, n, 2))
+        d[..., axis // 2] = 0.01 * (1.0 if axis % 2 == 0 else -1.0)
+        pos = (torch.rand((E, n, 2), generator=g) - 0.5) * 0.05 + torch.tensor([0.3, 0.4])        # one blob, well inside the radius of 0.1
+        status = torch.ones((E, n), dtype=torch.uint8)                                            # all VISCEK: every row is evaluated
+        if few_rows:                                            # three of four pedestrians FOLLOWERS: columns, but no rows (enslaving_degree 1)
+            status[:, torch.arange(n) % 4 != 0] = 2
+        st = dict(pos=pos, dir=d, status=status,
+                  agent_pos=torch.tensor([[-0.8, -0.8]]).repeat(E, 1), agent_dir=torch.zeros((E, 2)), now=torch.zeros((E,), dtype=torch.int32))
+        ref.set_state(**st); tm.set_state(**st)
+        a, b = ref.rollout(3), tm.rollout(3)
+        torch.cuda.synchronize()
+        assert tm.team_error() == 0
+        for key in ("obs", "reward", "terminated", "truncated"):
+            assert torch.equal(a[key].view(torch.int32), b[key].view(torch.int32)), (axis, key)
+        sa, sb = ref.get_state(), tm.get_state()
+        for key in sa:
+            assert torch.equal(sa[key], sb[key]), (axis, few_rows, key)
+    ref.close(); tm.close()
