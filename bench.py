@@ -463,7 +463,7 @@ def main(argv=None):
             if gather_rollout:
                 # the chunk's outputs are complete HERE on the compute stream.  (Rounds 2-3 recorded this event inside gather(),
                 # i.e. after the NEXT launch had been enqueued: the gather of chunk j-1 then waited for launch j to finish and
-                # never ran under it -- tools/gather_cost.py, profiles/r04_i_force_gather_world1.txt.)
+                # never ran under it -- tools/gather_cost.py, profiles/r04_j_force_gather_world1.txt.)
                 b["ready"].record(compute)
         else:
             loc.step(step_actions)
@@ -497,7 +497,7 @@ def main(argv=None):
         """Before a chunk reuses a buffer: the gather that read it is done.  Checked on the HOST (a query; a host-side wait only
         if the host has run `nbuf - 1` chunks ahead of the device) -- a device-side `compute.wait_event(fin)` puts a barrier
         packet between two rollout launches and costs 7-10 us per chunk on this runtime whether or not the event has fired
-        (profiles/r04_i_force_gather_world1.txt: 58.6 -> 48.2 us per chunk).  --device-wait restores it."""
+        (profiles/r04_j_force_gather_world1.txt: 58.6 -> 48.2 us per chunk).  --device-wait restores it."""
         if fin is None:
             return
         if args.device_wait:

@@ -19,11 +19,11 @@
 //     tile -- the columns of the next step's distance matrix.  (The first step of a launch and the step after an
 //     autoreset run the same exchange on their own.)
 // The rows are the member's own pedestrians that need one (step_env: needs_row), compacted per ped wave.  MANY rows (early in
-// an episode): two ped waves per pass (two rows per lane), each of the 16 waves takes 1/16 of the columns (wave-uniform
-// ds_read_b128 broadcasts).  FEW rows (<= kFewRows: most of an episode under enslaving_degree 1, when only the VISCEK
+// an episode): two ped waves per pass (two rows per lane -- or one, when the rows of both fit the 64 lanes), each of the 16 waves
+// takes 1/16 of the columns (wave-uniform ds_read_b128 broadcasts).  FEW rows (<= kFewRows: most of an episode under enslaving_degree 1, when only the VISCEK
 // pedestrians need one): the sweep is transposed -- the rows are dealt to the 16 waves, the lanes hold the columns.  Either
 // way the partial sums of a row meet in its LDS accumulator by integer atomics.  Heading sums are INTEGERS
-// (pair_accumulate_int), so the result does not depend on how the pairs were split -- it is bit-identical to the cell-list
+// (taken eight at a time in packed f32 -- exact -- since round 4), so the result does not depend on how the pairs were split -- it is bit-identical to the cell-list
 // kernel's (Cells<16>).
 // Everything else is the common step body (step_env) and rollout scaffolding (rollout_body); waves without pedestrians
 // ("helper" waves) skip the per-pedestrian arithmetic.
@@ -44,7 +44,7 @@
 namespace evac {
 
 // (measured at C5, profiles/r03_g_c5_ab_few_rows_threshold.txt and r03_g_c5_ab_sentinel_exchange.txt)
-constexpr int kTeamFewRows = 64;     // needed rows of a member up to which its sweep is transposed (32 the same, 96 / 128 12-15 % slower)
+constexpr int kTeamFewRows = 32;     // needed rows of a member up to which its sweep is transposed (with the packed-f32 sweeps of round 4: 16-32 flat, 48 -3 %, 64 -8 %, 96 -20 %: profiles/r04_j_c5_few_rows_threshold.txt)
 constexpr int kTeamFirstPoll = 8;    // s_sleep units (64 cycles) between the member's own publish and its first poll (8-12 flat, 2-4 cost 2-3 %)
 constexpr int kTeamPollGap = 2;      // ... between two polls
 
@@ -444,6 +444,40 @@ struct Team {
             for (int pw = 0; pw + 1 < PW; pw += 2) {
                 const int na = sm.rows[pw], nb = sm.rows[pw + 1];
                 if (na + nb == 0) continue;                                    // uniform
+                if (na != 0 && nb != 0 && na + nb <= kWave) {
+                    // the rows of BOTH ped waves fit one lane each (the middle of an episode: 33 .. 64 needed rows per member): one
+                    // row per lane -- lanes [0, na) the first wave's, [na, na + nb) the second's -- in plain arithmetic, 6
+                    // instructions per column + 4 per eight where the two-rows-per-lane form spends 6 PACKED ones (1.6x the pipe
+                    // time each) + 10 on register pairs that are half empty
+                    const bool second = c.lane >= na;
+                    const float2 rr = second ? sm.rowpos[pw + 1][min(c.lane - na, kWave - 1)] : sm.rowpos[pw][c.lane];
+                    int ax = 0, ay = 0;
+                    int j = jbeg;
+                    for (; j + 8 <= jend; j += 8) {
+                        f4 t[8];
+                        float fx = 0.0f, fy = 0.0f;          // (eight integer headings: the float sums are exact)
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) t[k] = tile[j + k];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) pair_accumulate(rr.x, rr.y, t[k], kRPed2Big, fx, fy);
+                        ax += (int)fx; ay += (int)fy;
+                    }
+                    if (j < jend) {
+                        f4 t[4];
+                        float fx = 0.0f, fy = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) t[k] = tile[j + k];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) pair_accumulate(rr.x, rr.y, t[k], kRPed2Big, fx, fy);
+                        ax += (int)fx; ay += (int)fy;
+                    }
+                    if (c.lane < na + nb) {
+                        int* dst = second ? sm.acc[pw + 1][c.lane - na] : sm.acc[pw][c.lane];
+                        lds_add(dst, ax);
+                        lds_add(dst + 1, ay);
+                    }
+                    continue;
+                }
                 const float2 ra = sm.rowpos[pw][c.lane], rb = sm.rowpos[pw + 1][c.lane];   // slots beyond the counts hold stale rows: computed, never read
                 int ax0 = 0, ay0 = 0, ax1 = 0, ay1 = 0;
                 if (na != 0 && nb != 0) {

@@ -52,7 +52,7 @@ def side_stream(device, beside=None, candidates: int = 8) -> "torch.cuda.Stream"
     streams onto a handful of hardware queues (4 by default) in the order in which they are first used, and two streams that share
     a queue execute strictly one after the other -- with the process group's and the allocator's streams created first, a fresh
     ``torch.cuda.Stream()`` landed on the compute stream's own queue in bench.py's forced-gather runs of round 4 and the gather never
-    ran under the rollout (profiles/r04_i_force_gather_world1.txt).  So: time two one-thread spin kernels (``torch.cuda._sleep``),
+    ran under the rollout (profiles/r04_j_force_gather_world1.txt).  So: time two one-thread spin kernels (``torch.cuda._sleep``),
     one on each stream; a pair that takes as long as one of them overlaps.  The first candidate that does is returned (the others are
     dropped; their queue assignments stay used up, which is what moves the next candidate on).  Falls back to the last candidate."""
     device = torch.device(device)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copies what tools/final_run.sh TAG left under gpurun_out/ into profiles/ under the names DESIGN.md cites (run here, after the
-# gpurun call has merged its outputs back).  usage: tools/collect_profiles.sh r04_i
+# gpurun call has merged its outputs back).  usage: tools/collect_profiles.sh r04_j
 set -e
 T=${1:?tag}
 cd "$(dirname "$0")/.."

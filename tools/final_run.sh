@@ -1,6 +1,6 @@
 # The round's measurements (run ON the GPU box: gpurun -- bash tools/final_run.sh <tag>): bench lines under gpurun_out/<tag>/,
 # rocprofv3 --stats + PMC passes under gpurun_out/<tag>_<workload>/ (tools/profile_pmc.sh), then profiles/traffic.json.
-TAG=${1:-r04_i}
+TAG=${1:-r04_j}
 mkdir -p gpurun_out/$TAG; cd gpurun_out/$TAG
 python ../../bench.py --steps 20 --warmup 5 > bench_c2_driver.json 2> bench_c2_driver.err
 python ../../bench.py --no-cpu-baseline > bench_c2_default.json 2>/dev/null
