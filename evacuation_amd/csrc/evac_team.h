@@ -45,7 +45,7 @@ namespace evac {
 
 // (measured at C5, profiles/r03_g_c5_ab_few_rows_threshold.txt and r03_g_c5_ab_sentinel_exchange.txt)
 constexpr int kTeamFewRows = 32;     // needed rows of a member up to which its sweep is transposed (with the packed-f32 sweeps of round 4: 16-32 flat, 48 -3 %, 64 -8 %, 96 -20 %: profiles/r04_j_c5_few_rows_threshold.txt)
-constexpr int kTeamFirstPoll = 8;    // s_sleep units (64 cycles) between the member's own publish and its first poll (8-12 flat, 2-4 cost 2-3 %)
+constexpr int kTeamFirstPoll = 12;   // s_sleep units (64 cycles) between the member's own publish and its first poll (round 4, after the sweeps got faster: 12 +1 % over 8, 4 -3 %, 16 -1 %, 24 -5 %)
 constexpr int kTeamPollGap = 2;      // ... between two polls
 
 __device__ __forceinline__ void store_dev(void* ptr, f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
