@@ -87,10 +87,14 @@ def parse_args(argv=None):
     ap.add_argument("--envs", type=int, default=0, help="override envs per GPU")
     ap.add_argument("--inner", type=int, default=100, help="env steps per kernel launch (rollout mode)")
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"])
-    ap.add_argument("--sweeps", type=int, default=0, help="passes over the episode (0: 3, or 1 when a block is a whole episode)")
+    ap.add_argument("--sweeps", type=int, default=0, help="passes over the episode (0: 11, or 1 when a block is a whole episode -- then raised until 20 blocks are timed)")
     ap.add_argument("--blocks", type=int, default=0, help="override the number of timed K-step blocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-api", action="store_true", help="skip the one-launch-per-step side measurement")
+    ap.add_argument("--no-side-workloads", action="store_true",
+                    help="skip the short runs of BASELINE configs 3 and 5 (one GPU's shard) and of the 524 288-env per-step run that ride "
+                         "along with the default C2 line as `workloads`")
+    ap.add_argument("--side-sweeps", type=int, default=5, help="episode sweeps per side workload (rollout mode)")
     ap.add_argument("--no-gather", action="store_true", help="skip the all-gather of the outputs (N>1)")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the gather path -- process group, collective on the comm stream, double-buffered pipeline -- with "
@@ -241,7 +245,7 @@ def block_plan(K: int, sweeps: int, blocks: int):
     """(blocks per sweep, sweeps): consecutive K-step blocks tile the episode."""
     per_sweep = max(1, math.ceil(EPISODE / K))
     if sweeps <= 0:
-        sweeps = 1 if per_sweep == 1 else 3
+        sweeps = 1 if per_sweep == 1 else 11             # (SURVEY.md 8(d): median of >= 5 repeats; eleven 20-step sweeps are 50 ms of GPU time)
     while per_sweep * sweeps < 20:                     # at least 20 timed blocks
         sweeps += 1
     if blocks > 0:
@@ -352,6 +356,102 @@ class ChunkPipeline:
             self._issue_gather(self.ungathered)
             self.ungathered = None
         self.drain()
+
+
+# --------------------------------------------------------------------------------------------------
+# side workloads: BASELINE configs 3 and 5 (one GPU's shard) and the roofline-evidence run, inside the driver's line
+# --------------------------------------------------------------------------------------------------
+SIDE_WORKLOADS = (
+    # key in `workloads`, WORKLOADS name, mode, steps per launch
+    ("c3", "c3", "rollout", 100),
+    ("c5_shard", "c5", "rollout", 100),
+    ("big_step", "big", "step", 1),
+)
+
+
+def side_workload(name: str, mode: str, inner: int, sweeps: int, device, traffic_json: str):
+    """One BASELINE config beside the headline: whole episode sweeps (2000 steps each, launches back to back, bracketed by
+    torch.cuda.synchronize and two HIP events on the launching stream) of a fresh batch, after one untimed sweep's worth of
+    warm-up launches (200 steps).  Returns the entry of `workloads` in the bench line.  `value` = envs / (median sweep / 2000),
+    `roofline` as for the headline: ALGORITHMIC bytes per launch / the mean launch of the median sweep (HIP events), counter
+    traffic from profiles/traffic.json under the same guard.  The per-step run of the 524 288-env batch (state 503 MB: every
+    step reads and writes it through HBM) is timed over ONE episode sweep of evac_step launches."""
+    import statistics
+
+    import torch
+
+    import evacuation_amd as ea
+
+    n_ped, E, wrap_kw, desc = WORKLOADS[name]
+    cfg = ea.EnvConfig(number_of_pedestrians=n_ped, is_new_exiting_reward=True, is_new_followers_reward=True,
+                       intrinsic_reward_coef=0.0, max_timesteps=EPISODE)
+    env = ea.BatchedEvacuationEnv(cfg, ea.EnvWrappersConfig(**wrap_kw), num_envs=E, device=device,
+                                  seed=0x5EED0000 + sorted(WORKLOADS).index(name))
+    env.reset()
+    stream = torch.cuda.current_stream(device)
+    if mode == "rollout":
+        out = {"slab": torch.empty((inner, E, env.obs_dim + 3), dtype=torch.float32, device=device),
+               "episode_stats": torch.zeros((inner, E, env.stats_words), dtype=torch.float32, device=device)}
+        go = env.rollout_launcher(inner, out, stream=stream)
+        launches = EPISODE // inner
+        warm = max(1, 200 // inner)
+    else:
+        actions = torch.rand((E, 2), device=device) * 2 - 1
+        go = env.step_launcher(actions, stream=stream)
+        launches, warm, sweeps = EPISODE, 20, 1
+    for _ in range(warm):
+        go()
+    torch.cuda.synchronize()
+    wall, dev = [], []
+    for _ in range(sweeps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for _ in range(launches):
+            go()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        wall.append(time.perf_counter() - t0)
+        dev.append(e0.elapsed_time(e1) * 1e-3)
+    if env.team_error():
+        raise SystemExit(f"bench.py: evac_team_error is set in side workload {name}; results discarded")
+    sweep_s = statistics.median(wall)
+    kernel_s = statistics.median(dev) / launches
+    variant = env.kernel_variant(mode)
+    tr = load_traffic(traffic_json, f"{name}:{mode}", variant, csrc_sha16())
+    bytes_per_env_step = env.algorithmic_bytes_per_env_step
+    bytes_per_launch = bytes_per_env_step * E * inner
+    achieved = bytes_per_launch / kernel_s / 1e9
+    traffic = tr["hbm_bytes_per_env_step"] * E * inner if tr["hbm_bytes_per_env_step"] is not None else None
+    value = E / (sweep_s / EPISODE)
+    env.close()
+    return {
+        "workload": desc, "mode": mode, "envs": E, "n_pedestrians": n_ped, "steps_per_launch": inner,
+        "value": value, "unit": "env-steps/s", "agent_updates_per_s": value * n_ped, "ms_per_step": sweep_s / EPISODE * 1e3,
+        "sweeps": {"timed": sweeps, "launches_per_sweep": launches, "wall_ms": [x * 1e3 for x in wall], "hip_event_ms": [x * 1e3 for x in dev],
+                   "value_min_median_max": [E * EPISODE / max(wall), value, E * EPISODE / min(wall)]},
+        "kernel": variant, "kernel_ms_per_launch": kernel_s * 1e3,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": traffic, "traffic_source": tr["source"], "traffic_note": tr["note"],
+                     "hbm_traffic_frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                     "algorithmic_bytes_per_env_step": bytes_per_env_step, "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "valu_wave_insts_per_env_step": tr["valu"], "salu_wave_insts_per_env_step": tr["salu"],
+                     "valu_pipe_frac": (tr["valu"] * 64.0 * E * inner / kernel_s / VALU_PIPE_PEAK) if tr["valu"] else None,
+                     "equivalent_bandwidth": mode == "rollout"},
+    }
+
+
+def side_workloads(args, device):
+    """`workloads` of the default line: each entry measured as side_workload() says; an entry that fails carries the error."""
+    out = {}
+    for key, name, mode, inner in SIDE_WORKLOADS:
+        try:
+            out[key] = side_workload(name, mode, inner, args.side_sweeps, device, args.traffic_json)
+        except SystemExit:
+            raise
+        except Exception as exc:  # noqa: BLE001
+            out[key] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+    return out
 
 
 def main(argv=None):

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+from collections import OrderedDict
 from typing import Dict as TDict, Optional
 
 import numpy as np
@@ -200,7 +201,8 @@ class BatchedEvacuationEnv:
         self.algorithmic_bytes_per_env_step = int(self.lib.evac_algorithmic_bytes_per_env_step(self._h))
         self._was_reset = False
         self._steps_taken = 0          # step() calls so far (StepInfos: a lazily built final_info must be read before the next one)
-        self._step_cache = {}          # step(): bound ctypes calls by buffer addresses (see step)
+        self._step_cache = OrderedDict()   # step(): bound ctypes calls by buffer addresses, oldest first (see step)
+        self._step_misses = 0          # consecutive step() calls that missed the cache (see _remember_step)
         self._stream_args = {}         # raw stream handle -> its ctypes argument
 
     # ------------------------------------------------------------------------------------------
@@ -258,6 +260,11 @@ class BatchedEvacuationEnv:
         _lib.check(self.lib.evac_team_clear_error(self._h), self._h)
 
     def close(self):
+        # (the bound calls of step() hold the handle: they go first, so that a step() after close() takes the checked path and
+        # gets EVAC_ERR_INVALID_ARGUMENT for the NULL handle instead of calling into a destroyed one)
+        if getattr(self, "_step_cache", None) is not None:
+            self._step_cache.clear()
+            self._stream_args.clear()
         if getattr(self, "_h", None) is not None and self._h.value:
             self.lib.evac_destroy(self._h)
             self._h = C.c_void_p()
@@ -308,15 +315,12 @@ class BatchedEvacuationEnv:
                 if rc != 0:
                     _lib.check(rc, self._h)
                 self._steps_taken += 1
-                obs, rew, term, trunc = ent[2]
-                if out_obs is not None:       # (the caller's own objects back, as the uncached path returns them)
-                    obs = out_obs
-                if out_reward is not None:
-                    rew = out_reward
-                if out_terminated is not None:
-                    term = out_terminated
-                if out_truncated is not None:
-                    trunc = out_truncated
+                self._step_misses = 0
+                # (the caller's own objects back, as the uncached path returns them; the env's buffers otherwise)
+                obs = self.obs if out_obs is None else out_obs
+                rew = self.reward if out_reward is None else out_reward
+                term = self.terminated if out_terminated is None else out_terminated
+                trunc = self.truncated if out_truncated is None else out_truncated
                 infos = StepInfos(self, term, trunc, final_observation=self.final_obs, episode_stats=self.final_stats) if self.autoreset else {}
                 return obs, rew, term, trunc, infos
         E, N = self.num_envs, self.n_ped
@@ -349,37 +353,49 @@ class BatchedEvacuationEnv:
             infos = StepInfos(self, term, trunc, final_observation=self.final_obs, episode_stats=self.final_stats)
         return obs, rew, term, trunc, infos
 
+    _STEP_CACHE_ENTRIES = 4096       # >= the reference trainer's num_steps storage rows (rpo_agent.py:60: 2048)
+
     def _remember_step(self, key, act, out_obs, out_reward, out_terminated, out_truncated, outs, fo, fs, _norm):
-        """Bind the ctypes call of a step that just passed every argument check (see ``step``).  The entry keeps its tensors
-        alive and re-validates on every hit what an address alone does not pin: shape, dtype and contiguity of the caller's
-        tensors (a different view can start at the same address)."""
+        """Bind the ctypes call of a step that just passed every argument check (see ``step``).  An entry holds ADDRESSES, not
+        tensors: a hit is keyed by the ``data_ptr`` of the tensors being passed NOW -- alive by definition -- and re-validates
+        what an address alone does not pin (shape, dtype, contiguity, device: a different view or a tensor of another device can
+        start at the same address).  Nothing the caller owns is kept alive, so a policy loop that makes a fresh ``actions``
+        tensor every step pins no memory (a kept tensor per miss held up to 4096 x E x 8 bytes); only the env's own
+        buffers and the normalisation state -- which live as long as the env anyway -- are referenced.  Oldest entries are
+        evicted one at a time; after 256 misses in a row (fresh tensors at fresh addresses every step: nothing to hit) calls
+        without any ``out_*`` storage row are no longer bound, so such a loop stops paying for entries it never uses."""
+        if self._step_misses >= 256 and out_obs is None and out_reward is None and out_terminated is None and out_truncated is None:
+            return
+        self._step_misses += 1
         E, D = self.num_envs, self.obs_dim
-        f32, u8 = torch.float32, torch.uint8
+        f32, u8, idx = torch.float32, torch.uint8, self._dev_index
+
+        def ok(t, shape, dtype):
+            return t.shape == shape and t.dtype is dtype and t.is_cuda and t.get_device() == idx and t.is_contiguous()
 
         def same(a, o, r, t, u, _s=((E, 2), (E, D), (E,), (E,), (E,))):
-            return (a.shape == _s[0] and a.dtype is f32 and a.is_contiguous()
-                    and (o is None or (o.shape == _s[1] and o.dtype is f32 and o.is_contiguous()))
-                    and (r is None or (r.shape == _s[2] and r.dtype is f32 and r.is_contiguous()))
-                    and (t is None or (t.shape == _s[3] and t.dtype is u8 and t.is_contiguous()))
-                    and (u is None or (u.shape == _s[4] and u.dtype is u8 and u.is_contiguous())))
+            return (ok(a, _s[0], f32) and (o is None or ok(o, _s[1], f32)) and (r is None or ok(r, _s[2], f32))
+                    and (t is None or ok(t, _s[3], u8)) and (u is None or ok(u, _s[4], u8)))
         obs, rew, term, trunc = outs
-        h, ar = self._h, int(self.autoreset)
+        ar = int(self.autoreset)
         a = (_ptr(act), _ptr(obs), _ptr(rew), _ptr(term), _ptr(trunc))
         if _norm is None:
             fn = self.lib.evac_step
 
-            def call(st, _keep=(act, outs)):
-                return fn(h, a[0], None, a[1], a[2], a[3], a[4], ar, fo, fs, st)
+            def call(st):
+                return fn(self._h, a[0], None, a[1], a[2], a[3], a[4], ar, fo, fs, st)   # (the handle as it is at call time)
         else:
             fn = self.lib.evac_step_normalized
             state, gamma, obs_clip, reward_clip, eps = _norm
             a_state = _ptr(state)
 
-            def call(st, _keep=(act, outs, state)):
-                return fn(h, a[0], None, a[1], a[2], a[3], a[4], ar, fo, fs, a_state, gamma, obs_clip, reward_clip, eps, st)
-        if len(self._step_cache) >= 4096:            # (a trainer's storage rows: num_steps entries; bounded all the same)
-            self._step_cache.clear()
-        self._step_cache[key] = (same, call, outs)
+            def call(st, _keep=state):      # (the wrapper's own statistics buffer)
+                return fn(self._h, a[0], None, a[1], a[2], a[3], a[4], ar, fo, fs, a_state, gamma, obs_clip, reward_clip, eps, st)
+        cache = self._step_cache
+        cache.pop(key, None)
+        while len(cache) >= self._STEP_CACHE_ENTRIES:
+            cache.popitem(last=False)
+        cache[key] = (same, call)
 
     def step_launcher(self, actions, *, out_obs=None, out_reward=None, out_terminated=None, out_truncated=None, stream=None):
         """A zero-argument callable that enqueues ``step(actions, out_*=...)`` with every ctypes argument prepared once -- for a

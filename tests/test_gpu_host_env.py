@@ -169,3 +169,46 @@ def test_step_cache_revalidates_shapes_and_returns_the_callers_tensors():
     with pytest.raises(ValueError):
         env.step(flat)                        # same address as a cached entry, wrong shape
     env.close(); ref.close()
+
+
+def test_step_cache_pins_no_caller_tensor_and_dies_with_the_env():
+    """an entry of the step() cache holds addresses, never the caller's tensors -- a policy loop that makes a fresh
+    ``actions`` tensor every step must not pin one [E, 2] block per step --, the cache evicts its oldest entry instead of
+    growing, a loop that never hits stops binding calls, and close() drops the bound calls (a step() after close() gets the
+    library's INVALID_ARGUMENT for the NULL handle, not a call into a destroyed one)."""
+    import weakref
+    import torch
+    import evacuation_amd as ea
+    E, n = 5, 12
+    env = ea.BatchedEvacuationEnv(ea.EnvConfig(number_of_pedestrians=n), ea.EnvWrappersConfig(positions="grav"), num_envs=E, seed=3)
+    env.reset()
+    env._STEP_CACHE_ENTRIES = 8
+    refs, held = [], []
+    for t in range(40):
+        a = torch.rand((E, 2), device=env.device) * 2 - 1
+        refs.append(weakref.ref(a))
+        if t < 20:
+            held.append(a)                    # distinct live addresses: every call a miss that binds an entry
+        env.step(a)
+        del a
+    assert len(env._step_cache) <= 8          # oldest entries evicted, never cleared wholesale nor grown past the bound
+    assert all(r() is None for r in refs[20:])     # nothing but the caller kept those tensors alive
+    del held
+    assert all(r() is None for r in refs)          # ... and the cache pins none of the first twenty either
+    # a loop that never hits stops paying for entries
+    env._step_cache.clear(); env._step_misses = 256
+    keep = [torch.zeros((E, 2), device=env.device) for _ in range(3)]
+    for a in keep:
+        env.step(a)
+    assert len(env._step_cache) == 0
+    store = torch.zeros((E, env.obs_dim), device=env.device)
+    env.step(keep[0], out_obs=store)          # storage rows are still bound
+    assert len(env._step_cache) == 1
+    o1 = env.step(keep[0], out_obs=store)[0]  # ... and hit, which re-arms the binding of plain calls
+    assert o1 is store and env._step_misses == 0
+    # another device's tensor at a cached address cannot hit: `same` checks the device index (only testable with > 1 GPU)
+    env.close()
+    assert len(env._step_cache) == 0
+    from evacuation_amd._lib import EvacError
+    with pytest.raises(EvacError):
+        env.step(keep[0], out_obs=store)

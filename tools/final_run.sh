@@ -1,6 +1,6 @@
 # The round's measurements (run ON the GPU box: gpurun -- bash tools/final_run.sh <tag>): bench lines under gpurun_out/<tag>/,
 # rocprofv3 --stats + PMC passes under gpurun_out/<tag>_<workload>/ (tools/profile_pmc.sh), then profiles/traffic.json.
-TAG=${1:-r04_j}
+TAG=${1:-r05_a}
 mkdir -p gpurun_out/$TAG; cd gpurun_out/$TAG
 python ../../bench.py --steps 20 --warmup 5 > bench_c2_driver.json 2> bench_c2_driver.err
 python ../../bench.py --no-cpu-baseline > bench_c2_default.json 2>/dev/null
@@ -21,7 +21,6 @@ python ../../tools/gather_cost.py 2>&1 | grep "us per gather\|bracket" > gather_
 python ../../tools/subwave_bench.py > subwave.txt 2>&1
 python ../../examples/rollout_with_policy.py > policy_example.txt 2>&1
 python ../../tools/launch_intercept.py > launch_intercept.txt 2>&1
-../../tools/microbench/mfma_4x4 > mfma_4x4.txt 2>&1
 cd ../..
 bash tools/profile_pmc.sh ${TAG}_c2_driver > /dev/null 2>&1
 bash tools/profile_pmc.sh ${TAG}_c3 --workload c3 --steps 400 --warmup 100 --sweeps 1 > /dev/null 2>&1

@@ -3,11 +3,11 @@
 #   bash tools/stamps.sh build      (here)      ;   gpurun -- bash tools/stamps.sh run
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 if [ "${1:-build}" = "build" ]; then
-  mkdir -p "$ROOT/tools/ablate_libs"
+  mkdir -p "$ROOT/tools/ab_libs"
   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -std=c++17 -fPIC -shared -DEVAC_STAMP \
-    "$ROOT/evacuation_amd/csrc/evac_api.hip" -o "$ROOT/tools/ablate_libs/libevac_stamp.so" && echo built
+    "$ROOT/evacuation_amd/csrc/evac_api.hip" -o "$ROOT/tools/ab_libs/libevac_stamp.so" && echo built
 else
-  EVAC_LIB="$ROOT/tools/ablate_libs/libevac_stamp.so" python3 - <<PY
+  EVAC_LIB="$ROOT/tools/ab_libs/libevac_stamp.so" python3 - <<PY
 import ctypes as C, sys, torch
 sys.path.insert(0, "$ROOT")
 import evacuation_amd as ea

@@ -1,5 +1,5 @@
 """Progress of the 16 waves of workgroup 0 inside ONE rollout launch (diagnostic build: hipcc ... -DEVAC_STEP_TIMES -o
-tools/ablate_libs/libevac_steptimes.so, loaded through EVAC_LIB):
+tools/ab_libs/libevac_steptimes.so, loaded through EVAC_LIB):
 s_memrealtime at the top of every step.  With the load schedule workgroup 0 carries the heaviest envs of the batch in its
 waves 0..3 (one per SIMD: the SIMDs' oldest waves), the lightest in waves 12..15.  GPU box."""
 import ctypes as C, os, sys

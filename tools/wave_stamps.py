@@ -1,5 +1,5 @@
 """Per-phase cycles of each of the 16 waves of workgroup 0 in ONE rollout launch (diagnostic build: hipcc ... -DEVAC_STAMP
--DEVAC_STAMP_WAVES -o tools/ablate_libs/libevac_wavestamps.so, loaded through EVAC_LIB).  With the load schedule workgroup 0
+-DEVAC_STAMP_WAVES -o tools/ab_libs/libevac_wavestamps.so, loaded through EVAC_LIB).  With the load schedule workgroup 0
 carries the heaviest envs of the batch in its waves 0..3: this is the heavy wave's own breakdown -- the chain that ends the
 launch -- next to the light waves'.  GPU box."""
 import ctypes as C, os, sys
