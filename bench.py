@@ -90,7 +90,7 @@ def parse_args(argv=None):
     ap.add_argument("--sweeps", type=int, default=0, help="passes over the episode (0: 11, or 1 when a block is a whole episode -- then raised until 20 blocks are timed)")
     ap.add_argument("--blocks", type=int, default=0, help="override the number of timed K-step blocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-step-api", action="store_true", help="skip the one-launch-per-step side measurement")
+    ap.add_argument("--no-step-api", action="store_true", help="skip the one-launch-per-step side measurement (and the side workloads: the headline kernel only)")
     ap.add_argument("--no-side-workloads", action="store_true",
                     help="skip the short runs of BASELINE configs 3 and 5 (one GPU's shard) and of the 524 288-env per-step run that ride "
                          "along with the default C2 line as `workloads`")
@@ -105,10 +105,13 @@ def parse_args(argv=None):
     ap.add_argument("--device-wait", action="store_true",
                     help="order a buffer's reuse behind its gather with a device-side stream wait (a barrier packet in front of the "
                          "launch) instead of the host-side check")
-    ap.add_argument("--gather", default="obs", choices=["obs", "slab", "direct", "peer"],
+    ap.add_argument("--gather", default="obs", choices=["obs", "slab", "direct", "peer", "auto"],
                     help="what the ranks all-gather per chunk and how: the observation batch (north_star) or the whole packed "
                          "record through RCCL; or the observation batch written into the peers' hipIpc-mapped buffers by one "
-                         "peer-store kernel (peer) or by copy-engine writes (direct) -- no library collective")
+                         "peer-store kernel (peer) or by copy-engine writes (direct) -- no library collective; auto: peer if the "
+                         "peer-store probe passes on every rank (decided before anything is timed), the RCCL observation gather if not")
+    ap.add_argument("--no-alt-gather", action="store_true",
+                    help="skip the two extra sweeps that time the OTHER gather form (peer-store kernel <-> RCCL) after the headline sweeps")
     ap.add_argument("--gather-schedule", default="pipelined", choices=["pipelined", "split"],
                     help="pipelined: the gather of chunk j-1 runs under the compute of chunk j (double-buffered, across blocks); "
                          "split: a one-launch block goes out as two K/2 launches, each gathered inside the block")
@@ -275,6 +278,61 @@ def summarize_blocks(wall_s, phases, per_sweep, K):
         "dense": {"episode_phase": dense_k, "ms_per_step": phase_median[dense_k] / K * 1e3},
         "mid_episode": {"episode_phase": mid_k, "ms_per_step": phase_median[mid_k] / K * 1e3},
     }
+
+
+def choose_gather(requested: str, probe: dict):
+    """(form timed, alternative form timed for two extra sweeps or None).  `auto` = the peer-store kernel when the probe passed on
+    every rank, RCCL's all-gather of the observation batch when it did not; the alternative is the other one of the two, when it
+    can run (the copy-engine and whole-slab forms have none)."""
+    peer_ok = bool(probe and probe.get("ok"))
+    form = ("peer" if peer_ok else "obs") if requested == "auto" else requested
+    alt = {"obs": "peer" if peer_ok else None, "peer": "obs"}.get(form)
+    return form, alt
+
+
+def gather_report(form, world, bytes_per_peer, alone_ms, chunks, launch_plain_ms, env=None, versions=None):
+    """What a multi-rank line says about ITS gather, per rank, from timestamps alone -- a pure function
+    (tests/test_bench_launcher_cpu.py feeds it synthetic ones).  `chunks`: one dict per chunk of the instrumented sweep with
+    the ms timestamps `l0`, `l1` (launch of the chunk on the compute stream) and, when a gather rode under it (the gather of
+    the previous chunk in the pipelined schedule), `g0`, `g1` of that gather on the comm stream; same clock.  `alone_ms`: the same
+    gather timed on an idle device before the sweeps.  bytes_per_peer: what one peer sends this rank per chunk (one xGMI link)."""
+    import statistics
+    med = lambda v: (statistics.median(v) if v else None)  # noqa: E731
+    with_g = [c for c in chunks if c.get("g0") is not None]
+    under = [c["g1"] - c["g0"] for c in with_g]
+    launch_with = [c["l1"] - c["l0"] for c in with_g]
+    started_before_end = [c["g0"] < c["l1"] for c in with_g]
+    overlap = [max(0.0, min(c["l1"], c["g1"]) - max(c["l0"], c["g0"])) for c in with_g]
+    tail = [max(0.0, c["g1"] - c["l1"]) for c in with_g]            # the part of the gather that outlasts the launch it rode under
+    gbps = lambda ms: (bytes_per_peer / (ms * 1e-3) / 1e9 if ms and ms > 0 else None)  # noqa: E731
+    return {
+        "form": form, "world": world, "chunks_instrumented": len(with_g),
+        "bytes_received_per_chunk": bytes_per_peer * max(world - 1, 0), "bytes_per_link_per_chunk": bytes_per_peer,
+        "gather_ms_alone": med(alone_ms), "gather_ms_under_compute": med(under),
+        "launch_ms_with_gather": med(launch_with), "launch_ms_plain": launch_plain_ms,
+        "launch_slowdown_under_gather": (med(launch_with) / launch_plain_ms) if (launch_with and launch_plain_ms) else None,
+        "gather_started_before_rollout_ended": (sum(started_before_end) / len(started_before_end)) if started_before_end else None,
+        "overlap_ms": med(overlap), "gather_tail_after_launch_ms": med(tail),
+        "link_GBps_alone": gbps(med(alone_ms)), "link_GBps_under_compute": gbps(med(under)),
+        "versions": versions, "env": env,
+        "checks_design_estimates": {"link_GBps_under_compute": "DESIGN 6: 48-60 GB/s per link assumed",
+                                    "gather_started_before_rollout_ended": "DESIGN 6: the gather kernel is co-resident with the rollout's workgroups (1.0 = always)",
+                                    "launch_slowdown_under_gather": "DESIGN 6: <= 1.10",
+                                    "gather_ms_under_compute": "DESIGN 6: 33-41 us wire time + ~10 us latency at 8 GPUs, 20-step chunks"},
+    }
+
+
+def comm_environment():
+    """Versions and the environment variables that shape the collective, for the multi-rank line."""
+    import torch
+    vers = {"torch": torch.__version__, "hip": getattr(torch.version, "hip", None)}
+    try:
+        vers["rccl"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception as exc:  # noqa: BLE001
+        vers["rccl"] = f"unknown ({type(exc).__name__})"
+    keys = ("NCCL_", "RCCL_", "HSA_", "HIP_", "ROCR_", "GPU_MAX_HW_QUEUES", "TORCH_NCCL_", "CUDA_VISIBLE", "ROCM_")
+    env = {k: v for k, v in sorted(os.environ.items()) if k.startswith(keys)}
+    return vers, env
 
 
 def chunk_sizes(K: int, inner: int, schedule: str, gather: bool):
@@ -511,7 +569,8 @@ def main(argv=None):
             raise SystemExit(f"bench.py: {dist.get_world_size()} ranks joined, --gpus {args.gpus} requested")
 
     import evacuation_amd as ea
-    from evacuation_amd.distributed import DirectGather, PeerStoreGather, ShardedEvacuationEnv, all_gather_envs, pack_outputs, side_stream
+    from evacuation_amd.distributed import (DirectGather, PeerStoreGather, ShardedEvacuationEnv, all_gather_envs, pack_outputs,
+                                             peer_store_probe, side_stream)
 
     cfg = ea.EnvConfig(number_of_pedestrians=n_ped, is_new_exiting_reward=True, is_new_followers_reward=True,
                        intrinsic_reward_coef=0.0, max_timesteps=EPISODE)       # SURVEY.md 8(d) synthetic inputs
@@ -526,13 +585,22 @@ def main(argv=None):
     sizes = chunk_sizes(K, inner, args.gather_schedule, gather_rollout)
     inner = sizes[0]                                           # the launch shape the roofline block describes
     lag = 0 if (args.gather_schedule == "split") else 1
+    # Which gather is timed is decided HERE, before anything is timed, by all ranks together: the peer-store probe (hipIpc
+    # mappings of every rank's buffer, peer access, a checked store pattern; never raises, every stage agreed over the host) runs
+    # whatever form was asked for -- its result is part of the line --; `--gather auto` takes the peer-store kernel when it passed
+    # on every rank and RCCL otherwise.  Nothing is restarted or re-executed: a rank that cannot map a peer simply says so.
+    probe = peer_store_probe(device) if gather_rollout else None
+    form, alt_form = choose_gather(args.gather, probe)
+    if args.no_alt_gather or not gather_rollout or lag == 0:
+        alt_form = None
+    forms = [form] + ([alt_form] if alt_form else [])
 
     # Preallocated, reused output chunks (the trainer's rollout buffer, rpo_agent.py:158-163): the kernel writes one packed
     # slab [T, E, D+3] = [obs | reward | terminated | truncated] per launch shape and buffer of the ring.
     compute = torch.cuda.current_stream(device)               # every launch of this benchmark goes to this stream
     comm = side_stream(device, beside=compute) if do_gather else None      # (a stream on ANOTHER hardware queue than `compute`)
     nbuf = args.buffers if args.buffers > 0 else (4 if (gather_rollout and lag == 1) else 2)
-    GW = D + 3 if args.gather == "slab" else D                # gathered words per env-step (obs, direct: the observation columns)
+    GW = D + 3 if form == "slab" else D                       # gathered words per env-step (obs, direct, peer: the observation columns)
     chunks = {}
 
     def chunk_bufs(t, parity):
@@ -545,21 +613,30 @@ def main(argv=None):
             if gather_rollout:
                 b["ready"], b["fin"] = torch.cuda.Event(), torch.cuda.Event()   # (reused: creating two events per gather cost 5 us of host time)
                 b["gathered"] = torch.empty((world, t, E, GW), dtype=torch.float32, device=device)
-                if args.gather in ("obs", "direct"):
+                if "obs" in forms or "direct" in forms:
                     b["gsrc"] = torch.empty((t, E, GW), dtype=torch.float32, device=device)
-                if args.gather == "direct":
+                if "direct" in forms:
                     b["direct"] = DirectGather(b["gsrc"], b["gathered"])     # peers' `gathered` buffers mapped through hipIpc
-                if args.gather == "peer":
+                if "peer" in forms:
                     b["peer"] = PeerStoreGather(b["slab"], D, b["gathered"])  # ... and written by one kernel, columns picked on the way
             chunks[key] = b
         return b
 
     step_actions = torch.rand((E, 2), device=device) * 2 - 1
 
+    run = {"form": form, "diag": None}      # the gather form in use; diag: {chunk: {...events}} while the instrumented sweep runs
+
     def launch(j, t):
         if args.mode == "rollout":
             b = chunk_bufs(t, j % nbuf)
-            b["launch"]()
+            if run["diag"] is not None:       # (instrumented sweep only: a timing event pair around the launch)
+                ev = run["diag"].setdefault(j, {})
+                ev["l0"], ev["l1"] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev["l0"].record(compute)
+                b["launch"]()
+                ev["l1"].record(compute)
+            else:
+                b["launch"]()
             if gather_rollout:
                 # the chunk's outputs are complete HERE on the compute stream.  (Rounds 2-3 recorded this event inside gather(),
                 # i.e. after the NEXT launch had been enqueued: the gather of chunk j-1 then waited for launch j to finish and
@@ -571,7 +648,7 @@ def main(argv=None):
     def gather(j, t):
         """Issue the gather of chunk j's outputs on the comm stream; returns the event that marks its end."""
         if args.mode == "step":
-            msg = loc.obs if args.gather == "obs" else pack_outputs(loc.obs, loc.reward, loc.terminated, loc.truncated)
+            msg = loc.obs if args.gather in ("obs", "auto") else pack_outputs(loc.obs, loc.reward, loc.terminated, loc.truncated)
             all_gather_envs(msg)                              # (per-step API: one small collective per step, on the compute stream)
             return None
         # (the comm stream is torch's CURRENT stream for the whole pipeline -- see run_pipeline_on_comm below --, so that no
@@ -580,18 +657,29 @@ def main(argv=None):
         b = chunk_bufs(t, j % nbuf)
         fin = b["fin"]
         comm.wait_event(b["ready"])                           # recorded right behind chunk j's launch (launch())
-        if args.gather == "slab":
+        ev = None
+        if run["diag"] is not None:                           # (instrumented sweep only: a timing event pair around the gather)
+            ev = run["diag"].setdefault(j, {})
+            ev["g0"], ev["g1"] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev["g0"].record(comm)
+        issue_gather(b, run["form"])
+        if ev is not None:
+            ev["g1"].record(comm)
+        fin.record(comm)
+        return fin
+
+    def issue_gather(b, f):
+        """The gather of one chunk's outputs in form `f`, enqueued on the comm stream (torch's current stream here)."""
+        if f == "slab":
             all_gather_envs(b["slab"], out=b["gathered"])
-        elif args.gather == "peer":
+        elif f == "peer":
             b["peer"].issue(comm)                             # one launch: the observation columns to every peer
         else:                                                 # the observation columns, copied out on the comm stream
             b["gsrc"].copy_(b["slab"][..., :D])
-            if args.gather == "direct":
+            if f == "direct":
                 b["direct"].issue(comm)                       # world copy-engine writes into the peers' buffers
             else:
                 all_gather_envs(b["gsrc"], out=b["gathered"])
-        fin.record(comm)
-        return fin
 
     def wait_gather(fin):
         """Before a chunk reuses a buffer: the gather that read it is done.  Checked on the HOST (a query; a host-side wait only
@@ -634,14 +722,15 @@ def main(argv=None):
                     chunk_bufs(t_, par_)
         if gather_rollout:
             b0 = chunk_bufs(sizes[0], 0)
-            if args.gather == "direct":
-                b0["direct"].issue(torch.cuda.current_stream())
-                b0["direct"].self_test()
-            elif args.gather == "peer":
-                b0["peer"].self_test()
-            else:
-                all_gather_envs(b0["slab"] if args.gather == "slab" else b0["gsrc"], out=b0["gathered"])
-            torch.cuda.synchronize()
+            for f_ in forms:
+                if f_ == "direct":
+                    b0["direct"].issue(torch.cuda.current_stream())
+                    b0["direct"].self_test()
+                elif f_ == "peer":
+                    b0["peer"].self_test()
+                else:
+                    all_gather_envs(b0["slab"] if f_ == "slab" else b0["gsrc"], out=b0["gathered"])
+                torch.cuda.synchronize()
     except Exception as exc:  # noqa: BLE001
         if not gather_rollout:
             raise
@@ -650,7 +739,9 @@ def main(argv=None):
 
     # With gathers the COMM stream is torch's current stream from here to the end of the timed parts (the launches are bound to
     # `compute`): the collectives and the column copies then need no stream switch per chunk.
-    if do_gather:
+    # (only the ROLLOUT pipeline: in --mode step the step launches and the per-step collective go to the current stream, which
+    # must stay `compute` -- the sweep's events are recorded there)
+    if gather_rollout:
         torch.cuda.set_stream(comm)
     # W untimed warm-up steps through the same pipeline (so that, pipelined, the first timed launch has a gather to carry)
     w_done = 0
@@ -659,6 +750,20 @@ def main(argv=None):
         pipe.run_block([t])
         w_done += t
     pipe.drain()
+    barrier()
+    # one chunk's gather ALONE on an idle device, in every form that will be timed (untimed region; the data is whatever the
+    # warm-up left): what the same gather takes under a rollout launch is measured in the instrumented sweep below
+    alone_ms = {f_: [] for f_ in forms} if gather_rollout else {}
+    for f_ in alone_ms:
+        b0 = chunk_bufs(sizes[0], 0)
+        for _ in range(5):
+            barrier()
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record(comm)
+            issue_gather(b0, f_)
+            a1.record(comm)
+            comm.synchronize()
+            alone_ms[f_].append(a0.elapsed_time(a1))
     barrier()
     state0 = [t.clone() for t in (loc.ped, loc.status, loc.agent, loc.clock, loc.acc)]   # for the per-launch replay below
     ws0 = loc.workspace.clone() if loc.workspace is not None else None
@@ -689,12 +794,57 @@ def main(argv=None):
     steps_per_sweep = per_sweep * K
     sweep_s = statistics.median(sweep_wall)
     kernel_s = statistics.median(sweep_dev) / launches_per_sweep      # mean launch of a sweep (kernel + the ~1.5 us launch boundary)
+    sweeps_run = sweeps
+
+    # ---- the gather explains itself (N > 1, or --force-gather): one INSTRUMENTED sweep per form -- a timing event pair around
+    # every launch (compute stream) and around every gather (comm stream) --, and two plain sweeps of the alternative form.
+    # Untimed as far as the headline goes; all ranks run the same sweeps (the forms were agreed before the warm-up).
+    def extra_sweep(instrumented):
+        barrier()
+        ref = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        run["diag"] = {} if instrumented else None
+        t0 = time.perf_counter()
+        ref.record(compute)
+        for b in range(per_sweep):
+            pipe.run_block(sizes)
+        e1.record(compute)
+        pipe.drain()
+        wall_ = time.perf_counter() - t0
+        pipe.flush()
+        barrier()
+        diag_, run["diag"] = run["diag"], None
+        chunks_ = []
+        if diag_:
+            for j in sorted(diag_):
+                c = {"l0": ref.elapsed_time(diag_[j]["l0"]), "l1": ref.elapsed_time(diag_[j]["l1"])}
+                g = diag_.get(j - lag)                        # the gather that rode under launch j: chunk j - 1's (pipelined)
+                if g is not None and "g0" in g and lag == 1:
+                    c["g0"], c["g1"] = ref.elapsed_time(g["g0"]), ref.elapsed_time(g["g1"])
+                chunks_.append(c)
+        return wall_, ref.elapsed_time(e1) * 1e-3, chunks_
+
+    gather_runs = {}
+    if gather_rollout:
+        for f_ in forms:
+            run["form"] = f_
+            rec = {"sweep_wall_s": [], "sweep_dev_s": []}
+            if f_ != form:
+                for _ in range(2):
+                    w_, d_, _c = extra_sweep(False)
+                    rec["sweep_wall_s"].append(w_)
+                    rec["sweep_dev_s"].append(d_)
+                    sweeps_run += 1
+            w_, d_, rec["chunks"] = extra_sweep(True)
+            sweeps_run += 1
+            gather_runs[f_] = rec
+        run["form"] = form
 
     # ---- diagnostic 1: one sweep of blocks, each bracketed by a device-idle sync of its own (the headline of rounds 1-3) ----
     wall, phases, t_call = [], [], []
     one_launch = chunk_bufs(K, 0)["launch"] if (args.mode == "rollout" and sizes == [K] and not do_gather) else None
     for b in range(per_sweep):
-        phases.append((phase0 + (sweeps * per_sweep + b) * K) % EPISODE)     # RandomAgent episodes end by truncation at 2000
+        phases.append((phase0 + (sweeps_run * per_sweep + b) * K) % EPISODE)     # RandomAgent episodes end by truncation at 2000
         barrier()
         t0 = time.perf_counter()
         if one_launch is not None:
@@ -720,7 +870,7 @@ def main(argv=None):
         with open(os.environ["EVAC_BENCH_DUMP"], "w") as f:
             json.dump({"sweep_wall_s": sweep_wall, "sweep_dev_s": sweep_dev, "wall_s": wall, "phase": phases, "launch_call_s": t_call}, f)
 
-    if do_gather:
+    if gather_rollout:
         torch.cuda.set_stream(compute)
     # ---- diagnostic 2: an event pair around every launch of one sweep (state restored, no gathers): the dense launch ----
     def restore():
@@ -751,13 +901,48 @@ def main(argv=None):
     dense_b = min(range(per_sweep), key=lambda k: (phase0 + k * K) % EPISODE)
     full = [a.elapsed_time(z) * 1e-3 for b, t, a, z in per_launch if t == inner]
     dense_l = [a.elapsed_time(z) * 1e-3 for b, t, a, z in per_launch if t == inner and b == dense_b]
+    sweep_launch_s = kernel_s                                 # mean launch of the median timed sweep (with gathers: incl. their contention and the host's buffer waits)
     if not uniform:
         kernel_s = sum(full) / max(1, len(full))
     # (an event pair around ONE short launch also times the few us between the markers and the kernel: corrected by the mean
     # difference between the pairs and the back-to-back sweep)
-    event_overhead_s = max(0.0, sum(full) / max(1, len(full)) - kernel_s) if uniform else 0.0
-    kernel_dense_s = (sorted(dense_l)[len(dense_l) // 2] - event_overhead_s) if dense_l else kernel_s
+    event_overhead_s = max(0.0, sum(full) / max(1, len(full)) - kernel_s) if (uniform and not gather_rollout) else 0.0
+    if gather_rollout and uniform:
+        #  with gathers in the timed sweeps the span between their two events is not a kernel figure (gather kernels
+        # competing for CUs, host-side waits before a buffer is reused): the roofline block describes the KERNEL, taken from
+        # the replayed sweep without gathers; the sweep's own mean launch is reported beside it as launch_ms_with_gather
+        kernel_s = sum(full) / max(1, len(full))
+    kernel_s = max(kernel_s, 1e-9)                            # (never divide by a zero span)
+    kernel_dense_s = max((sorted(dense_l)[len(dense_l) // 2] - event_overhead_s) if dense_l else kernel_s, 1e-9)
     back_to_back = launches_per_sweep * sweeps
+    # ---- per-rank account of the gather(s), gathered on rank 0 ----
+    gather_info = None
+    if gather_rollout:
+        vers, envv = comm_environment()
+        mine = {"rank": rank, "device": dev_index}
+        for f_, rec in gather_runs.items():
+            rep = gather_report(f_, world, inner * E * (D + 3 if f_ == "slab" else D) * 4, alone_ms.get(f_, []), rec["chunks"], kernel_s * 1e3,
+                                env=envv if f_ == form else None, versions=vers if f_ == form else None)
+            if rec["sweep_wall_s"]:
+                rep["sweep_wall_ms"] = [x * 1e3 for x in rec["sweep_wall_s"]]
+                rep["value_this_rank"] = total_envs * steps_per_sweep / statistics.median(rec["sweep_wall_s"])
+            mine[f_] = rep
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        gather_info = {"timed_form": form, "requested": args.gather, "alternative_form": alt_form, "peer_store_probe": probe,
+                       "schedule": args.gather_schedule, "per_rank": everyone,
+                       "note": "per rank, from one instrumented sweep per form (timing event pairs around every launch and every gather; "
+                               "not the headline sweeps): gather_ms_alone = one chunk's gather on an idle device; "
+                               "gather_ms_under_compute / launch_ms_with_gather = the same gather under the next chunk's launch and "
+                               "that launch; launch_ms_plain = the mean launch of the replayed sweep without gathers; "
+                               "gather_started_before_rollout_ended = share of chunks whose gather began before the launch it rode "
+                               "under had ended (co-residency of the gather kernel with the rollout's workgroups); link_GBps = bytes "
+                               "one peer sends this rank per chunk / gather time; the alternative form: two plain sweeps + one "
+                               "instrumented (value_this_rank from the plain ones)"}
+        if alt_form and alt_form in gather_runs and gather_runs[alt_form]["sweep_wall_s"]:
+            tt = torch.tensor(gather_runs[alt_form]["sweep_wall_s"], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            gather_info["alternative_value"] = total_envs * steps_per_sweep / statistics.median([float(x) for x in tt.tolist()])
     if loc.team_error():                                      # a team barrier timed out somewhere above: the numbers are void
         raise SystemExit("bench.py: evac_team_error is set (a team rollout lost a member); results discarded")
     bytes_per_env_step = loc.algorithmic_bytes_per_env_step
@@ -827,6 +1012,13 @@ def main(argv=None):
         except Exception as exc:  # noqa: BLE001
             step_api["host_vector_env_error"] = f"{type(exc).__name__}: {exc}"[:160]
 
+    # BASELINE configs 3 and 5 (one GPU's shard) and the 524 288-env per-step run, a few episode sweeps each: in the driver's line
+    # (VERDICT r04 item 2).  Only beside the default single-GPU C2 rollout line; every entry is a measurement of its own batch.
+    side = None
+    if (rank == 0 and world == 1 and args.workload == "c2" and args.mode == "rollout" and not args.envs and not args.no_side_workloads
+            and not args.no_step_api and not do_gather):        # (--no-step-api = "the headline kernel only": profiling and A/B runs)
+        side = side_workloads(args, device)
+
     if rank == 0:
         tr = load_traffic(args.traffic_json, f"{args.workload}:{args.mode}", loc.kernel_variant(args.mode), csrc_sha16())
         traffic = tr["hbm_bytes_per_env_step"] * E * inner if tr["hbm_bytes_per_env_step"] is not None else None   # per env-step, scaled to one launch
@@ -841,7 +1033,7 @@ def main(argv=None):
             coll = "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + ", host-staged: testing aid"
             what = {"obs": f"observation batch ({coll})", "slab": f"[obs|reward|flags] records ({coll})",
                     "direct": "observation batch (copy-engine peer writes over hipIpc, no CU-resident collective kernel)",
-                    "peer": "observation batch (one peer-store kernel, evac_peer_gather, into hipIpc-mapped buffers; no library collective)"}[args.gather]
+                    "peer": "observation batch (one peer-store kernel, evac_peer_gather, into hipIpc-mapped buffers; no library collective)"}[form]
             how = ("issued after the NEXT chunk's launch, inside the timed block (double-buffered; block b carries block b-1's gather)"
                    if lag == 1 else "each chunk gathered as soon as it is computed, inside its block")
             gather_desc = f", all-gather of the {what} per {inner}-step chunk on a side stream, {how}"
@@ -861,7 +1053,15 @@ def main(argv=None):
                                  "-> t1, max over ranks; ms_per_step = median sweep / 2000 = the episode-average step; `blocks`: the "
                                  "per-block view (a device-idle sync around every K-step launch) as a diagnostic",
                        "sweeps": {"timed": sweeps, "launches_per_sweep": launches_per_sweep, "steps_per_sweep": steps_per_sweep,
-                                  "wall_ms": [x * 1e3 for x in sweep_wall], "hip_event_ms": [x * 1e3 for x in sweep_dev]},
+                                  "wall_ms": [x * 1e3 for x in sweep_wall], "hip_event_ms": [x * 1e3 for x in sweep_dev],
+                                  "gpu_ms_timed_total": sum(sweep_dev) * 1e3,
+                                  "value_min_median_max": [total_envs * steps_per_sweep / max(sweep_wall), value,
+                                                           total_envs * steps_per_sweep / min(sweep_wall)]},
+                       "timing_method": "r05: median of whole-episode sweeps (11 by default for K-step blocks), back-to-back launches; "
+                                        "roofline.kernel_ms_per_launch = median sweep (HIP events) / launches -- with gathers in the "
+                                        "sweeps: the mean launch of a replayed sweep WITHOUT gathers (the sweep's own figure is "
+                                        "roofline.launch_ms_with_gather)",
+                       "gather": (form if gather_rollout else None), "gather_requested": (args.gather if do_gather else None),
                        "gather_schedule": (args.gather_schedule if gather_rollout else None),
                        "gather_buffers": (nbuf if gather_rollout else None),
                        "ranks_joined": dist.get_world_size() if use_dist else 1,
@@ -874,7 +1074,8 @@ def main(argv=None):
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": tr["note"],
                          "salu_wave_insts_per_env_step": tr["salu"], "lds_wave_insts_per_env_step": tr["lds"],
                          "kernel": loc.kernel_variant(args.mode),
-                         "kernel_ms_per_launch": kernel_s * 1e3, "kernel_launches_timed": back_to_back if uniform else len(full),
+                         "kernel_ms_per_launch": kernel_s * 1e3, "kernel_launches_timed": back_to_back if (uniform and not gather_rollout) else len(full),
+                         "launch_ms_with_gather": (sweep_launch_s * 1e3 if gather_rollout else None),
                          "kernel_ms_per_launch_event_pairs": sum(full) / max(1, len(full)) * 1e3,
                          "kernel_ms_per_launch_dense": kernel_dense_s * 1e3,
                          "frac_dense": bytes_per_launch / kernel_dense_s / 1e9 / HBM_PEAK_GBPS,
@@ -899,6 +1100,10 @@ def main(argv=None):
             "step_api": step_api,
         }
         out["cpu_baseline"] = cpu_base
+        if side is not None:
+            out["workloads"] = side
+        if gather_info is not None:
+            out["gather_report"] = gather_info
         print(json.dumps(out), flush=True)
     env.close()
     if use_dist:

@@ -175,16 +175,109 @@ class DirectGather:
             raise RuntimeError(f"DirectGather self-test failed on rank {self.rank}: got {got.tolist()}, expected {want.tolist()}")
 
 
+def _exchange_handles(gathered: torch.Tensor, group=None):
+    """hipIpc handles of every rank's `gathered` buffer (PyTorch's CUDA-IPC tensor sharing), by rank."""
+    from torch.multiprocessing.reductions import reduce_tensor
+    handles = [None] * dist.get_world_size(group)
+    dist.all_gather_object(handles, reduce_tensor(gathered), group=group)
+    return handles
+
+
+def _open_handles(handles, gathered: torch.Tensor, group=None):
+    """The peers' buffers mapped into this process (this rank's own entry is `gathered` itself).  May raise (hipIpcOpenMemHandle)."""
+    rank = dist.get_rank(group)
+    return [gathered if r == rank else rebuild(*rebuild_args) for r, (rebuild, rebuild_args) in enumerate(handles)]
+
+
 def _map_peer_buffers(gathered: torch.Tensor, group=None):
     """Every rank's `gathered` buffer mapped into this process (hipIpc through PyTorch's CUDA-IPC tensor sharing); returns the
     list of tensors by rank (this rank's own entry is `gathered` itself) and what must be kept alive with them."""
-    from torch.multiprocessing.reductions import reduce_tensor
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    handles = [None] * world
-    dist.all_gather_object(handles, reduce_tensor(gathered), group=group)
-    peers = [gathered if r == rank else rebuild(*rebuild_args) for r, (rebuild, rebuild_args) in enumerate(handles)]
+    handles = _exchange_handles(gathered, group)
+    peers = _open_handles(handles, gathered, group)
     dist.barrier(group)                  # every rank has mapped every buffer before anybody writes
     return peers, handles
+
+
+def _enable_peer_access(mine: int, others) -> None:
+    """Stores issued by a kernel of device `mine` into buffers of the devices `others`: hipDeviceEnablePeerAccess must succeed
+    (or report that access is enabled already) for every one of them -- a store to a peer without access faults the GPU, so
+    anything else is an error here, not something for a self-test to find."""
+    import ctypes as C
+    others = sorted(set(others) - {mine})
+    if not others:
+        return
+    hip = C.CDLL("libamdhip64.so")               # (OSError propagates: PyTorch-ROCm has loaded this library already)
+    hip.hipDeviceEnablePeerAccess.restype = C.c_int
+    hip.hipGetErrorString.restype = C.c_char_p
+    HIP_SUCCESS, HIP_ERROR_PEER_ACCESS_ALREADY_ENABLED = 0, 704
+    with torch.cuda.device(mine):
+        for d in others:
+            rc = hip.hipDeviceEnablePeerAccess(C.c_int(d), C.c_uint(0))
+            if rc == HIP_ERROR_PEER_ACCESS_ALREADY_ENABLED:
+                hip.hipGetLastError()            # (clear the sticky error)
+            elif rc != HIP_SUCCESS:
+                msg = hip.hipGetErrorString(C.c_int(rc))
+                raise RuntimeError(f"hipDeviceEnablePeerAccess(device {d}) from device {mine} failed with "
+                                   f"{rc} ({msg.decode() if msg else '?'}): no peer stores to that rank")
+
+
+def peer_store_probe(device, group=None, rows: int = 256, row_words: int = 9, take: int = 6) -> dict:
+    """Can this group gather by peer stores (PeerStoreGather)?  Run by ALL ranks together, before anything is timed; never
+    raises and never leaves a rank behind in a collective: the three stages -- (1) every rank's buffer mapped into every other
+    rank through hipIpc, (2) peer access enabled towards the devices that own them, (3) a rank- and position-coded pattern stored
+    by evac_peer_gather and checked slice by slice -- each end with an agreement over the host (``all_gather_object``), and the
+    first stage that fails ANYWHERE ends the probe everywhere.  Returns ``{"ok", "stage", "error", "world", "devices",
+    "store_ms"}``: what ``bench.py --gather auto`` decides by, and what every multi-rank bench line reports whatever gather it
+    times.  (A store to an unmapped address would fault the GPU rather than raise; stage 2 is strict for that reason.)"""
+    import time
+    device = torch.device(device)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    info = {"ok": False, "stage": "map", "error": None, "world": world, "devices": None, "store_ms": None}
+
+    def agree(err):
+        errs = [None] * world
+        dist.all_gather_object(errs, None if err is None else f"rank {rank}: {err}"[:240], group=group)
+        bad = [e for e in errs if e is not None]
+        if bad:
+            info["error"] = bad[0]
+        return not bad
+
+    err, peers, handles, g = None, None, None, None
+    try:
+        slab = torch.zeros((rows, row_words), dtype=torch.float32, device=device)
+        gathered = torch.zeros((world, rows, take), dtype=torch.float32, device=device)
+        handles = _exchange_handles(gathered, group)
+        try:
+            peers = _open_handles(handles, gathered, group)
+        except Exception as exc:  # noqa: BLE001
+            err = f"{type(exc).__name__}: {exc}"
+        if not agree(err):
+            return info
+        devs = [None] * world
+        dist.all_gather_object(devs, int(device.index if device.index is not None else torch.cuda.current_device()), group=group)
+        info["devices"] = devs
+        info["stage"] = "peer_access"
+        try:
+            _enable_peer_access(slab.device.index, {p.device.index for p in peers})
+        except Exception as exc:  # noqa: BLE001
+            err = f"{type(exc).__name__}: {exc}"
+        if not agree(err):
+            return info
+        info["stage"] = "store"
+        try:
+            g = PeerStoreGather(slab, take, gathered, group=group, _mapped=(peers, handles))
+            t0 = time.perf_counter()
+            g.self_test()
+            info["store_ms"] = (time.perf_counter() - t0) * 1e3
+        except Exception as exc:  # noqa: BLE001  (self_test's own barriers are passed by every rank before it compares)
+            err = f"{type(exc).__name__}: {exc}"
+        if not agree(err):
+            return info
+        info["ok"], info["stage"] = True, "done"
+        return info
+    except Exception as exc:  # noqa: BLE001  (the exchange itself: all ranks see the same failure or the process group is gone)
+        info["error"] = f"rank {rank}: {type(exc).__name__}: {exc}"[:240]
+        return info
 
 
 class PeerStoreGather:
@@ -198,7 +291,7 @@ class PeerStoreGather:
     afterwards marks the end of this rank's OUTGOING stores; a consumer of ``gathered`` needs all ranks to have passed theirs.
     ``bench.py --gather peer``."""
 
-    def __init__(self, slab: torch.Tensor, take_words: int, gathered: torch.Tensor, group=None, wgs_per_peer: int = 8):
+    def __init__(self, slab: torch.Tensor, take_words: int, gathered: torch.Tensor, group=None, wgs_per_peer: int = 8, _mapped=None):
         import ctypes as C
         from . import _lib
         self.group = group
@@ -208,35 +301,12 @@ class PeerStoreGather:
         self.rows = slab.numel() // self.row_words
         assert tuple(gathered.shape) == (self.world,) + tuple(slab.shape[:-1]) + (self.take,), (gathered.shape, slab.shape, take_words)
         self.slab, self.gathered, self.wgs = slab, gathered, int(wgs_per_peer)
-        self.peers, self._keep = _map_peer_buffers(gathered, group)
-        self._enable_peer_access()
+        self.peers, self._keep = _mapped if _mapped is not None else _map_peer_buffers(gathered, group)   # (_mapped: peer_store_probe)
+        _enable_peer_access(self.slab.device.index, {p.device.index for p in self.peers})
         self._lib = _lib.load()
         self._ptrs = (C.c_void_p * self.world)(*[p.data_ptr() for p in self.peers])
         self._src = C.c_void_p(slab.data_ptr())
         self._C = C
-
-    def _enable_peer_access(self) -> None:
-        """The stores come from THIS device's kernel: it needs access to the devices that own the mapped buffers.
-        hipDeviceEnablePeerAccess must succeed (or report that access is enabled already) for every such device -- a store to a
-        peer without access faults the GPU, so anything else is an error here, not something for self_test to find."""
-        import ctypes as C
-        mine = self.slab.device.index
-        others = sorted({p.device.index for p in self.peers} - {mine})
-        if not others:
-            return
-        hip = C.CDLL("libamdhip64.so")               # (OSError propagates: PyTorch-ROCm has loaded this library already)
-        hip.hipDeviceEnablePeerAccess.restype = C.c_int
-        hip.hipGetErrorString.restype = C.c_char_p
-        HIP_SUCCESS, HIP_ERROR_PEER_ACCESS_ALREADY_ENABLED = 0, 704
-        with torch.cuda.device(mine):
-            for d in others:
-                rc = hip.hipDeviceEnablePeerAccess(C.c_int(d), C.c_uint(0))
-                if rc == HIP_ERROR_PEER_ACCESS_ALREADY_ENABLED:
-                    hip.hipGetLastError()            # (clear the sticky error)
-                elif rc != HIP_SUCCESS:
-                    msg = hip.hipGetErrorString(C.c_int(rc))
-                    raise RuntimeError(f"PeerStoreGather: hipDeviceEnablePeerAccess(device {d}) from device {mine} failed with "
-                                       f"{rc} ({msg.decode() if msg else '?'}): no peer stores to that rank")
 
     def issue(self, stream=None) -> None:
         # (evac_peer_gather takes no handle and launches on the CURRENT device: make it the slab's, whatever the caller has current)
@@ -248,23 +318,32 @@ class PeerStoreGather:
             raise RuntimeError(f"evac_peer_gather failed with status {rc}")
 
     def self_test(self) -> None:
-        """Every rank fills its slab with a rank- and position-coded pattern, gathers, and checks every slice it received."""
+        """Every rank fills its slab with a rank- and position-coded pattern, gathers, and checks every slice it received.
+        Every rank passes every barrier whatever happens to it locally (a failed launch is remembered and raised at the end), so
+        a failure on one rank cannot leave the others waiting."""
         keep = self.slab.clone()
         flat = self.slab.view(-1, self.row_words)
         base = torch.arange(flat.numel(), dtype=torch.float32, device=self.slab.device).view_as(flat) % 4093.0
         flat.copy_(base + 5000.0 * (self.rank + 1))
-        dist.barrier(self.group)
-        self.issue()
         torch.cuda.synchronize(self.slab.device)
         dist.barrier(self.group)
+        err = None
+        try:
+            self.issue()
+            torch.cuda.synchronize(self.slab.device)
+        except Exception as exc:  # noqa: BLE001
+            err = exc
+        dist.barrier(self.group)
         got = self.gathered.view(self.world, -1, self.take)
-        ok = True
+        ok = err is None
         for r in range(self.world):
             want = base[:, : self.take] + 5000.0 * (r + 1)
             ok = ok and bool(torch.equal(got[r], want))
         self.slab.copy_(keep)
         torch.cuda.synchronize(self.slab.device)
         dist.barrier(self.group)
+        if err is not None:
+            raise RuntimeError(f"PeerStoreGather self-test: the store kernel failed on rank {self.rank}: {err}") from err
         if not ok:
             raise RuntimeError(f"PeerStoreGather self-test failed on rank {self.rank}")
 

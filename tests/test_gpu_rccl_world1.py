@@ -26,7 +26,7 @@ def test_sharded_env_gathers_through_a_one_rank_rccl_communicator():
     assert p.returncode == 0 and "RCCL_WORLD1_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
-@pytest.mark.parametrize("extra", [[], ["--gather", "slab"], ["--gather", "peer"], ["--gather-schedule", "split"], ["--device-wait", "--buffers", "2"]])
+@pytest.mark.parametrize("extra", [[], ["--gather", "slab"], ["--gather", "peer"], ["--gather", "auto"], ["--gather-schedule", "split"], ["--device-wait", "--buffers", "2"]])
 def test_bench_force_gather_runs_the_pipeline_with_rccl(extra):
     """bench.py --force-gather: world size 1, backend nccl, the SAME ChunkPipeline as an N-GPU run -- the gather of chunk j - 1
     on the comm stream under chunk j, buffer-reuse waits, the drain of both streams -- and a bench line that says so."""
@@ -38,6 +38,24 @@ def test_bench_force_gather_runs_the_pipeline_with_rccl(extra):
     assert line["n_gpus"] == 1 and line["config"]["collective_backend"] == "nccl" and line["config"]["ranks_joined"] == 1
     assert "all-gather" in line["config"]["parallelism"] and line["value"] > 1e8
     assert line["config"]["gather_schedule"] == ("split" if "split" in extra else "pipelined")
+    # the line explains its gather: the probe, the form timed, and per rank what the gather cost
+    rep = line["gather_report"]
+    assert rep["peer_store_probe"]["ok"] is True and rep["peer_store_probe"]["stage"] == "done", rep["peer_store_probe"]
+    want = {"slab": "slab", "peer": "peer", "auto": "peer"}.get(extra[1] if extra[:1] == ["--gather"] else "", "obs")
+    assert rep["timed_form"] == want == line["config"]["gather"] and len(rep["per_rank"]) == 1
+    mine = rep["per_rank"][0][want]
+    for k in ("gather_ms_alone", "launch_ms_plain", "bytes_per_link_per_chunk", "versions", "env"):
+        assert mine[k] is not None, k
+    assert mine["versions"]["rccl"] and mine["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    if "split" not in extra:                                 # pipelined: chunk j - 1's gather rides under launch j
+        for k in ("gather_ms_under_compute", "launch_ms_with_gather", "gather_started_before_rollout_ended", "link_GBps_under_compute"):
+            assert mine[k] is not None and mine[k] >= 0, k
+        assert mine["chunks_instrumented"] >= 90
+        if want in ("obs", "peer"):                          # ... and the OTHER form ran two plain sweeps + an instrumented one
+            other = "peer" if want == "obs" else "obs"
+            assert rep["alternative_form"] == other and rep["alternative_value"] > 1e8
+            assert rep["per_rank"][0][other]["gather_ms_under_compute"] is not None
+    assert line["roofline"]["launch_ms_with_gather"] > 0 and line["roofline"]["kernel_ms_per_launch"] > 0
 
 
 def test_side_stream_really_runs_beside_the_compute_stream():
