@@ -75,7 +75,7 @@ struct evac_handle {
                         // in moving[g & 1] and deals perm[(g + 1) & 1] from moving[(g - 1) & 1] (rollout_body)
     bool team_bound;    // the workspace holds the teams' exchange areas
     int team_fit;       // -1: not checked yet; 1 / 0: the team grid fits the device at once (occupancy x CUs >= workgroups) or not
-    size_t team_xchg_bytes;   // the teams' exchange area (records + tile slots), reset to the sentinel before every team launch
+    size_t team_xchg_bytes;   // the teams' exchange area (records + tile slots), filled with 0xff (the tag of no round) before every team launch
     bool team_coop;     // EVAC_TEAM_COOP=1 (and the device supports it): team kernels are launched with hipLaunchCooperativeKernel
     int cus;            // compute units of the device
     bool team_fault;    // EVAC_TEAM_FAULT=1 (tests): launch the team grid one workgroup short
@@ -450,8 +450,8 @@ WorkspaceLayout workspace_layout(const evac_handle* h) {
     w.sched = o; o = up(o + 4 * E * sizeof(int32_t));          // moving[2][E] | perm[2][E]
     w.stats = o; o = up(o + 64);
     if (h->team_k) {
-        w.team_rec = o; o = up(o + 3 * E * 32 * 16);          // (three slot sets: evac_team.h, exchange)
-        w.team_tile = o; o = up(o + 3 * E * 1024 * 16);
+        w.team_rec = o; o = up(o + evac::kTeamSets * E * 32 * 16);          // (two slot sets: evac_team.h, exchange)
+        w.team_tile = o; o = up(o + evac::kTeamSets * E * 1024 * 16);
         w.team_xchg_end = o;
     }
     w.total = o;
@@ -632,7 +632,7 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
         // it: tests/test_gpu_team.py keeps a second stream busy throughout.  EVAC_TEAM_COOP=1 launches cooperatively instead
         // (the runtime then guarantees co-residency); it costs 3-4 % of the C5 shard's throughput and is not the default.
         hipStream_t s_ = (hipStream_t)stream;
-        // every slot of the exchange area starts a launch holding the sentinel (the last two rounds of the previous launch left data)
+        // every slot of the exchange area starts a launch with tag 31 in every word -- no round's (the previous launch left tagged data)
         if (hipMemsetAsync(h->p.team_rec, 0xff, h->team_xchg_bytes, s_) != hipSuccess) return fail(h, EVAC_ERR_HIP, "evac_rollout: hipMemsetAsync failed");
         const dim3 grid(team_grid(h)), block(1024);
         int n_steps_ = (int)n_steps;

@@ -110,8 +110,8 @@ struct Params {
     float4* agent;
     int4* clock;
     float4* acc;
-    // exchange areas of the team kernels (evac_team.h, exchange()), inside the caller's workspace: three slot sets of
-    // rec [3][E][32] x 16 B and tile [3][E][1024] x 16 B, contiguous, reset to the sentinel (0xff bytes) by the host in front of
+    // exchange areas of the team kernels (evac_team.h, exchange()), inside the caller's workspace: two slot sets of
+    // rec [2][E][32] x 16 B and tile [2][E][1024] x 16 B, contiguous, filled with 0xff bytes (= the tag of no round) by the host in front of
     // every team launch; team_err: the handle's host-mapped error word
     void *team_tile, *team_rec;
     unsigned* team_err;

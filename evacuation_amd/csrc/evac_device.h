@@ -198,7 +198,20 @@ __device__ __forceinline__ void step_env(const Params& p, typename F::Ctx& c, bo
     }   // work
     if constexpr (GRAV) F::exit_publish(c, exit_lane, gx, gy);
     if constexpr (F::kPipelined) F::stage_next(p, c, q, work);   // team kernels: the next step's tile entry travels with this reduction
-    if constexpr (!(EVAC_ABLATE & 8)) F::template reduce<false>(p, c, s, pred);
+    if constexpr (!(EVAC_ABLATE & 8)) {
+        if constexpr (F::kPipelined) {
+            // team kernels: the reduction is a round trip through global memory; the step's observation row -- per-lane data that does
+            // not depend on it -- is stored between the publish and the poll, under that latency (rollout_body stores it again, over
+            // this one, on the rare step that ends an episode: the reset observation)
+            F::reduce_publish(p, c, s, pred);
+            if constexpr (!GRAV) {
+                if (work && c.obs_dst != nullptr) write_obs_generic(p, c.i, active, q, e, StorePlain{c.obs_dst});
+            }
+            F::reduce_collect(p, c, s);
+        } else {
+            F::template reduce<false>(p, c, s, pred);
+        }
+    }
     out.reward = out.gx = out.gy = out.ex = out.ey = 0.0f;
     if (GRAV && work) {                       // (helper waves store no observation)
         float ex = 0.0f, ey = 0.0f;
@@ -716,6 +729,8 @@ __device__ __forceinline__ void rollout_body(
         EVAC_T(w, 0);   // action fetch + noise Philox
         // (EVAC_ABLATE & 32, timing experiment only: a wave without a row to evaluate skips its step -- what the heavy waves would
         // gain if the light ones cost nothing: 46.5 -> 36.4 us per 20-step C2 launch, profiles/r04_h_c2_light_waves_cost.txt)
+        float* rowp = slab_out + ((size_t)t * E + w.env) * row;
+        if constexpr (F::kPipelined && !GRAV && !(EVAC_ABLATE & 2)) w.obs_dst = rowp;     // (team kernels: step_env stores the observation row itself)
         if (!((EVAC_ABLATE & 32) && !wants_noise)) step_env<F, GRAV>(p, w, active, q, e, adir, nz, o);
         // trajectory capture for rendering (Pedestrians.save / Agent.save, pedestrians.py:33-35, area.py:32-33):
         // the post-step, pre-reset state of the first `capture_envs` envs; row N holds the leader.
@@ -746,7 +761,6 @@ __device__ __forceinline__ void rollout_body(
             F::invalidate(w);
             if constexpr (GRAV) grav_observation<F>(p, w, active, q, e, o6);
         }
-        float* rowp = slab_out + ((size_t)t * E + w.env) * row;
         if constexpr (GRAV) {
             if constexpr (!(EVAC_ABLATE & 16)) {
                 if (w.owner) {
@@ -775,6 +789,7 @@ __device__ __forceinline__ void rollout_body(
             if constexpr (!(EVAC_ABLATE & 2)) {
                 bool stores = true;             // (team kernels: waves without pedestrians store no observation)
                 if constexpr (F::kHelpers) stores = !w.helper;
+                if constexpr (F::kPipelined) stores = stores && o.done;   // (... and the row went out inside step_env: only the reset observation of a finished episode is left)
                 if (stores) write_obs_generic(p, w.i, active, q, e, StorePlain{rowp});
             }
             if (w.owner && !(EVAC_ABLATE & 16)) {

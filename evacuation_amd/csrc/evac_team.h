@@ -6,7 +6,7 @@
 // Member k of a team owns pedestrians [k P, (k+1) P), P = 1024 / K, in the lanes of its first P / 64 waves ("ped waves");
 // all 16 waves of the workgroup share the member's part of the pair work.  The members meet ONCE per step through global
 // memory (device-scope write-through stores and device-scope loads, no cache flush or invalidation, and NO counter: every
-// published word validates itself against a sentinel that its slot holds between uses -- exchange() below; round 2's
+// published 8-byte half carries the tag of its round and validates itself -- exchange() below; round 2's
 // store / acknowledgement / counter / spin / load protocol is tools/experiments/r04_team_counter_exchange.patch;
 // tools/microbench/team_sentinel.hip and team_barrier.hip time both in isolation).  What travels in that round:
 //   * the step's reduction: every ped wave publishes the same 32-byte record as a wave of Cells<16> leaves in LDS; after the
@@ -47,25 +47,30 @@ namespace evac {
 constexpr int kTeamFewRows = 32;     // needed rows of a member up to which its sweep is transposed (with the packed-f32 sweeps of round 4: 16-32 flat, 48 -3 %, 64 -8 %, 96 -20 %: profiles/r04_j_c5_few_rows_threshold.txt)
 constexpr int kTeamFirstPoll = 12;   // s_sleep units (64 cycles) between the member's own publish and its first poll (round 4, after the sweeps got faster: 12 +1 % over 8, 4 -3 %, 16 -1 %, 24 -5 %)
 constexpr int kTeamPollGap = 2;      // ... between two polls
+constexpr int kTeamMinPoll = 4;      // round 5: the first poll adapts to where the last round's data arrived (exchange()); never earlier than this
 
 __device__ __forceinline__ void store_dev(void* ptr, f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
 __device__ __forceinline__ void store_dev_i32(void* ptr, int v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
 __device__ __forceinline__ void lds_add(int* ptr, int v) { (void)__hip_atomic_fetch_add(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// The self-validating exchange: a slot of the exchange area holds the sentinel in all its words until
-// its writer publishes, and goes back to it one round after it was read.  No published word can be the sentinel: positions
-// and float sums that happen to carry this NaN payload are published as the canonical NaN, integer headings are 24-bit
-// fields under a flag byte, packed counts never have their top bit set.
-constexpr unsigned kSent = 0xffffffffu;
-constexpr int kEntryNull = 1 << 29, kEntryNan = 1 << 30;   // flag byte of an entry's heading-x word: no pedestrian that moves here / NaN heading
-__device__ __forceinline__ float unsent(float v) { return __builtin_bit_cast(unsigned, v) == kSent ? __builtin_nanf("") : v; }
-__device__ __forceinline__ bool fresh(f4 v) {
-    const float a = v.x, b = v.y, c = v.z, d = v.w;   // (bit_cast straight from a vector element picks element 0 with this compiler)
-    return __builtin_bit_cast(unsigned, a) != kSent && __builtin_bit_cast(unsigned, b) != kSent && __builtin_bit_cast(unsigned, c) != kSent &&
-           __builtin_bit_cast(unsigned, d) != kSent;
-}
+// The self-validating exchange, round 5: every 8-byte half of a published entry / record carries the TAG of its round
+// (round mod 31, five spare bits of a word that has them: the flag byte of the integer headings, the top bits of the packed counts);
+// the host fills the area with 0xff before a launch, which reads as tag 31 -- never a round's.  A slot is fresh when all its tags
+// are the round's; what it held before is a few rounds old (a slot is rewritten every second round, or after at most four when
+// rounds without a tile or without records intervene), never a multiple of 31.  Round 3's form kept a sentinel in every word of a
+// slot between uses and RESET each slot one round after it was read: a second store per entry and step -- 16.5 KB of the 77.9 KB
+// of HBM traffic per env-step (profiles/traffic.json of round 4) -- and a third slot set to keep the reset off the next poll; both
+// are gone.  (An 8-byte half is the unit the tags protect: positions and float sums have no spare bits, so they travel next to a
+// tagged word; global accesses of a lane are not torn below that on this hardware -- and tools/soak_variants.py compares every
+// launch of 10^6 steps with the one-workgroup kernels bit for bit.)
+constexpr int kTeamSets = 2;
+constexpr int kTagBits = 5, kTagMod = 31;
+constexpr int kEntryTagShift = 24;                          // heading words: 24-bit field | tag << 24 | flags (bits 29, 30)
+constexpr int kEntryNull = 1 << 29, kEntryNan = 1 << 30;   // flag bits of an entry's heading-x word: no pedestrian that moves here / NaN heading
+constexpr int kCountTagShift = 27;                          // packed-count words: two counts of at most 1024 in bits 0-10 and 16-26 | tag << 27
+__device__ __forceinline__ bool tagged(float w, int shift, int tag) { return ((__builtin_bit_cast(int, w) >> shift) & ((1 << kTagBits) - 1)) == tag; }
 __device__ __forceinline__ void load_dev(f4& v, const void* ptr) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory"); }
-__device__ __forceinline__ void land(f4& a, f4& b) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b)::"memory"); }   // the loads into a and b have returned
+__device__ __forceinline__ void land(f4& a, f4& b, f4& c) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)::"memory"); }   // the loads into a, b and c have returned
 
 template <int K_>
 struct Team {
@@ -99,7 +104,10 @@ struct Team {
         Smem& sm;
         int env, slot, wave_in_env, lane, i, member, wave;
         bool owner, helper;
-        int set = 0, prev_set = -1;           // slot set of the round in progress (round % 3), of the round before
+        int round = 0;                        // exchange rounds of this launch so far (the same in every wave of the team): slot set round & 1, tag round % 31
+        int first_poll = kTeamFirstPoll;      // s_sleep units between the publish and the first poll: adapted to how long the last round's data took
+        float* obs_dst = nullptr;             // rollouts with the generic observation: where this step's observation row goes -- stored by step_env
+                                              // between the publish of the reduction record and the poll for the others' (under the round's latency)
         // the tile in LDS: valid for the coming step?  its size, its NaN headings, this lane's row slot in it
         bool tile_valid = false, staged = false;
         int n_cols = 0, n_nan = 0, row_slot = 0;
@@ -135,10 +143,11 @@ struct Team {
         __syncthreads();
     }
 
-    static __device__ __forceinline__ f4* xtile(const Params& p, const Ctx& c, int set) { return (f4*)p.team_tile + ((size_t)set * p.n_envs + c.env) * 1024; }
-    static __device__ __forceinline__ f4* xrec(const Params& p, const Ctx& c, int set) { return (f4*)p.team_rec + ((size_t)set * p.n_envs + c.env) * (2 * WPE); }
+    static __device__ __forceinline__ f4* xtile(const Params& p, const Ctx& c) { return (f4*)p.team_tile + ((size_t)(c.round & 1) * p.n_envs + c.env) * 1024; }
+    static __device__ __forceinline__ f4* xrec(const Params& p, const Ctx& c) { return (f4*)p.team_rec + ((size_t)(c.round & 1) * p.n_envs + c.env) * (2 * WPE); }
+    static __device__ __forceinline__ int tag_of(const Ctx& c) { return c.round % kTagMod; }
 
-    // EVERY lane of a ped wave publishes an entry for the step that starts from state `q` -- its slot must leave the sentinel
+    // EVERY lane of a ped wave publishes an entry for the step that starts from state `q` -- its slot must carry the round's tag
     // for the readers to go on; a pedestrian that does not move is flagged (kEntryNull) and dropped by the reader, a NaN
     // heading is flagged too (the integer conversion loses it).  The row position goes to LDS, compacted per ped wave.
     static __device__ __forceinline__ void publish_entry(const Params& p, Ctx& c, const Ped& q, bool efv, bool row, float ux, float uy) {
@@ -149,9 +158,10 @@ struct Team {
         const float hs = p.head_scale;
         const int hx = (int)__builtin_rintf(ux * hs), hy = (int)__builtin_rintf(uy * hs);
         const bool nanh = ux != ux || uy != uy;
-        const int fx = (hx & 0xffffff) | (efv ? (nanh ? kEntryNan : 0) : kEntryNull), fy = hy & 0xffffff;
-        wait_vmem();      // the reset of this slot (a step ago) is acknowledged before the new data goes out: see exchange()
-        store_dev(xtile(p, c, c.set) + c.wave_in_env * kWave + c.lane, f4{unsent(X), unsent(Y), __builtin_bit_cast(float, fx), __builtin_bit_cast(float, fy)});
+        const int tag = tag_of(c);
+        const int fx = (hx & 0xffffff) | (tag << kEntryTagShift) | (efv ? (nanh ? kEntryNan : 0) : kEntryNull), fy = (hy & 0xffffff) | (tag << kEntryTagShift);
+        // (X, heading x | tag, Y, heading y | tag): a tagged word in each 8-byte half
+        store_dev(xtile(p, c) + c.wave_in_env * kWave + c.lane, f4{X, __builtin_bit_cast(float, fx), Y, __builtin_bit_cast(float, fy)});
         if (c.lane == 0) sm.rows[c.wave] = __popcll(m_row);
         if (row) sm.rowpos[c.wave][c.row_slot] = make_float2(X, Y);
     }
@@ -162,53 +172,59 @@ struct Team {
         int rank;
     };
 
-    // ONE ROUND of the exchange, called by all 16 waves after this member's ped waves have issued their stores into set
-    // c.set.  There is no counter: a slot holds the sentinel until its writer publishes, so every reader polls the data
-    // itself -- TILE rounds: wave w of every member entry `lane` of segment w; RECORD rounds: two helper waves the 16 records
-    // (lane w: record w), which they fold with the DPP tree of Wave<16>::reduce (same tree, same rounding) and leave in LDS.
-    // One fabric trip after the last member's stores have landed everybody has the data (the counter protocol took three:
-    // store acknowledgement, counter, loads; tools/microbench/team_sentinel.hip: 2.2 against 2.6 us per round with balanced
-    // members, 3.4 against 4.4 with imbalanced ones).  The workgroup barrier at the top parks the helper waves without memory
-    // traffic while the member's own ped waves still compute.
-    // Re-use of the slots: after the barrier at the bottom this member has seen every member's data of round r, and a member
-    // publishes round r only after all its waves have read round r - 1 (a workgroup barrier lies between): so every writer
-    // now resets its round r - 1 slots to the sentinel.  That store is acknowledged before the writer publishes again
-    // (wait_vmem in front of every publish, a step later: free), i.e. before round r + 1's data exists, which every reader
-    // must have seen before it polls set (r - 1) % 3 again at round r + 2.  With two sets the reset would race with that poll.
+    // ONE ROUND of the exchange, called by all 16 waves after this member's ped waves have issued their stores into the round's slot
+    // set.  There is no counter and no barrier across the members: every published 8-byte half carries the round's tag (above), so
+    // every reader polls the data itself -- TILE rounds: wave w of every member entry `lane` of segment w; RECORD rounds: two helper
+    // waves the 16 records (lane w: record w), which they fold with the DPP tree of Wave<16>::reduce (same tree, same rounding) and
+    // leave in LDS.  One fabric trip after the last member's stores have landed everybody has the data (the counter protocol of
+    // round 2 took three: store acknowledgement, counter, loads).  The workgroup barrier at the top parks the helper waves without
+    // memory traffic while the member's own ped waves still compute.
+    // Re-use of the slots (two sets, round & 1): a member publishes round r + 2 -- into the set of round r -- only after all its
+    // waves have read round r + 1 (the barrier at the bottom), i.e. after EVERY member has published round r + 1, which each did
+    // only after all its waves had read round r.  Nothing is reset: round r's data simply stops being fresh.
+    // The first poll comes `first_poll` sleep units after the barrier: what the last round's data took, less one gap (polls are
+    // device-scope loads that go out to the fabric, and a wave that polls early slows everybody's round trips down: round 3).
     // Bounded: 2^20 polls (about a second), then the team is lost (see team_round).
     template <bool RECORDS>
     static __device__ __forceinline__ Fetched exchange(const Params& p, Ctx& c, bool tile) {
         auto& sm = c.sm;
         __syncthreads();
-        const f4* gt = xtile(p, c, c.set) + c.wave * kWave + c.lane;
+        const int tag = tag_of(c);
+        const f4* gt = xtile(p, c) + c.wave * kWave + c.lane;
         const int w = c.lane < WPE ? c.lane : WPE - 1;
         const bool folds = RECORDS && (c.wave == PW || c.wave == PW + 1);
-        const f4* gr = xrec(p, c, c.set) + 2 * w + (c.wave == PW + 1 ? 1 : 0);
-        f4 ev = f4{0.0f, 0.0f, __builtin_bit_cast(float, kEntryNull), 0.0f}, rv = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        const f4* gr = xrec(p, c) + 2 * w;
+        const f4 none = f4{0.0f, __builtin_bit_cast(float, kEntryNull), 0.0f, 0.0f};
+        f4 ev = none, ra = f4{0.0f, 0.0f, 0.0f, 0.0f}, rb = ra;
         if ((tile || folds) && !sm.abort) {      // (uniform)
-            __builtin_amdgcn_s_sleep(kTeamFirstPoll);
+            for (int u = c.first_poll; u > 0; u -= kTeamPollGap) __builtin_amdgcn_s_sleep(kTeamPollGap);   // (s_sleep takes an immediate: in steps of the poll gap)
             int tries = 0;
             for (;;) {
                 if (tile) load_dev(ev, gt);
-                if (folds) load_dev(rv, gr);
-                land(ev, rv);
-                const bool stale = (tile && !fresh(ev)) || (folds && !fresh(rv));
+                if (folds) { load_dev(ra, gr); load_dev(rb, gr + 1); }
+                land(ev, ra, rb);
+                const bool stale = (tile && !(tagged(ev.y, kEntryTagShift, tag) && tagged(ev.w, kEntryTagShift, tag))) ||
+                                   (folds && !(tagged(ra.y, kCountTagShift, tag) && tagged(ra.w, kCountTagShift, tag) &&
+                                               tagged(rb.y, kCountTagShift, tag) && tagged(rb.w, kCountTagShift, tag)));
                 if (ballot(stale) == 0ull) break;
                 if (++tries >= (1 << 20)) {
                     if (c.lane == 0) {
                         sm.abort = 1;
                         __hip_atomic_store(p.team_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped: the host reads it without a sync
                     }
-                    ev = f4{0.0f, 0.0f, __builtin_bit_cast(float, kEntryNull), 0.0f};
+                    ev = none;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(kTeamPollGap);
             }
+            // the next round's first poll: where this round's data arrived, less one gap (never before kTeamMinPoll, never later
+            // than 64 units: a round that waited for a straggler must not put the next one to sleep)
+            c.first_poll = min(max(c.first_poll + (tries - 1) * kTeamPollGap, kTeamMinPoll), 64);
         }
         if constexpr (RECORDS) {
             static_assert(PW + 1 < WPE, "two helper waves fold the records");
-            if (c.wave == PW) {                 // the float sums
-                f4 rf = rv;
+            if (c.wave == PW) {                 // the float sums: (f0, ., f1, .) (f2, ., ., .)
+                f4 rf = f4{ra.x, ra.z, rb.x, 0.0f};
 #define EVAC_RED_STEP(CTRL) rf.x = dpp_add<CTRL, 0xf>(rf.x); rf.y = dpp_add<CTRL, 0xf>(rf.y); rf.z = dpp_add<CTRL, 0xf>(rf.z);
                 EVAC_RED_STEP(0x111)
                 EVAC_RED_STEP(0x112)
@@ -216,8 +232,10 @@ struct Team {
                 EVAC_RED_STEP(0x118)
 #undef EVAC_RED_STEP
                 if (c.lane == WPE - 1) sm.red_f = rf;
-            } else if (c.wave == PW + 1) {      // the packed counts
-                i4 ri = __builtin_bit_cast(i4, rv);
+            } else if (c.wave == PW + 1) {      // the packed counts: (., c01, ., c23) (., c45, ., c67), the tags taken off
+                const float w0 = ra.y, w1 = ra.w, w2 = rb.y, w3 = rb.w;
+                constexpr int kCounts = (1 << kCountTagShift) - 1;
+                i4 ri = i4{__builtin_bit_cast(int, w0) & kCounts, __builtin_bit_cast(int, w1) & kCounts, __builtin_bit_cast(int, w2) & kCounts, __builtin_bit_cast(int, w3) & kCounts};
 #define EVAC_RED_STEP(CTRL)                                                                                       \
     ri.x = dpp_addi<CTRL, 0xf>(ri.x); ri.y = dpp_addi<CTRL, 0xf>(ri.y); ri.z = dpp_addi<CTRL, 0xf>(ri.z);         \
     ri.w = dpp_addi<CTRL, 0xf>(ri.w);
@@ -231,8 +249,8 @@ struct Team {
         }
         Fetched f{ev, false, 0};
         if (tile) {                             // which entries of the segment are pedestrians that move, and where they go
-            const float ez = ev.z;
-            const int fx = __builtin_bit_cast(int, ez);
+            const float ey = ev.y;
+            const int fx = __builtin_bit_cast(int, ey);
             f.valid = (fx & kEntryNull) == 0;
             const unsigned long long mv = ballot(f.valid);
             f.rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mv >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mv, 0u));
@@ -240,16 +258,7 @@ struct Team {
             if (c.lane == 0) sm.segcnt[c.wave] = __popcll(mv) | (nn << 16);
         }
         __syncthreads();
-        if (c.prev_set >= 0 && !c.helper) {     // (all members have read the previous round)
-            const f4 sent = f4{__builtin_bit_cast(float, kSent), __builtin_bit_cast(float, kSent), __builtin_bit_cast(float, kSent), __builtin_bit_cast(float, kSent)};
-            store_dev(xtile(p, c, c.prev_set) + c.wave_in_env * kWave + c.lane, sent);
-            if (c.lane == 0) {
-                store_dev(xrec(p, c, c.prev_set) + 2 * c.wave_in_env, sent);
-                store_dev(xrec(p, c, c.prev_set) + 2 * c.wave_in_env + 1, sent);
-            }
-        }
-        c.prev_set = c.set;
-        c.set = c.set == 2 ? 0 : c.set + 1;
+        c.round += 1;
         return f;
     }
 
@@ -267,9 +276,9 @@ struct Team {
         const int off = __builtin_amdgcn_readlane(incl - cnt, c.wave);
         const int n_cols = __builtin_amdgcn_readlane(incl, WPE - 1), n_nan = __builtin_amdgcn_readlane(nans, WPE - 1);
         if (f.valid) {
-            const float ez = f.ev.z, ew = f.ev.w;
-            const int hx = (__builtin_bit_cast(int, ez) << 8) >> 8, hy = (__builtin_bit_cast(int, ew) << 8) >> 8;   // (flag byte off, sign back)
-            sm.tile[off + f.rank] = f4{f.ev.x, f.ev.y, (float)hx, (float)hy};       // integer headings AS FLOATS (|h| < 2^22: exact)
+            const float ey = f.ev.y, ew = f.ev.w;
+            const int hx = (__builtin_bit_cast(int, ey) << 8) >> 8, hy = (__builtin_bit_cast(int, ew) << 8) >> 8;   // (flag / tag byte off, sign back)
+            sm.tile[off + f.rank] = f4{f.ev.x, f.ev.z, (float)hx, (float)hy};       // integer headings AS FLOATS (|h| < 2^22: exact)
         }
         if (threadIdx.x < kPad) sm.tile[n_cols + threadIdx.x] = f4{__builtin_inff(), 0.0f, 0.0f, 0.0f};
         c.n_cols = n_cols;
@@ -287,20 +296,26 @@ struct Team {
         c.staged = true;
     }
 
-    template <bool GUARD, class C>
-    static __device__ __forceinline__ void reduce(const Params& p, C& c, Sums& s, const unsigned long long (&pred)[8]) {
+    // The step's reduction in two halves, so that step_env can put work that does not depend on it -- the observation stores --
+    // between the publish and the poll (kPipelined): the round's latency, one device-scope hand-off, is there anyway.
+    template <class C>
+    static __device__ __forceinline__ void reduce_publish(const Params& p, C& c, Sums& s, const unsigned long long (&pred)[8]) {
         wave_sum3(s.f0, s.f1, s.f2);
 #pragma unroll
         for (int k = 0; k < 8; ++k) s.i[k] = mask_count(pred[k]);
+        if (!c.helper && c.lane == 0) {        // the wave's record: the same sums and counts as a wave of Cells<16> leaves in LDS
+            f4* rec = xrec(p, c);
+            const int tg = tag_of(c) << kCountTagShift;       // (a count is at most 64 per wave, 1024 per env: bits 27-31 are free)
+            const int c01 = s.i[0] | (s.i[1] << 16) | tg, c23 = s.i[2] | (s.i[3] << 16) | tg, c45 = s.i[4] | (s.i[5] << 16) | tg, c67 = s.i[6] | (s.i[7] << 16) | tg;
+            // (sum, counts | tag) pairs: a tagged word in each 8-byte half
+            store_dev(rec + 2 * c.wave_in_env, f4{s.f0, __builtin_bit_cast(float, c01), s.f1, __builtin_bit_cast(float, c23)});
+            store_dev(rec + 2 * c.wave_in_env + 1, f4{s.f2, __builtin_bit_cast(float, c45), 0.0f, __builtin_bit_cast(float, c67)});
+        }
+    }
+    template <class C>
+    static __device__ __forceinline__ void reduce_collect(const Params& p, C& c, Sums& s) {
         const bool staged = c.staged;          // uniform over the team: this round also carries the next step's tile
         c.staged = false;
-        if (!c.helper && c.lane == 0) {        // the wave's record: the same 32 bytes as a wave of Cells<16> leaves in LDS
-            f4* rec = xrec(p, c, c.set);
-            wait_vmem();                       // (the slot's reset, a step ago)
-            store_dev(rec + 2 * c.wave_in_env, f4{unsent(s.f0), unsent(s.f1), unsent(s.f2), 0.0f});
-            const i4 ri = i4{s.i[0] | (s.i[1] << 16), s.i[2] | (s.i[3] << 16), s.i[4] | (s.i[5] << 16), s.i[6] | (s.i[7] << 16)};
-            store_dev(rec + 2 * c.wave_in_env + 1, __builtin_bit_cast(f4, ri));
-        }
         EVAC_T(c, 12);   // (sub-phase: per-pedestrian work of the ped waves, record stores)
         const Fetched f = exchange<true>(p, c, staged);
         EVAC_T(c, 13);   // (sub-phase: the round -- waiting for the member's ped waves, polls, folds)
@@ -317,6 +332,11 @@ struct Team {
         s.i[2] = b & 0xffff; s.i[3] = b >> 16;
         s.i[4] = d & 0xffff; s.i[5] = d >> 16;
         s.i[6] = g & 0xffff; s.i[7] = g >> 16;
+    }
+    template <bool GUARD, class C>
+    static __device__ __forceinline__ void reduce(const Params& p, C& c, Sums& s, const unsigned long long (&pred)[8]) {
+        reduce_publish(p, c, s, pred);
+        reduce_collect(p, c, s);
     }
     template <class C>
     static __device__ __forceinline__ void exit_publish(C&, bool, float, float) {}
