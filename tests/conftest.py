@@ -25,7 +25,16 @@ def pytest_terminal_summary(terminalreporter):
     mod = sys.modules.get("test_gpu_parity") or sys.modules.get("tests.test_gpu_parity")
     log = getattr(mod, "TIE_LOG", None)
     if log:
-        terminalreporter.write_sep("-", "near-tie exclusions (steps of a fixture whose env-level outputs were skipped; pedestrians left out)")
-        for label, n, ties, peds in log:
-            terminalreporter.write_line(f"  {label:34s} steps {n:4d}  with a near-tie {ties:3d}  pedestrians excluded {peds:3d}")
+        terminalreporter.write_sep("-", "near-ties (steps of a fixture with a comparison within 1e-6 of its threshold; of them env-level outputs checked "
+                                        "EITHER WAY; the rest skipped them; pedestrians left out of the element-wise check)")
+        for label, n, ties, resolved, peds in log:
+            terminalreporter.write_line(f"  {label:34s} steps {n:4d}  with a near-tie {ties:3d}  checked either way {resolved:3d}  skipped {ties - resolved:3d}  "
+                                        f"pedestrians excluded {peds:3d}")
 
+    mod = sys.modules.get("test_gpu_production_faces") or sys.modules.get("tests.test_gpu_production_faces")
+    log = getattr(mod, "FACE_LOG", None)
+    if log:
+        terminalreporter.write_sep("-", "production faces against the oracle: what was compared (the rest: pedestrians a near-tie may have reached)")
+        for name, peds, all_peds, scalars, all_scalars in log:
+            terminalreporter.write_line(f"  {name[:96]:96s} pedestrian-steps {peds:7d} of {all_peds:7d} ({100.0 * peds / max(all_peds, 1):5.1f} %)  "
+                                        f"rewards / flags {scalars:5d} of {all_scalars:5d} env-steps ({100.0 * scalars / max(all_scalars, 1):5.1f} %)")

@@ -93,19 +93,40 @@ def grav_tolerance(st, alpha, eps):
     return 1e-5 * scale, 1e-5 * scale_exit
 
 
-TIE_LOG = []      # (fixture or case, envs, envs with a near-tie, pedestrians excluded): printed at the end of the session (conftest)
+TIE_LOG = []      # (fixture or case, envs, envs with a near-tie, of them resolved either way, pedestrians excluded): printed at the end of the session (conftest)
+
+
+def legal_statuses(p, pos_i, agent_pos):
+    """The statuses pedestrian i may legally get when a threshold comparison of statuses.py:29-48 lies within TIE of its radius: each
+    such comparison may come out either way in f32 (both are 'the reference's result up to rounding'); the others are fixed."""
+    d_lead = float(np.linalg.norm(pos_i - np.asarray(agent_pos, dtype=np.float64)))
+    d_exit = float(np.linalg.norm(pos_i - O.EXIT_POSITION.astype(np.float64)))
+    opts = []
+    for d, r in ((d_lead, O.R_LEADER), (d_exit, O.R_EXIT), (d_exit, O.R_ESCAPE)):
+        opts.append((True, False) if abs(d - r) < TIE else ((d < r),))
+    out = set()
+    for f in opts[0]:
+        for e1 in opts[1]:
+            for e2 in opts[2]:
+                out.add(O.ESCAPED if e2 else (O.EXITING if e1 else (O.FOLLOWER if f else O.VISCEK)))
+    return out
 
 
 def compare_step(p, wrap, pre_states, actions, noise, got, min_checked=1, label=None):
     """Oracle (reference precision) from the same f32-representable inputs vs the GPU outputs.  A comparison whose f64 margin is
     below TIE may legitimately flip in f32: the pedestrians it involves are left out of the element-wise comparison (positions,
-    directions, statuses of every OTHER pedestrian of that env are still compared), and the env-level outputs of such an env
-    (rewards, flags, observation sums -- they depend on every status) are skipped.  Both counts are returned and logged."""
-    checked = ties = peds_out = 0
+    directions, statuses of every OTHER pedestrian of that env are still compared).  The env-level outputs of such an env (rewards,
+    flags, observation sums -- they depend on every status) are checked EITHER WAY: when the tie is one of
+    the status thresholds -- the pedestrian's position and direction agree with the oracle's, only its class is in question --
+    the GPU's class must be one of the legal outcomes, and the oracle's reward / termination / observation are re-evaluated with it;
+    only a tie that changed a pedestrian's MOTION (a pair of the neighbour test, a wall test) still skips the env-level outputs.
+    All counts are returned and logged."""
+    checked = ties = resolved = peds_out = 0
     worst = 0.0
     for e, pre in enumerate(pre_states):
         st = f32_state(pre)
         pre_pos = st.pos.copy()
+        old_status = st.status.copy()
         with np.errstate(all="ignore"):
             out = O.env_step(p, st, np.asarray(actions[e], dtype=np.float32), np.asarray(noise[e], dtype=np.float32).astype(np.float64))
         finite = np.isfinite(st.pos).all()
@@ -122,13 +143,29 @@ def compare_step(p, wrap, pre_states, actions, noise, got, min_checked=1, label=
         assert bool(got["truncated"][e]) == out["truncated"], f"env {e} truncated"
         if finite and ok.any():
             worst = max(worst, float(np.abs(got["pos"][e][ok] - st.pos[ok]).max()), float(np.abs(got["dir"][e][ok] - st.dir[ok]).max()))
+        ref_reward, ref_term = out["reward"], out["terminated"]
         if tied.any():
             ties += 1
             peds_out += int(tied.sum())
-            continue
+            # status-only ties: same motion, class in question -> take the GPU's class if it is a legal one and re-evaluate
+            idx = np.nonzero(tied)[0]
+            same_motion = (np.abs(got["pos"][e][idx] - st.pos[idx]).max() <= ATOL) and (np.abs(got["dir"][e][idx] - st.dir[idx]).max() <= ATOL)
+            if not same_motion:
+                continue                                                   # (a pair / wall tie moved the pedestrian elsewhere: no env-level check)
+            alt = st.status.copy()
+            for i in idx:
+                g = int(got["status"][e][i])
+                assert g in legal_statuses(p, st.pos[i], st.agent_pos), f"env {e} pedestrian {i}: status {g} is no legal outcome of its near-tie"
+                alt[i] = g
+            st.status = alt
+            r_ped = O.status_reward(p, old_status, alt, st.now)
+            ref_reward = out["reward_agent"] + r_ped + p.intrinsic_reward_coef * out["intrinsic"]
+            term_agent = bool(out["reward_agent"] != 0.0 and p.is_termination_agent_wall_collision)     # area.py:196-199
+            ref_term = bool(term_agent or np.all(alt == O.ESCAPED))                                      # area.py:175-178, env.py:171
+            resolved += 1
         checked += 1
-        np.testing.assert_allclose(got["reward"][e], out["reward"], rtol=1e-5, atol=1e-5, equal_nan=True, err_msg=f"env {e} reward")
-        assert bool(got["terminated"][e]) == out["terminated"], f"env {e} terminated"
+        np.testing.assert_allclose(got["reward"][e], ref_reward, rtol=1e-5, atol=1e-5, equal_nan=True, err_msg=f"env {e} reward")
+        assert bool(got["terminated"][e]) == ref_term, f"env {e} terminated"
         ref_obs = flat_oracle_obs(st, wrap, p.eps)
         if wrap.positions == "grav":
             tol_p, tol_e = grav_tolerance(st, wrap.alpha, p.eps)
@@ -139,7 +176,7 @@ def compare_step(p, wrap, pre_states, actions, noise, got, min_checked=1, label=
             np.testing.assert_allclose(got["obs"][e], ref_obs, rtol=0, atol=ATOL, equal_nan=True, err_msg=f"env {e} obs")
     assert checked >= min_checked, (checked, ties)
     if label is not None:
-        TIE_LOG.append((label, len(pre_states), ties, peds_out))
+        TIE_LOG.append((label, len(pre_states), ties, resolved, peds_out))
     return checked, ties, worst
 
 
@@ -157,9 +194,10 @@ def test_teacher_forced_steps_match_reference_fixtures(ea, path):
     p = H.load_params(d["params_json"])
     K = len(d["action"])
     pre = [H.state_at(d, k) for k in range(K)]
-    # Steps with a near-tie somewhere: their env-level outputs are skipped (compare_step).  A follower that keeps its distance to
-    # the leader (enslaving_degree 1) carries the same near-tie from step to step, so the bound scales with the fixture's length;
-    # the count is printed at the end of the session (TIE_LOG), so that a silent growth is visible.
+    # Steps with a near-tie somewhere: a status-threshold tie is checked either way, a tie that moved a pedestrian skips the env-level
+    # outputs of that step (compare_step).  A follower that keeps its distance to the leader (enslaving_degree 1) carries the same
+    # near-tie from step to step, so the bound scales with the fixture's length; the counts are printed at the end of the session
+    # (TIE_LOG), so that a silent growth is visible.
     total_ties = 0
     for i, w in enumerate(WRAPS if p.number_of_pedestrians <= 256 else WRAPS[:1] + WRAPS[8:9]):
         wrap = ea.EnvWrappersConfig(**w)
@@ -289,9 +327,11 @@ def test_late_episode_states_with_few_rows(ea, n):
         compare_step(p, wrap, pre, acts, nzs, got, min_checked=2)
 
 
-def test_free_running_50_steps_vs_reference_fixture(ea):
-    """Same reset draws, actions and per-pedestrian noise as the reference episode; free-running."""
-    d = np.load(os.path.join(H.GOLDEN, "traj_n60_s1_noise05_ens05.npz"))
+@pytest.mark.parametrize("fixture", ["traj_n60_s1_noise05_ens05", "traj_n256_s5"])
+def test_free_running_50_steps_vs_reference_fixture(ea, fixture):
+    """Same reset draws, actions and per-pedestrian noise as the reference episode; free-running (N = 60: one wave per env;
+    N = 256: four waves per env, the row-blocked all-pairs sweep)."""
+    d = np.load(os.path.join(H.GOLDEN, fixture + ".npz"))
     p = H.load_params(d["params_json"])
     env = ea.BatchedEvacuationEnv(cfg_from_params(ea, p), ea.EnvWrappersConfig(positions="grav", alpha=3), num_envs=1, autoreset=False)
     draws = np.concatenate([d["draw_pos"], d["draw_dir"]], axis=1).astype(np.float32)[None]
@@ -475,6 +515,13 @@ def test_single_env_facade_matches_reference_surface(ea):
     np.testing.assert_allclose(u.pedestrians.positions, d["pos"][1], atol=ATOL)
     assert [s.value for s in u.pedestrians.statuses] == d["status"][1].tolist()
     assert u.area.exit.position.tolist() == [0.0, -1.0] and u.area.step_size == p.step_size and u.time.now == 1
+    # what the reference's scripted agent reads off the env (baseline_wacuum_cleaner.py:14-28): exit position, step size, room half-widths
+    assert env.area is u.area and env.area.width == p.width and env.area.height == p.height
+    assert env.area.exit.position.dtype == np.float32 and env.area.exit.position.shape == (2,) and env.area.eps == p.eps
+    SWITCH = 0.2                                                                  # constants.py:35 SWITCH_DISTANCE_TO_LEADER
+    go_up = lambda pos: pos[1] < env.area.height - SWITCH / 2 + env.area.step_size      # noqa: E731  (baseline_wacuum_cleaner.py:19-20, verbatim)
+    go_left = lambda pos: pos[0] > -env.area.width + SWITCH / 2 - env.area.step_size    # noqa: E731  (:25-26)
+    assert go_up(obs["agent_position"]) and go_left(obs["agent_position"])              # the leader starts in the middle of the room
     with pytest.raises(TypeError):
         env.step([1, 0])                       # integer action: the reference raises too (area.py:190)
     agent = ea.RandomAgent(env.action_space)

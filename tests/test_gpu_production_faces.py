@@ -107,6 +107,9 @@ def oracle_episode(p, wrap, seed, gid, T):
     return rows, st, taint, counts
 
 
+FACE_LOG = []     # (kernel variant, pedestrian-steps compared, of, env-steps whose rewards / flags were compared, of): printed at the end of the session (conftest)
+
+
 def check_against_oracle(ea, p, wrap, E, T, seed, offset, expect_variant):
     """Returns (pedestrian-steps compared, pedestrian-steps in all, env-steps whose rewards / flags were compared)."""
     import torch
@@ -152,6 +155,7 @@ def check_against_oracle(ea, p, wrap, E, T, seed, offset, expect_variant):
         np.testing.assert_allclose(fin["agent_pos"][e], st.agent_pos, rtol=0, atol=1e-6)
         assert fin["now"][e] == st.now
     env.close()
+    FACE_LOG.append((name, ped_steps, E * T * n, scalar_steps, E * T))
     return ped_steps, E * T * n, scalar_steps
 
 
@@ -163,7 +167,7 @@ def test_cu_wide_default_config_rollout_vs_oracle(ea):
     with _Env(EVAC_CU_WIDE="1"):
         peds, all_peds, scalars = check_against_oracle(ea, p, wrap, E=96, T=50, seed=0x5EED0002, offset=1000,
                                                        expect_variant=("k_rollout_default_config", "CU-wide"))
-    assert peds >= 0.7 * all_peds and scalars >= 0.9 * 96 * 50, (peds, all_peds, scalars)
+    assert peds >= 0.92 * all_peds and scalars >= 0.97 * 96 * 50, (peds, all_peds, scalars)     # (observed: 97.6 % / 100 %, printed at the end of the session)
 
 
 def test_cu_wide_four_wave_rollout_vs_oracle(ea):
@@ -173,7 +177,7 @@ def test_cu_wide_four_wave_rollout_vs_oracle(ea):
     with _Env(EVAC_CU_WIDE="1"):
         peds, all_peds, scalars = check_against_oracle(ea, p, wrap, E=24, T=20, seed=0x5EED0003, offset=0,
                                                        expect_variant=("k_rollout_default_config", "4 waves/env", "CU-wide"))
-    assert peds >= 0.3 * all_peds and scalars >= 0.8 * 24 * 20, (peds, all_peds, scalars)
+    assert peds >= 0.62 * all_peds and scalars >= 0.9 * 24 * 20, (peds, all_peds, scalars)      # (observed: 72.3 % / 97.1 %)
 
 
 @pytest.mark.parametrize("team", ["8", "16"])
@@ -188,7 +192,7 @@ def test_team_default_config_rollout_vs_oracle(ea, team):
     with _Env(EVAC_TEAM=team):
         peds, all_peds, scalars = check_against_oracle(ea, p, wrap, E=8, T=10, seed=0x5EED0005, offset=64,
                                                        expect_variant=("k_rollout_default_config", f"<{team} CUs/env"))
-    assert peds >= 0.5 * all_peds and scalars >= 40, (peds, all_peds, scalars)
+    assert peds >= 0.8 * all_peds and scalars >= 48, (peds, all_peds, scalars)                   # (observed: 87.1 % / 56 of 80)
 
 
 @pytest.mark.parametrize("n,E,wrap_kw", [(600, 6, dict(positions="grav", alpha=3)),
