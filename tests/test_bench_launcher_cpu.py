@@ -165,7 +165,7 @@ def test_torchrun_style_environment_is_honoured():
 def test_block_plan_tiles_the_episode():
     sys.path.insert(0, ROOT)
     import bench
-    assert bench.block_plan(20, 0, 0) == (100, 3)      # the driver's --steps 20: 100 blocks per episode sweep, 3 sweeps
+    assert bench.block_plan(20, 0, 0) == (100, 11)     # the driver's --steps 20: 100 blocks per episode sweep, 11 sweeps
     assert bench.block_plan(2000, 0, 0) == (1, 20)     # default: a block is a whole episode, 20 of them
     assert bench.block_plan(500, 0, 0)[0] == 4 and bench.block_plan(500, 0, 0)[0] * bench.block_plan(500, 0, 0)[1] >= 20
     per, sw = bench.block_plan(20, 0, 7)

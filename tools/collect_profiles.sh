@@ -8,7 +8,7 @@ G=gpurun_out/$T
 for f in $G/bench_*.json; do
   b=$(basename $f .json); tail -1 $f > profiles/${T}_${b}.json
 done
-for k in c2_driver c2_step c3 c5; do
+for k in c2_driver c2_step c3 c5 big_step; do
   d=gpurun_out/${T}_$k
   [ -d $d ] || continue
   cp $d/stats/*/*_kernel_stats.csv profiles/${T}_${k}_kernel_stats.csv

@@ -26,7 +26,8 @@ bash tools/profile_pmc.sh ${TAG}_c2_driver > /dev/null 2>&1
 bash tools/profile_pmc.sh ${TAG}_c3 --workload c3 --steps 400 --warmup 100 --sweeps 1 > /dev/null 2>&1
 bash tools/profile_pmc.sh ${TAG}_c5 --workload c5 --steps 400 --warmup 100 --sweeps 1 > /dev/null 2>&1
 bash tools/profile_pmc.sh ${TAG}_c2_step --mode step --steps 200 --warmup 50 --sweeps 1 > /dev/null 2>&1
-python tools/make_traffic_json.py gpurun_out/${TAG}_c2_driver c2:rollout 4096 20 gpurun_out/${TAG}_c3 c3:rollout 1024 100 gpurun_out/${TAG}_c5 c5:rollout 32 100 gpurun_out/${TAG}_c2_step c2:step 4096 1 > gpurun_out/$TAG/traffic_update.txt 2>&1
+bash tools/profile_pmc.sh ${TAG}_big_step --workload big --mode step --steps 100 --warmup 20 --sweeps 1 --blocks 3 > /dev/null 2>&1
+python tools/make_traffic_json.py gpurun_out/${TAG}_c2_driver c2:rollout 4096 20 gpurun_out/${TAG}_c3 c3:rollout 1024 100 gpurun_out/${TAG}_c5 c5:rollout 32 100 gpurun_out/${TAG}_c2_step c2:step 4096 1 gpurun_out/${TAG}_big_step big:step 524288 1 > gpurun_out/$TAG/traffic_update.txt 2>&1
 cp profiles/traffic.json gpurun_out/$TAG/traffic.json
 # (gpurun merges at most 64 MiB back: the raw per-dispatch counter and trace tables go, the summaries and the stats tables stay)
 find gpurun_out/${TAG}_* -name "*counter_collection.csv" -delete
