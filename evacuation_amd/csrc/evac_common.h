@@ -19,8 +19,9 @@
 
 // Profiling-only phase ablation (tools/ablate.sh builds side libraries with -DEVAC_ABLATE=mask; the
 // shipped library is always built with 0).  1: no pair loop, 2: no observation epilogue,
-// 4: no Philox (constant action / noise), 8: no status/reward reductions, 16: no per-step stores, 32: rollouts skip the
-// step of a wave without a row to evaluate (wrong results: how much the light waves cost the heavy ones).
+// 4: no Philox (constant action / noise), 8: no status/reward reductions, 16: no per-step stores.  (Round 4's mask 32 -- waves
+// without a row to evaluate skip their step -- is gone: a skipped env's clock stops, it is never reset, and over a benchmark's
+// sweeps the batch drifts into that frozen state; what it timed was another workload, not a bound: DESIGN.md 9.)
 #ifndef EVAC_ABLATE
 #define EVAC_ABLATE 0
 #endif

@@ -727,11 +727,9 @@ __device__ __forceinline__ void rollout_body(
         }
         StepOut o{};
         EVAC_T(w, 0);   // action fetch + noise Philox
-        // (EVAC_ABLATE & 32, timing experiment only: a wave without a row to evaluate skips its step -- what the heavy waves would
-        // gain if the light ones cost nothing: 46.5 -> 36.4 us per 20-step C2 launch, profiles/r04_h_c2_light_waves_cost.txt)
         float* rowp = slab_out + ((size_t)t * E + w.env) * row;
         if constexpr (F::kPipelined && !GRAV && !(EVAC_ABLATE & 2)) w.obs_dst = rowp;     // (team kernels: step_env stores the observation row itself)
-        if (!((EVAC_ABLATE & 32) && !wants_noise)) step_env<F, GRAV>(p, w, active, q, e, adir, nz, o);
+        step_env<F, GRAV>(p, w, active, q, e, adir, nz, o);
         // trajectory capture for rendering (Pedestrians.save / Agent.save, pedestrians.py:33-35, area.py:32-33):
         // the post-step, pre-reset state of the first `capture_envs` envs; row N holds the leader.
         if (DIAG && capture && w.env < capture_envs) {   // wave-/workgroup-uniform; compiled out of the default kernel
