@@ -1140,14 +1140,20 @@ def dry_run(args, rank, world, total_envs, envs_per_gpu, K, W, inner, per_sweep,
 
     nbuf = args.buffers if args.buffers > 0 else (4 if (do_gather and lag == 1) else 2)
 
+    stamps = {}                         # chunk -> host-clock stamps of its stand-in launch and gather (ms): the multi-rank line's report, dry
+
     def launch(j, t):
+        t0_ = time.perf_counter() * 1e3
         bufs[j % nbuf] = gid[None, :, None] + 1000.0 * j + torch.zeros((min(t, 4), n_local, 9))   # chunk j's "outputs"
+        stamps.setdefault(j, {}).update(l0=t0_, l1=time.perf_counter() * 1e3)
 
     def gather(j, t):
+        t0_ = time.perf_counter() * 1e3
         g, _ = all_gather_envs(bufs[j % nbuf])
         full = gathered_view(g)
         state["ok"] = state["ok"] and bool((full[0, :, 0] == torch.arange(total_envs, dtype=torch.float32) + 1000.0 * j).all())
         state["gathers"] += 1
+        stamps.setdefault(j, {}).update(g0=t0_, g1=time.perf_counter() * 1e3)
         return j
 
     pipe = ChunkPipeline(launch, gather if do_gather else None, lambda tok: None, lambda: None, lambda: None, lag=lag, trace=trace, nbuf=nbuf)
@@ -1174,8 +1180,25 @@ def dry_run(args, rank, world, total_envs, envs_per_gpu, K, W, inner, per_sweep,
         dist.barrier()
         tt = torch.tensor(wall, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    # the multi-rank line's account of its gather, assembled exactly as main() does it -- one dict per rank through all_gather_object,
+    # the form decided by choose_gather from a probe result -- from the stand-ins' host-clock stamps (no GPU: the probe says so)
+    probe = {"ok": False, "stage": "skipped", "error": "dry run: no GPU", "world": world}
+    form, alt_form = choose_gather(args.gather, probe)
+    report = None
+    if do_gather:
+        chunks = []
+        for j in sorted(stamps):
+            c = {"l0": stamps[j]["l0"], "l1": stamps[j]["l1"]}
+            g = stamps.get(j - lag)
+            if lag == 1 and g is not None and "g0" in g:
+                c["g0"], c["g1"] = g["g0"], g["g1"]
+            chunks.append(c)
+        mine = {"rank": rank, form: gather_report(form, world, min(sizes[0], 4) * n_local * 9 * 4, [], chunks, None)}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        report = {"timed_form": form, "requested": args.gather, "alternative_form": alt_form, "peer_store_probe": probe, "per_rank": everyone}
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_joined": dist.get_world_size() if world > 1 else 1,
+        print(json.dumps({"dry_run": True, "n_gpus": world, "gather_report": report, "ranks_joined": dist.get_world_size() if world > 1 else 1,
                           "steps": K, "warmup": W, "total_envs": total_envs, "envs_per_gpu": envs_per_gpu,
                           "gather_in_global_env_order": state["ok"], "gathers": state["gathers"], "blocks": len(wall),
                           "launches_per_block": len(sizes), "chunk_sizes": sizes, "gather_schedule": args.gather_schedule,

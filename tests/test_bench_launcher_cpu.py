@@ -33,6 +33,23 @@ def test_plain_invocation_spawns_its_own_ranks():
     assert d["gather_in_global_env_order"] is True
 
 
+def test_the_multi_rank_line_carries_every_ranks_account_of_the_gather():
+    """`gather_report.per_rank` is gathered from ALL ranks (all_gather_object), the form that is timed is decided
+    by choose_gather from the probe -- here, without a GPU, the probe says no, so `--gather auto` falls back to the RCCL form."""
+    r = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run", "--gather", "auto"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json_lines(r.stdout)[0]["gather_report"]
+    assert rep["requested"] == "auto" and rep["timed_form"] == "obs" and rep["alternative_form"] is None
+    assert rep["peer_store_probe"]["ok"] is False and rep["peer_store_probe"]["stage"] == "skipped"
+    assert [x["rank"] for x in rep["per_rank"]] == [0, 1]
+    for x in rep["per_rank"]:
+        mine = x["obs"]
+        assert mine["world"] == 2 and mine["chunks_instrumented"] >= 4 and mine["gather_ms_under_compute"] > 0
+        assert mine["bytes_received_per_chunk"] == mine["bytes_per_link_per_chunk"] > 0       # one peer
+    r = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run", "--no-gather"])
+    assert json_lines(r.stdout)[0]["gather_report"] is None
+
+
 def _blocks_of(trace):
     """Split a dry-run trace into the event lists of its timed blocks (between t0 and t1) and what lies outside."""
     blocks, outside, cur = [], [], None
