@@ -396,9 +396,7 @@ struct Wave {
 #pragma unroll
                         for (int r = 2 * R2; r < R; ++r) pair_accumulate(X[r], Y[r], t, r2b, ax[r], ay[r]);
                     };
-                    // peers per LDS round trip (register budget; round 5: eight also for three row slices -- the flocked env that ends the late
-                    // launches of C3 has three: 7 round trips instead of 13 per sweep, +0.5 %, profiles/r05_g2_c3_ab_eight_columns_per_trip_for_three_slices.txt)
-                    constexpr int B = (R <= 3 && !(kEnvBarrier && R == 2)) ? 8 : 4;
+                    constexpr int B = (R <= 2 && !(kEnvBarrier && R == 2)) ? 8 : 4;   // peers per LDS round trip (register budget)
                     int j = jbeg;
                     for (; j + B <= jend; j += B) {
                         f4 t[B];
