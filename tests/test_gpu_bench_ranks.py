@@ -29,9 +29,20 @@ def _run(extra, timeout=600):
     return lines[0]
 
 
-@pytest.mark.parametrize("extra", [[], ["--gather-schedule", "split"], ["--gather", "slab"], ["--gather", "direct"], ["--gather", "peer"]])
+@pytest.mark.parametrize("extra", [[], ["--gather-schedule", "split"], ["--gather", "slab"], ["--gather", "direct"], ["--gather", "peer"], ["--gather", "auto"]])
 def test_two_ranks_on_one_gpu(extra):
     d = _run(extra)
+    # the line explains its gather -- with TWO real processes: the staged peer-store probe (hipIpc mappings of each
+    # other's buffers, a checked store pattern, an agreement over the host after every stage) and one account per rank
+    rep = d["gather_report"]
+    assert rep["peer_store_probe"]["ok"] is True and rep["peer_store_probe"]["world"] == 2 and rep["peer_store_probe"]["devices"] == [0, 0]
+    assert [x["rank"] for x in rep["per_rank"]] == [0, 1]
+    form = rep["timed_form"]
+    assert form == {"slab": "slab", "direct": "direct", "peer": "peer", "auto": "peer"}.get(extra[1] if extra[:1] == ["--gather"] else "", "obs") == d["config"]["gather"]
+    for x in rep["per_rank"]:
+        assert x[form]["world"] == 2 and x[form]["gather_ms_alone"] > 0 and x[form]["bytes_received_per_chunk"] == x[form]["bytes_per_link_per_chunk"] > 0
+    if "split" not in extra and form in ("obs", "peer"):
+        assert rep["alternative_form"] == ("peer" if form == "obs" else "obs") and rep["alternative_value"] > 0
     assert d["n_gpus"] == 2 and d["config"]["ranks_joined"] == 2 and d["config"]["total_envs"] == 1024
     assert d["value"] > 0 and d["blocks"]["timed_blocks"] == 6
     assert d["config"]["launches_per_block"] == (2 if "split" in extra else 1)
