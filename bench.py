@@ -1009,6 +1009,14 @@ def main(argv=None):
             dt = time.perf_counter() - t1
             step_api["host_vector_env_us_per_step"] = dt / n_host * 1e6
             step_api["host_vector_env_env_steps_per_s"] = E * n_host / dt
+            step_api["host_vector_env_zero_copy"] = host.zero_copy
+            staged = ea.HostVectorEnv(loc, copy=True, zero_copy=False)     # round 4's form: an asynchronous copy each way
+            for _ in range(20):
+                staged.step(act_np)
+            t1 = time.perf_counter()
+            for _ in range(n_host):
+                staged.step(act_np)
+            step_api["host_vector_env_staged_us_per_step"] = (time.perf_counter() - t1) / n_host * 1e6
         except Exception as exc:  # noqa: BLE001
             step_api["host_vector_env_error"] = f"{type(exc).__name__}: {exc}"[:160]
 

@@ -14,9 +14,11 @@ adapter is the drop-in for the UNMODIFIED trainer: NumPy actions in; ``obs [E, D
 device env builds them (``"final_info" in infos`` / ``infos["final_info"]`` with the reference's episode record and
 ``episode = {"r", "l"}``; the lazily built list reuses the flags this adapter has already brought to the host).
 
-One pinned staging buffer each way: the actions go up and the packed step outputs come down with one asynchronous copy
-each and ONE stream synchronisation per step.  Like SyncVectorEnv the returned arrays are buffers of the env that the next
-``step`` overwrites (``copy=True``, SyncVectorEnv's default, hands out copies instead)."""
+One pinned buffer each way and ONE stream synchronisation per step.  Round 5: the step kernel reads the actions FROM and writes its
+outputs TO those pinned host buffers itself (pinned host memory is mapped into the device's address space at the same address on
+ROCm; checked with hipHostGetDevicePointer, with the staged form of round 4 -- an asynchronous copy each way -- as the fallback):
+no copy calls, one pre-bound launch.  Like SyncVectorEnv the returned arrays are buffers of the env that the next ``step`` overwrites
+(``copy=True``, SyncVectorEnv's default, hands out copies instead)."""
 from __future__ import annotations
 
 import dataclasses
@@ -25,7 +27,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .vector_env import BatchedEvacuationEnv
+from .vector_env import BatchedEvacuationEnv, StepInfos
 from .wrappers import NormalizedVectorEnv
 
 
@@ -35,7 +37,7 @@ class HostVectorEnv:
     ``env``: a ``BatchedEvacuationEnv`` or a ``NormalizedVectorEnv`` (the trainer's wrapper chain).  ``make`` builds what
     ``SyncVectorEnv([make_env(env_config, wrap_config, gamma)] * num_envs)`` builds (rpo_agent.py:35-39,123-126)."""
 
-    def __init__(self, env, copy: bool = True):
+    def __init__(self, env, copy: bool = True, zero_copy: bool = True):
         self.env = env
         base = env.env if isinstance(env, NormalizedVectorEnv) else env
         if not isinstance(base, BatchedEvacuationEnv):
@@ -62,32 +64,66 @@ class HostVectorEnv:
         self._h_act = torch.empty((E, 2), dtype=torch.float32, pin_memory=True)
         self._d_act = torch.empty((E, 2), dtype=torch.float32, device=self.device)
         self._np_act = self._h_act.numpy()
+        # zero-copy: the kernel's own loads / stores go to the pinned buffers (one launcher, bound once)
+        self.zero_copy = bool(zero_copy) and self._device_sees(self._h_out) and self._device_sees(self._h_act)
+        self._launch, self._closed = None, False
+        if self.zero_copy:
+            hb = self._h_out
+            hf32 = hb[:n_f32 * 4].view(torch.float32)
+            self._p_obs, self._p_reward = hf32[:E * D].view(E, D), hf32[E * D:]
+            self._p_term, self._p_trunc = hb[n_f32 * 4:n_f32 * 4 + E], hb[n_f32 * 4 + E:]
+            norm = None
+            if isinstance(env, NormalizedVectorEnv):
+                norm = (env.norm_state, env.gamma, env.obs_clip, env.reward_clip, env.epsilon)
+            self._launch = base.step_launcher(self._h_act, out_obs=self._p_obs, out_reward=self._p_reward, out_terminated=self._p_term,
+                                              out_truncated=self._p_trunc, _norm=norm, _allow_host=True)
         self._reward = np.zeros((E,), dtype=np.float64)            # SyncVectorEnv's buffer dtypes
         self._term = np.zeros((E,), dtype=np.bool_)
         self._trunc = np.zeros((E,), dtype=np.bool_)
         self._obs = np.zeros((E, D), dtype=np.float32)
 
     @classmethod
-    def make(cls, env_config, wrap_config=None, num_envs: int = 1, gamma: float = 0.99, normalize: bool = True, copy: bool = True, **kw):
+    def make(cls, env_config, wrap_config=None, num_envs: int = 1, gamma: float = 0.99, normalize: bool = True, copy: bool = True,
+             zero_copy: bool = True, **kw):
         """The env + the trainer's wrapper chain (``wrapping(env, gamma)``, rpo_agent.py:24-33) for ``num_envs`` envs."""
         if normalize:
-            return cls(NormalizedVectorEnv.make(env_config, wrap_config, num_envs=num_envs, gamma=gamma, **kw), copy=copy)
+            return cls(NormalizedVectorEnv.make(env_config, wrap_config, num_envs=num_envs, gamma=gamma, **kw), copy=copy, zero_copy=zero_copy)
         cfg = dataclasses.replace(env_config, clip_action=True)
-        return cls(BatchedEvacuationEnv(cfg, wrap_config, num_envs=num_envs, autoreset=True, **kw), copy=copy)
+        return cls(BatchedEvacuationEnv(cfg, wrap_config, num_envs=num_envs, autoreset=True, **kw), copy=copy, zero_copy=zero_copy)
+
+    @staticmethod
+    def _device_sees(t: torch.Tensor) -> bool:
+        """Is this pinned host tensor mapped into the device's address space at its own address?"""
+        import ctypes as C
+        try:
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipHostGetDevicePointer.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint]
+            dp = C.c_void_p()
+            rc = hip.hipHostGetDevicePointer(C.byref(dp), C.c_void_p(t.data_ptr()), 0)
+            return rc == 0 and dp.value == t.data_ptr()
+        except Exception:  # noqa: BLE001
+            return False
 
     # ------------------------------------------------------------------------------------------
     def _download(self, stepped: bool):
         self._h_out.copy_(self._d_out, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
+        self._sync()
         np.copyto(self._obs, self._np_obs)
         if stepped:
             np.copyto(self._reward, self._np_reward)                  # float32 -> float64, exact
             np.not_equal(self._np_term, 0, out=self._term)
             np.not_equal(self._np_trunc, 0, out=self._trunc)
 
+    def _sync(self):
+        torch.cuda.current_stream(self.device).synchronize()
+
     def reset(self, seed: Optional[int] = None, options=None):
         """``SyncVectorEnv.reset(seed=)`` -> ``(obs [E, D] float32, {})``."""
         obs, infos = self.env.reset(seed=seed, options=options)
+        if self._launch is not None:
+            self._p_obs.copy_(obs, non_blocking=True)
+            self._sync()
+            return (self._np_obs.copy() if self.copy else self._np_obs), infos
         self._d_obs.copy_(obs)
         self._download(False)
         return (self._obs.copy() if self.copy else self._obs), infos
@@ -97,7 +133,25 @@ class HostVectorEnv:
         a = np.asarray(actions, dtype=np.float32)
         if a.shape != (self.num_envs, 2):
             raise ValueError(f"actions: expected shape {(self.num_envs, 2)}, got {a.shape}")
+        if self._closed:
+            raise RuntimeError("HostVectorEnv.step() after close()")
         np.copyto(self._np_act, a)
+        if self._launch is not None:                                  # zero-copy: the kernel reads the pinned actions and writes the pinned outputs
+            self._launch()
+            self._sync()
+            b = self._base
+            infos = StepInfos(b, self._p_term, self._p_trunc, final_observation=b.final_obs, episode_stats=b.final_stats) if b.autoreset else {}
+            if self.copy:                                             # ONE copy of each output: pinned buffer -> the array handed out
+                term, trunc = self._np_term != 0, self._np_trunc != 0
+                if b.autoreset:
+                    infos._done = term | trunc
+                return self._np_obs.copy(), self._np_reward.astype(np.float64), term, trunc, infos
+            np.copyto(self._reward, self._np_reward)                  # float32 -> float64, exact
+            np.not_equal(self._np_term, 0, out=self._term)
+            np.not_equal(self._np_trunc, 0, out=self._trunc)
+            if b.autoreset:
+                infos._done = self._term | self._trunc
+            return self._np_obs, self._reward, self._term, self._trunc, infos      # (obs: the pinned plane itself, rewritten by the next step)
         self._d_act.copy_(self._h_act, non_blocking=True)
         _, _, _, _, infos = self.env.step(self._d_act, out_obs=self._d_obs, out_reward=self._d_reward, out_terminated=self._d_term,
                                           out_truncated=self._d_trunc)
@@ -109,4 +163,5 @@ class HostVectorEnv:
         return self._obs, self._reward, self._term, self._trunc, infos
 
     def close(self):
+        self._closed, self._launch = True, None       # (the launcher holds the env's handle: it goes before the env does)
         self.env.close()

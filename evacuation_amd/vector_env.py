@@ -209,7 +209,11 @@ class BatchedEvacuationEnv:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _check_tensor(self, t: torch.Tensor, shape, dtype, name):
+    def _check_tensor(self, t: torch.Tensor, shape, dtype, name, allow_host: bool = False):
+        # (allow_host: PINNED host memory is device-accessible at the same address on ROCm -- HostVectorEnv lets the step kernel read
+        # its actions from and write its outputs to such buffers directly instead of staging them through device copies)
+        if allow_host and t.device.type == "cpu" and t.is_pinned() and tuple(t.shape) == tuple(shape) and t.dtype == dtype and t.is_contiguous():
+            return t
         if tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != self.device or not t.is_contiguous():
             raise ValueError(f"{name}: expected contiguous {dtype} tensor of shape {tuple(shape)} on {self.device}, "
                              f"got {t.dtype} {tuple(t.shape)} on {t.device}")
@@ -397,7 +401,8 @@ class BatchedEvacuationEnv:
             cache.popitem(last=False)
         cache[key] = (same, call)
 
-    def step_launcher(self, actions, *, out_obs=None, out_reward=None, out_terminated=None, out_truncated=None, stream=None):
+    def step_launcher(self, actions, *, out_obs=None, out_reward=None, out_terminated=None, out_truncated=None, stream=None,
+                      _norm=None, _allow_host: bool = False):
         """A zero-argument callable that enqueues ``step(actions, out_*=...)`` with every ctypes argument prepared once -- for a
         trainer that steps through preallocated storage (one launcher per row: ``actions[t]``, ``out_obs=obs[t + 1]``, ...) or
         re-fills one ``actions`` tensor in place before every call.  The call only enqueues the kernel (~3.5 us of host time
@@ -405,25 +410,40 @@ class BatchedEvacuationEnv:
         ``self.obs`` / ``reward`` / ``terminated`` / ``truncated``), ``final_obs`` / ``final_stats`` are filled as by ``step``.
         On the stream that is current at each call, or always on ``stream`` if one is given."""
         E = self.num_envs
-        act = self._check_tensor(actions, (E, 2), torch.float32, "actions")
-        obs = self.obs if out_obs is None else self._check_tensor(out_obs, (E, self.obs_dim), torch.float32, "out_obs")
-        rew = self.reward if out_reward is None else self._check_tensor(out_reward, (E,), torch.float32, "out_reward")
-        term = self.terminated if out_terminated is None else self._check_tensor(out_terminated, (E,), torch.uint8, "out_terminated")
-        trunc = self.truncated if out_truncated is None else self._check_tensor(out_truncated, (E,), torch.uint8, "out_truncated")
-        fn, h, ar = self.lib.evac_step, self._h, int(self.autoreset)
+        ah = bool(_allow_host)
+        act = self._check_tensor(actions, (E, 2), torch.float32, "actions", ah)
+        obs = self.obs if out_obs is None else self._check_tensor(out_obs, (E, self.obs_dim), torch.float32, "out_obs", ah)
+        rew = self.reward if out_reward is None else self._check_tensor(out_reward, (E,), torch.float32, "out_reward", ah)
+        term = self.terminated if out_terminated is None else self._check_tensor(out_terminated, (E,), torch.uint8, "out_terminated", ah)
+        trunc = self.truncated if out_truncated is None else self._check_tensor(out_truncated, (E,), torch.uint8, "out_truncated", ah)
+        h, ar = self._h, int(self.autoreset)
         a = (_ptr(act), None, _ptr(obs), _ptr(rew), _ptr(term), _ptr(trunc))
         fo = _ptr(self.final_obs) if self.autoreset else None
         fs = _ptr(self.final_stats) if self.autoreset else None
         keep = (act, obs, rew, term, trunc)                      # the tensors stay alive as long as the launcher does
         cur, dev = torch.cuda.current_stream, self.device
         a_stream = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        if _norm is None:
+            fn = self.lib.evac_step
 
-        def launch(_keep=keep):
-            rc = fn(h, a[0], a[1], a[2], a[3], a[4], a[5], ar, fo, fs, a_stream if a_stream is not None else C.c_void_p(cur(dev).cuda_stream))
+            def launch(_keep=keep):
+                rc = fn(h, a[0], a[1], a[2], a[3], a[4], a[5], ar, fo, fs, a_stream if a_stream is not None else C.c_void_p(cur(dev).cuda_stream))
+                if rc != 0:
+                    _lib.check(rc, h)
+                self._steps_taken += 1
+            return launch
+        # the trainer's normalisation chain fused into the same launch (NormalizedVectorEnv; HostVectorEnv binds it once)
+        fn = self.lib.evac_step_normalized
+        state, gamma, obs_clip, reward_clip, eps = _norm
+        a_state = _ptr(state)
+
+        def launch_norm(_keep=(keep, state)):
+            rc = fn(h, a[0], a[1], a[2], a[3], a[4], a[5], ar, fo, fs, a_state, gamma, obs_clip, reward_clip, eps,
+                    a_stream if a_stream is not None else C.c_void_p(cur(dev).cuda_stream))
             if rc != 0:
                 _lib.check(rc, h)
             self._steps_taken += 1
-        return launch
+        return launch_norm
 
     def kernel_variant(self, mode: str = "rollout") -> str:
         """Name of the kernel instantiation behind ``step`` ("step") or ``rollout`` ("rollout")."""

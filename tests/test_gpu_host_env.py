@@ -74,8 +74,9 @@ class _ReferenceRolloutLoop:
         return obs, rewards, dones
 
 
+@pytest.mark.parametrize("zero_copy", [True, False])
 @pytest.mark.parametrize("normalize", [True, False])
-def test_the_reference_trainers_rollout_lines_run_verbatim(normalize, capsys):
+def test_the_reference_trainers_rollout_lines_run_verbatim(normalize, zero_copy, capsys):
     import dataclasses
     import torch
     import evacuation_amd as ea
@@ -83,7 +84,9 @@ def test_the_reference_trainers_rollout_lines_run_verbatim(normalize, capsys):
     E, n, L, gamma, seed = 5, 24, 9, 0.97, 77
     cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=L, is_new_exiting_reward=True, is_new_followers_reward=True)
     wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
-    envs = ea.HostVectorEnv.make(cfg, wrap, num_envs=E, gamma=gamma, normalize=normalize, seed=seed)
+    # (zero_copy: the step kernel reads the pinned action buffer and writes the pinned output planes itself; False: staged copies)
+    envs = ea.HostVectorEnv.make(cfg, wrap, num_envs=E, gamma=gamma, normalize=normalize, seed=seed, zero_copy=zero_copy)
+    assert envs.zero_copy is zero_copy
     tcfg = _Cfg(num_steps=8, num_envs=E, num_updates=3, seed=1)
     rng = np.random.default_rng(5)
     T = tcfg.num_steps * tcfg.num_updates
@@ -135,6 +138,8 @@ def test_host_env_hands_out_copies_or_live_buffers():
     with pytest.raises(ValueError):
         a.step(np.zeros((4, 2), dtype=np.float32))
     a.close(); b.close()
+    with pytest.raises(RuntimeError, match="after close"):
+        a.step(acts)
 
 
 def test_step_cache_revalidates_shapes_and_returns_the_callers_tensors():
