@@ -569,8 +569,8 @@ def main(argv=None):
             raise SystemExit(f"bench.py: {dist.get_world_size()} ranks joined, --gpus {args.gpus} requested")
 
     import evacuation_amd as ea
-    from evacuation_amd.distributed import (DirectGather, PeerStoreGather, ShardedEvacuationEnv, all_gather_envs, pack_outputs,
-                                             peer_store_probe, side_stream)
+    from evacuation_amd.distributed import (DirectGather, PeerStoreGather, ShardedEvacuationEnv, agree_all, all_gather_envs,
+                                             pack_outputs, peer_store_probe, side_stream)
 
     cfg = ea.EnvConfig(number_of_pedestrians=n_ped, is_new_exiting_reward=True, is_new_followers_reward=True,
                        intrinsic_reward_coef=0.0, max_timesteps=EPISODE)       # SURVEY.md 8(d) synthetic inputs
@@ -617,10 +617,36 @@ def main(argv=None):
                     b["gsrc"] = torch.empty((t, E, GW), dtype=torch.float32, device=device)
                 if "direct" in forms:
                     b["direct"] = DirectGather(b["gsrc"], b["gathered"])     # peers' `gathered` buffers mapped through hipIpc
-                if "peer" in forms:
-                    b["peer"] = PeerStoreGather(b["slab"], D, b["gathered"])  # ... and written by one kernel, columns picked on the way
+                if "peer" in forms:                          # ... and written by one kernel, columns picked on the way
+                    b["peer"], perr = PeerStoreGather.try_build(b["slab"], D, b["gathered"],    # (all ranks: the gather, or the same error)
+                                                                 _inject_failure=os.environ.get("EVAC_BENCH_FAIL_PEER_BUILD") == str(rank))
+                    if perr:
+                        raise PeerFormUnavailable(perr)
             chunks[key] = b
         return b
+
+    class PeerFormUnavailable(RuntimeError):
+        """The peer-store gather cannot be built / failed its self-test -- on SOME rank; every rank raises it together."""
+
+    def without_peer_form(why):
+        """The peer-store form is out, on all ranks alike (`why` is the agreed first error): the alternative form of a line is a
+        diagnostic and simply goes; `--gather auto` falls back to RCCL -- before anything is timed --; an explicit `--gather peer` is a
+        hard error (returns False)."""
+        nonlocal form, alt_form
+        if form == "peer" and args.gather != "auto":
+            return False
+        if form == "peer":
+            form, alt_form = "obs", None
+            run["form"] = form
+            run["auto_fell_back"] = why
+        else:
+            alt_form = None
+            run["alternative_dropped"] = why
+        forms[:] = [form]
+        for b in chunks.values():
+            b.pop("peer", None)
+        chunks.clear()                                        # (rebuilt for the forms that are left)
+        return True
 
     step_actions = torch.rand((E, 2), device=device) * 2 - 1
 
@@ -715,27 +741,44 @@ def main(argv=None):
     # Then the collective is exercised once before anything is timed.  A collective that fails is a hard error: an N-GPU value
     # without the gather traffic is not the benchmark (use --no-gather to measure independent shards on purpose).
     all_sizes = sorted(set(sizes) | ({min(inner, W - d) for d in range(0, W, inner)} if W > 0 else set()))
-    try:
-        if args.mode == "rollout":
-            for t_ in all_sizes:
-                for par_ in range(nbuf):
-                    chunk_bufs(t_, par_)
-        if gather_rollout:
-            b0 = chunk_bufs(sizes[0], 0)
-            for f_ in forms:
-                if f_ == "direct":
-                    b0["direct"].issue(torch.cuda.current_stream())
-                    b0["direct"].self_test()
-                elif f_ == "peer":
-                    b0["peer"].self_test()
-                else:
-                    all_gather_envs(b0["slab"] if f_ == "slab" else b0["gsrc"], out=b0["gathered"])
-                torch.cuda.synchronize()
-    except Exception as exc:  # noqa: BLE001
-        if not gather_rollout:
-            raise
-        raise SystemExit(f"bench.py: rank {rank}: the all-gather failed ({type(exc).__name__}: {exc}); no {world}-GPU result "
-                         f"(--no-gather measures independent shards)") from exc
+    while True:
+        try:
+            if args.mode == "rollout":
+                for t_ in all_sizes:
+                    for par_ in range(nbuf):
+                        chunk_bufs(t_, par_)
+            if gather_rollout:
+                b0 = chunk_bufs(sizes[0], 0)
+                for f_ in list(forms):
+                    # every form's first gather ends with an agreement over the host: a rank whose gather failed does not
+                    # leave the others waiting in the warm-up's collectives
+                    err = None
+                    try:
+                        if f_ == "direct":
+                            b0["direct"].issue(torch.cuda.current_stream())
+                            b0["direct"].self_test()
+                        elif f_ == "peer":
+                            b0["peer"].self_test()
+                        else:
+                            all_gather_envs(b0["slab"] if f_ == "slab" else b0["gsrc"], out=b0["gathered"])
+                        torch.cuda.synchronize()
+                    except Exception as exc:  # noqa: BLE001
+                        err = f"{type(exc).__name__}: {exc}"
+                    bad = agree_all(err)
+                    if bad and f_ == "peer":
+                        raise PeerFormUnavailable(bad)
+                    if bad:
+                        raise RuntimeError(bad)
+            break
+        except PeerFormUnavailable as exc:
+            if without_peer_form(str(exc)):
+                continue                                      # build again without it (nothing has been timed yet)
+            raise SystemExit(f"bench.py: rank {rank}: --gather peer: {exc}; no {world}-GPU result (--gather auto falls back to RCCL)") from exc
+        except Exception as exc:  # noqa: BLE001
+            if not gather_rollout:
+                raise
+            raise SystemExit(f"bench.py: rank {rank}: the all-gather failed ({type(exc).__name__}: {exc}); no {world}-GPU result "
+                             f"(--no-gather measures independent shards)") from exc
 
     # With gathers the COMM stream is torch's current stream from here to the end of the timed parts (the launches are bound to
     # `compute`): the collectives and the column copies then need no stream switch per chunk.
@@ -825,6 +868,10 @@ def main(argv=None):
         return wall_, ref.elapsed_time(e1) * 1e-3, chunks_
 
     gather_runs = {}
+    if gather_rollout and rank == 0:
+        # (should a diagnostic below take the process down, the measurement is in the log at least)
+        print(f"bench.py: headline sweeps done ({form}): {total_envs * steps_per_sweep / sweep_s:.6g} env-steps/s over {world} rank(s), "
+              f"sweeps {[round(x * 1e3, 3) for x in sweep_wall]} ms; the gather diagnostics follow", file=sys.stderr, flush=True)
     if gather_rollout:
         for f_ in forms:
             run["form"] = f_
@@ -931,6 +978,7 @@ def main(argv=None):
         dist.all_gather_object(everyone, mine)
         gather_info = {"timed_form": form, "requested": args.gather, "alternative_form": alt_form, "peer_store_probe": probe,
                        "schedule": args.gather_schedule, "per_rank": everyone,
+                       "auto_fell_back": run.get("auto_fell_back"), "alternative_dropped": run.get("alternative_dropped"),
                        "note": "per rank, from one instrumented sweep per form (timing event pairs around every launch and every gather; "
                                "not the headline sweeps): gather_ms_alone = one chunk's gather on an idle device; "
                                "gather_ms_under_compute / launch_ms_with_gather = the same gather under the next chunk's launch and "

@@ -175,6 +175,16 @@ class DirectGather:
             raise RuntimeError(f"DirectGather self-test failed on rank {self.rank}: got {got.tolist()}, expected {want.tolist()}")
 
 
+def agree_all(err, group=None) -> Optional[str]:
+    """Every rank hands in what went wrong locally (or None); every rank gets back the first failure ANYWHERE (None: all fine).
+    One host-side ``all_gather_object``: a rank that failed still takes part, so nobody is left waiting in a collective."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    errs = [None] * world
+    dist.all_gather_object(errs, None if err is None else f"rank {rank}: {err}"[:240], group=group)
+    bad = [e for e in errs if e is not None]
+    return bad[0] if bad else None
+
+
 def _exchange_handles(gathered: torch.Tensor, group=None):
     """hipIpc handles of every rank's `gathered` buffer (PyTorch's CUDA-IPC tensor sharing), by rank."""
     from torch.multiprocessing.reductions import reduce_tensor
@@ -307,6 +317,41 @@ class PeerStoreGather:
         self._ptrs = (C.c_void_p * self.world)(*[p.data_ptr() for p in self.peers])
         self._src = C.c_void_p(slab.data_ptr())
         self._C = C
+
+    @classmethod
+    def try_build(cls, slab: torch.Tensor, take_words: int, gathered: torch.Tensor, group=None, wgs_per_peer: int = 8, _inject_failure: bool = False):
+        """``(gather, None)`` on every rank, or ``(None, first error anywhere)`` on every rank: the constructor in stages (handles
+        made and exchanged, peers' buffers opened, peer access enabled), each closed by ``agree_all`` -- a rank whose
+        hipIpcGetMemHandle / hipIpcOpenMemHandle / hipDeviceEnablePeerAccess fails does not leave the others in a collective.
+        For callers that have another way to gather (bench.py: the alternative form of a line; ``--gather auto``)."""
+        from torch.multiprocessing.reductions import reduce_tensor
+        world = dist.get_world_size(group)
+        err, mine, peers = None, None, None
+        try:
+            if _inject_failure:                  # (testing aid: this rank cannot export its buffer)
+                raise RuntimeError("injected failure (hipIpcGetMemHandle)")
+            mine = reduce_tensor(gathered)
+        except Exception as exc:  # noqa: BLE001
+            err = f"{type(exc).__name__}: {exc}"
+        handles = [None] * world
+        dist.all_gather_object(handles, mine, group=group)
+        bad = agree_all(err, group)
+        if bad:
+            return None, bad
+        try:
+            peers = _open_handles(handles, gathered, group)
+            _enable_peer_access(slab.device.index, {p.device.index for p in peers})
+        except Exception as exc:  # noqa: BLE001
+            err = f"{type(exc).__name__}: {exc}"
+        bad = agree_all(err, group)             # (also the barrier: every rank has mapped every buffer before anybody writes)
+        if bad:
+            return None, bad
+        try:
+            g = cls(slab, take_words, gathered, group=group, wgs_per_peer=wgs_per_peer, _mapped=(peers, handles))
+        except Exception as exc:  # noqa: BLE001
+            g, err = None, f"{type(exc).__name__}: {exc}"
+        bad = agree_all(err, group)
+        return (None, bad) if bad else (g, None)
 
     def issue(self, stream=None) -> None:
         # (evac_peer_gather takes no handle and launches on the CURRENT device: make it the slab's, whatever the caller has current)

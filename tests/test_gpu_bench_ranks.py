@@ -15,14 +15,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, timeout=600):
+def _run(extra, timeout=600, env_extra=None, expect_rc0=True):
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update(EVAC_BENCH_FORCE_DEVICE="0", EVAC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(env_extra or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--blocks", "6",
                         "--envs", "512", "--no-step-api"] + extra, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+    if not expect_rc0:
+        assert r.returncode != 0
+        return r.stderr
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -48,3 +52,22 @@ def test_two_ranks_on_one_gpu(extra):
     assert d["config"]["launches_per_block"] == (2 if "split" in extra else 1)
     assert "all-gather" in d["config"]["parallelism"]
     assert d["roofline"]["frac"] > 0
+
+
+def test_a_rank_that_cannot_build_the_peer_form_takes_nobody_down():
+    """The peer-store gather is built in stages that every rank closes with an agreement over the host: when ONE rank cannot
+    export its buffer (injected), the alternative form of a line is dropped, `--gather auto` falls back to RCCL's form before
+    anything is timed, and an explicit `--gather peer` is a hard error on every rank -- no rank is left waiting in a collective."""
+    fail = {"EVAC_BENCH_FAIL_PEER_BUILD": "1"}
+    d = _run([], env_extra=fail)                                     # default: RCCL's form timed, the peer form its alternative
+    rep = d["gather_report"]
+    assert rep["timed_form"] == "obs" and rep["alternative_form"] is None and "alternative_value" not in rep
+    assert "rank 1" in rep["alternative_dropped"] and "injected" in rep["alternative_dropped"] and rep["auto_fell_back"] is None
+    assert d["value"] > 0 and d["config"]["ranks_joined"] == 2
+    d = _run(["--gather", "auto"], env_extra=fail)
+    rep = d["gather_report"]
+    assert rep["peer_store_probe"]["ok"] is True                     # (the probe passed: it is the build of the real buffers that failed)
+    assert rep["timed_form"] == "obs" == d["config"]["gather"] and "rank 1" in rep["auto_fell_back"]
+    assert d["value"] > 0
+    err = _run(["--gather", "peer"], env_extra=fail, expect_rc0=False, timeout=300)
+    assert "--gather peer" in err and "injected" in err
