@@ -801,6 +801,18 @@ int evac_debug_step_times(unsigned long long* out2048) {
     return EVAC_OK;
 }
 #endif
+#ifdef EVAC_STEP_TIMES
+int evac_debug_launch_marks(unsigned long long* out8192) {
+    if (hipMemcpyFromSymbol(out8192, HIP_SYMBOL(g_launch_marks), 64 * 2 * 16 * 8 * sizeof(unsigned long long)) != hipSuccess) return EVAC_ERR_HIP;
+    return EVAC_OK;
+}
+#endif
+#ifdef EVAC_STEP_TIMES
+int evac_debug_launch_span(unsigned long long* out32768) {
+    if (hipMemcpyFromSymbol(out32768, HIP_SYMBOL(g_launch_span), 64 * 256 * 2 * sizeof(unsigned long long)) != hipSuccess) return EVAC_ERR_HIP;
+    return EVAC_OK;
+}
+#endif
 #ifdef EVAC_STAMP_WAVES
 int evac_debug_stamp_block(int block, unsigned long long* slowest) {      // set the reporting workgroup; read and clear the slowest-workgroup word
     unsigned long long z = 0;

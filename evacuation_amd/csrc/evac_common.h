@@ -32,7 +32,14 @@
 // workgroup 0 -- how the waves of one CU progress through a launch.  (Separate from EVAC_STAMP: the phase stamps end every wave
 // with atomics on 16 shared words, which stall the waves still running and distort exactly this picture.)
 #ifdef EVAC_STEP_TIMES
+#ifndef EVAC_STEP_TIMES_BLOCK
+#define EVAC_STEP_TIMES_BLOCK 0      // (the workgroup whose waves are stamped)
+#endif
 __device__ unsigned long long g_step_times[16][128];
+// ... and, for the waves of workgroups 0 and 100, the 100 MHz clock at kernel entry / at the top of the first step / after the last step /
+// in front of the state write-back (+ four marks inside the prologue), for the last 64 launches (tools/launch_edges.py: what a launch boundary is made of)
+__device__ unsigned long long g_launch_marks[64][2][16][8];
+__device__ unsigned long long g_launch_span[64][256][2];      // ... and entry / exit of wave 0 of EVERY workgroup: the true kernel boundary
 #endif
 #ifdef EVAC_STAMP
 __device__ unsigned long long g_stamps[16];

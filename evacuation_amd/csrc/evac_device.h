@@ -569,12 +569,24 @@ __device__ __forceinline__ void rollout_body(
     float* __restrict__ slab_out, evac_episode_stats_t* __restrict__ final_stats, int capture_envs,
     float* __restrict__ capture, const float* __restrict__ noise_in, const int* __restrict__ perm = nullptr,
     int* __restrict__ moving_out = nullptr, const int* __restrict__ deal_loads = nullptr, int* __restrict__ deal_perm = nullptr) {
+#ifdef EVAC_STEP_TIMES
+    unsigned long long mark_entry_, mark_loop_ = 0, mark_done_, mark_perm_, mark_init_, mark_act_, mark_state_;
+#define EVAC_MARK(M) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(M)::"memory")
+    EVAC_MARK(mark_entry_);
+#endif
     typename F::Ctx w(sm);
     if (w.env >= p.n_envs) return;
     // the schedule of the CU-wide workgroups: which env this wave carries; any permutation gives the same results
     const int my_slot = w.env;
     if (perm) w.env = __builtin_amdgcn_readfirstlane(perm[w.env]);
+#ifdef EVAC_STEP_TIMES
+    asm volatile("" ::"s"(w.env));
+    EVAC_MARK(mark_perm_);
+#endif
     F::init(w);
+#ifdef EVAC_STEP_TIMES
+    EVAC_MARK(mark_init_);
+#endif
     const bool active = w.i < p.n_ped;
     Ped q;
     Env e;
@@ -620,11 +632,18 @@ __device__ __forceinline__ void rollout_body(
         lane_adir = agent_direction(p, lane_act.x, lane_act.y);
     };
     draw_actions(0);
+#ifdef EVAC_STEP_TIMES
+    asm volatile("" ::"v"(lane_adir.x), "v"(lane_adir.y));
+    EVAC_MARK(mark_act_);
+#endif
     // flush mapping of the staged outputs: lane l carries word l % 9 of staged step l / 9
     const int fl_s = w.lane / kGravRow, fl_k = w.lane - fl_s * kGravRow;
     // Retire the state loads HERE, or their first use inside the loop puts `s_waitcnt vmcnt(0)` -- which
     // also waits for the previous step's stores -- into every iteration.
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
+#ifdef EVAC_STEP_TIMES
+    EVAC_MARK(mark_state_);
+#endif
     // (the wave's place among its SIMD-mates: recomputed where it is used rather than held in two more scalar registers)
 #define EVAC_PACE_SIMD (F::WPE == 1 ? (w.slot & 3) : (w.wave_in_env & 3))
 #define EVAC_PACE_K (F::WPE == 1 ? (w.slot >> 2) : w.slot)
@@ -664,11 +683,12 @@ __device__ __forceinline__ void rollout_body(
     constexpr int kStageRowBytes = (int)sizeof(sm.stage[0][0]);
     for (int t = 0; t < n_steps; ++t) {
 #ifdef EVAC_STEP_TIMES
-        if (w.lane == 0 && t < 128 && blockIdx.x == 0 && threadIdx.x < 1024) {
+        if (w.lane == 0 && t < 128 && blockIdx.x == EVAC_STEP_TIMES_BLOCK && threadIdx.x < 1024) {
             unsigned long long now_;
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");
             g_step_times[threadIdx.x >> 6][t] = now_;
         }
+        if (t == 0) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mark_loop_)::"memory");
 #endif
         if constexpr (kRotate) {
             if (p.fair) {
@@ -825,6 +845,9 @@ __device__ __forceinline__ void rollout_body(
         atomicMax(&g_stamps[11], ~0ull - (rt1_ - rt0_));
     }
 #endif
+#ifdef EVAC_STEP_TIMES
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mark_done_)::"memory");
+#endif
     if constexpr (F::kEnvBarrier) {               // (multi-wave envs: the load is the column count the last reduction delivered)
         if (moving_out && w.owner) moving_out[w.env] = w.have_next ? w.next_cols : p.n_ped;
     }
@@ -838,6 +861,28 @@ __device__ __forceinline__ void rollout_body(
         if (F::aborted(w)) return;      // a team that lost a member: void results, the env keeps its pre-launch state
     }
     store_env(p, w.env, w.i, active, w.owner, q, e);
+#ifdef EVAC_STEP_TIMES
+    if (w.lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && threadIdx.x < 1024 && n_steps > 0) {
+        unsigned long long mark_exit_;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mark_exit_)::"memory");   // (the state stores have left)
+        unsigned long long* m = g_launch_marks[((e.total - 1u) / (uint32_t)n_steps) & 63][blockIdx.x == 0 ? 0 : 1][threadIdx.x >> 6];
+        m[0] = mark_entry_;
+        m[1] = mark_loop_;
+        m[2] = mark_done_;
+        m[3] = mark_exit_;
+        m[4] = mark_perm_;
+        m[5] = mark_init_;
+        m[6] = mark_act_;
+        m[7] = mark_state_;
+    }
+    if (threadIdx.x == 0 && blockIdx.x < 256 && n_steps > 0) {
+        unsigned long long mark_exit_;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mark_exit_)::"memory");
+        unsigned long long* m = g_launch_span[((e.total - 1u) / (uint32_t)n_steps) & 63][blockIdx.x];
+        m[0] = mark_entry_;
+        m[1] = mark_exit_;
+    }
+#endif
 }
 
 template <class F, bool GRAV>

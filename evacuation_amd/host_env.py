@@ -22,6 +22,7 @@ no copy calls, one pre-bound launch.  Like SyncVectorEnv the returned arrays are
 from __future__ import annotations
 
 import dataclasses
+import sys
 from typing import Optional
 
 import numpy as np
@@ -77,6 +78,7 @@ class HostVectorEnv:
                 norm = (env.norm_state, env.gamma, env.obs_clip, env.reward_clip, env.epsilon)
             self._launch = base.step_launcher(self._h_act, out_obs=self._p_obs, out_reward=self._p_reward, out_terminated=self._p_term,
                                               out_truncated=self._p_trunc, _norm=norm, _allow_host=True)
+        self._pools, self._pool_next = [[None] * self._POOL for _ in range(4)], [0, 0, 0, 0]
         self._reward = np.zeros((E,), dtype=np.float64)            # SyncVectorEnv's buffer dtypes
         self._term = np.zeros((E,), dtype=np.bool_)
         self._trunc = np.zeros((E,), dtype=np.bool_)
@@ -90,6 +92,21 @@ class HostVectorEnv:
             return cls(NormalizedVectorEnv.make(env_config, wrap_config, num_envs=num_envs, gamma=gamma, **kw), copy=copy, zero_copy=zero_copy)
         cfg = dataclasses.replace(env_config, clip_action=True)
         return cls(BatchedEvacuationEnv(cfg, wrap_config, num_envs=num_envs, autoreset=True, **kw), copy=copy, zero_copy=zero_copy)
+
+    # ``copy=True`` hands out arrays the caller may keep.  A FRESH 147 KB observation array per step (4096 envs) is an mmap, three
+    # dozen page faults and a munmap whenever the C library's heap is not in the mood to recycle the block -- per process, by luck:
+    # whole runs at 34 us per step and whole runs at 70-100 (profiles/r05_i_host_vector_env_zero_copy.txt).  So the arrays come from
+    # a small pool, and an array goes out again only when NOBODY holds it any more (its reference count is back to the pool's own:
+    # views, ``torch.from_numpy`` tensors and slices all hold the base array); otherwise a new one takes its slot.
+    _POOL = 4
+
+    def _fresh(self, kind: int, shape, dtype):
+        pool = self._pools[kind]
+        i = self._pool_next[kind] = (self._pool_next[kind] + 1) % self._POOL
+        a = pool[i]
+        if a is None or sys.getrefcount(a) != 3:          # (3 = the pool's slot + the local name + getrefcount's argument)
+            a = pool[i] = np.empty(shape, dtype=dtype)
+        return a
 
     @staticmethod
     def _device_sees(t: torch.Tensor) -> bool:
@@ -142,10 +159,16 @@ class HostVectorEnv:
             b = self._base
             infos = StepInfos(b, self._p_term, self._p_trunc, final_observation=b.final_obs, episode_stats=b.final_stats) if b.autoreset else {}
             if self.copy:                                             # ONE copy of each output: pinned buffer -> the array handed out
-                term, trunc = self._np_term != 0, self._np_trunc != 0
+                E, D = self.num_envs, self.obs_dim
+                obs, rew = self._fresh(0, (E, D), np.float32), self._fresh(1, (E,), np.float64)
+                term, trunc = self._fresh(2, (E,), np.bool_), self._fresh(3, (E,), np.bool_)
+                np.copyto(obs, self._np_obs)
+                np.copyto(rew, self._np_reward)                       # float32 -> float64, exact
+                np.not_equal(self._np_term, 0, out=term)
+                np.not_equal(self._np_trunc, 0, out=trunc)
                 if b.autoreset:
                     infos._done = term | trunc
-                return self._np_obs.copy(), self._np_reward.astype(np.float64), term, trunc, infos
+                return obs, rew, term, trunc, infos
             np.copyto(self._reward, self._np_reward)                  # float32 -> float64, exact
             np.not_equal(self._np_term, 0, out=self._term)
             np.not_equal(self._np_trunc, 0, out=self._trunc)
@@ -159,7 +182,11 @@ class HostVectorEnv:
         if hasattr(infos, "_done"):                                   # the lazy final_info list: the flags are on the host already
             infos._done = np.logical_or(self._term, self._trunc)
         if self.copy:
-            return self._obs.copy(), self._reward.copy(), self._term.copy(), self._trunc.copy(), infos
+            E, D = self.num_envs, self.obs_dim
+            obs, rew = self._fresh(0, (E, D), np.float32), self._fresh(1, (E,), np.float64)
+            term, trunc = self._fresh(2, (E,), np.bool_), self._fresh(3, (E,), np.bool_)
+            np.copyto(obs, self._obs); np.copyto(rew, self._reward); np.copyto(term, self._term); np.copyto(trunc, self._trunc)
+            return obs, rew, term, trunc, infos
         return self._obs, self._reward, self._term, self._trunc, infos
 
     def close(self):

@@ -142,6 +142,41 @@ def test_host_env_hands_out_copies_or_live_buffers():
         a.step(acts)
 
 
+@pytest.mark.parametrize("zero_copy", [True, False])
+def test_arrays_handed_out_are_never_overwritten_while_somebody_holds_them(zero_copy):
+    """copy=True recycles its output arrays from a small pool -- only those that nobody references any more (a kept array, a view of
+    it or a torch tensor made from it keeps it out of circulation)."""
+    import torch
+    import evacuation_amd as ea
+    cfg = ea.EnvConfig(number_of_pedestrians=12, max_timesteps=7)
+    h = ea.HostVectorEnv.make(cfg, ea.EnvWrappersConfig(positions="grav"), num_envs=5, seed=4, zero_copy=zero_copy)
+    h.reset()
+    rng = np.random.default_rng(1)
+    kept, snapshots, ids = [], [], set()
+    for t in range(24):
+        out = h.step(rng.uniform(-1, 1, (5, 2)).astype(np.float32))[:4]
+        ids.add(id(out[0]))
+        if t % 3 == 0:
+            kept.append(out)                                              # the arrays themselves
+        elif t % 3 == 1:
+            kept.append((out[0][1:3], torch.from_numpy(out[1]), out[2][:2], out[3].view(np.uint8)))   # views / tensors of them only
+        else:
+            kept.append(None)                                             # dropped: these may be recycled
+        snapshots.append(tuple(np.array(x, copy=True) for x in out))
+    for t, k in enumerate(kept):
+        if k is None:
+            continue
+        o, r, te, tr = snapshots[t]
+        if t % 3 == 0:
+            for a, b in zip(k, (o, r, te, tr)):
+                np.testing.assert_array_equal(a, b)
+        else:
+            np.testing.assert_array_equal(k[0], o[1:3]); np.testing.assert_array_equal(k[1].numpy(), r)
+            np.testing.assert_array_equal(k[2], te[:2]); np.testing.assert_array_equal(k[3], tr.view(np.uint8))
+    assert len(ids) < 24                                                  # (and the dropped ones DID come back)
+    h.close()
+
+
 def test_step_cache_revalidates_shapes_and_returns_the_callers_tensors():
     """BatchedEvacuationEnv.step binds its ctypes call per set of buffer addresses: a second call with the same storage rows
     takes the cached path (same results as a fresh env stepping uncached), a tensor of another shape at a cached address is

@@ -67,8 +67,30 @@ def flag_wait_experiment(E=4096):
     h.close()
 
 
+def distribution(E=4096, n=3000):
+    """Per-step wall time of HostVectorEnv.step() (the distribution, not only the mean)."""
+    cfg = ea.EnvConfig(number_of_pedestrians=60)
+    act = np.random.default_rng(0).uniform(-1, 1, (E, 2)).astype(np.float32)
+    for zero_copy in (True, False, True, False):
+        h = ea.HostVectorEnv.make(cfg, ea.EnvWrappersConfig(positions="grav"), num_envs=E, normalize=False, seed=3, zero_copy=zero_copy)
+        h.reset()
+        for _ in range(100):
+            h.step(act)
+        t = np.zeros(n)
+        for i in range(n):
+            t0 = time.perf_counter()
+            h.step(act)
+            t[i] = time.perf_counter() - t0
+        t *= 1e6
+        print(f"zero_copy={zero_copy!s:5}  mean {t.mean():6.1f}  median {np.median(t):6.1f}  p90 {np.percentile(t, 90):6.1f}  p99 {np.percentile(t, 99):6.1f}  "
+              f"max {t.max():7.1f} us", flush=True)
+        h.close()
+
+
 if __name__ == "__main__":
-    if "--flag" in sys.argv:
+    if "--dist" in sys.argv:
+        distribution()
+    elif "--flag" in sys.argv:
         flag_wait_experiment()
     else:
         main()
