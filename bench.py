@@ -1252,7 +1252,8 @@ def dry_run(args, rank, world, total_envs, envs_per_gpu, K, W, inner, per_sweep,
         mine = {"rank": rank, form: gather_report(form, world, min(sizes[0], 4) * n_local * 9 * 4, [], chunks, None)}
         everyone = [None] * world
         dist.all_gather_object(everyone, mine)
-        report = {"timed_form": form, "requested": args.gather, "alternative_form": alt_form, "peer_store_probe": probe, "per_rank": everyone}
+        report = {"timed_form": form, "requested": args.gather, "alternative_form": alt_form, "peer_store_probe": probe, "per_rank": everyone,
+                  "auto_fell_back": None, "alternative_dropped": None}     # (the keys of the real line: no peer form is built in a dry run)
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "gather_report": report, "ranks_joined": dist.get_world_size() if world > 1 else 1,
                           "steps": K, "warmup": W, "total_envs": total_envs, "envs_per_gpu": envs_per_gpu,

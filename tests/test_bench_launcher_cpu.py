@@ -41,6 +41,7 @@ def test_the_multi_rank_line_carries_every_ranks_account_of_the_gather():
     rep = json_lines(r.stdout)[0]["gather_report"]
     assert rep["requested"] == "auto" and rep["timed_form"] == "obs" and rep["alternative_form"] is None
     assert rep["peer_store_probe"]["ok"] is False and rep["peer_store_probe"]["stage"] == "skipped"
+    assert rep["auto_fell_back"] is None and rep["alternative_dropped"] is None       # (keys of the real line; nothing was built here)
     assert [x["rank"] for x in rep["per_rank"]] == [0, 1]
     for x in rep["per_rank"]:
         mine = x["obs"]
