@@ -499,9 +499,73 @@ def side_workload(name: str, mode: str, inner: int, sweeps: int, device, traffic
     }
 
 
+def split_batch_workload(sweeps: int, device, inner: int = 20, parts: int = 2):
+    """The HEADLINE batch (C2: N = 60 x 4096 envs, the driver's 20 steps per launch) as `parts` independent handles on streams of
+    their own (evacuation_amd.SplitBatchEnv: the same global env ids, bit-identical trajectories): whole episode sweeps, launches
+    back to back, the host clock between two device synchronisations.  A side figure, not the headline: the headline prices ONE
+    kernel per launch on ONE stream (the C ABI's contract); here two kernels run concurrently per round, so the entry gives the
+    device-level figure (the batch's algorithmic bytes per round / the round's time) next to each part's own kernel time."""
+    import statistics
+
+    import torch
+
+    import evacuation_amd as ea
+
+    n_ped, E, wrap_kw, desc = WORKLOADS["c2"]
+    cfg = ea.EnvConfig(number_of_pedestrians=n_ped, is_new_exiting_reward=True, is_new_followers_reward=True,
+                       intrinsic_reward_coef=0.0, max_timesteps=EPISODE)
+    env = ea.SplitBatchEnv(cfg, ea.EnvWrappersConfig(**wrap_kw), num_envs=E, parts=parts, device=device, seed=0x5EED0000 + sorted(WORKLOADS).index("c2"))
+    env.reset()
+    launch, _outs = env.rollout_launcher(inner)
+    rounds = EPISODE // inner
+    for _ in range(max(1, 200 // inner)):
+        launch()
+    torch.cuda.synchronize()
+    wall, part_ms = [], [[] for _ in range(parts)]
+    for _ in range(sweeps):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(parts)]
+        t0 = time.perf_counter()
+        for (a, _b), s in zip(ev, env.streams):
+            a.record(s)
+        for _ in range(rounds):
+            launch()
+        for (_a, b), s in zip(ev, env.streams):
+            b.record(s)
+        torch.cuda.synchronize()
+        wall.append(time.perf_counter() - t0)
+        for k, (a, b) in enumerate(ev):
+            part_ms[k].append(a.elapsed_time(b) / rounds)
+    sweep_s = statistics.median(wall)
+    value = E / (sweep_s / EPISODE)
+    bytes_per_env_step = env.parts[0].algorithmic_bytes_per_env_step
+    round_s = sweep_s / rounds
+    achieved = bytes_per_env_step * E * inner / round_s / 1e9
+    variant = env.kernel_variant("rollout")
+    env.close()
+    return {
+        "workload": desc + f" -- as {parts} independent handles of {E // parts} envs on {parts} streams (SplitBatchEnv)", "mode": "rollout", "envs": E,
+        "parts": parts, "steps_per_launch": inner, "value": value, "unit": "env-steps/s", "ms_per_step": sweep_s / EPISODE * 1e3,
+        "sweeps": {"timed": sweeps, "rounds_per_sweep": rounds, "wall_ms": [x * 1e3 for x in wall],
+                   "value_min_median_max": [E * EPISODE / max(wall), value, E * EPISODE / min(wall)]},
+        "kernel": variant, "kernels_in_flight": parts, "round_ms": round_s * 1e3,
+        "part_kernel_ms_per_launch": [statistics.median(x) for x in part_ms],
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "algorithmic_bytes_per_env_step": bytes_per_env_step, "equivalent_bandwidth": True,
+                     "note": "device level: the whole batch's algorithmic bytes per round of launches / the round's time (host clock over the "
+                             "sweep); each of the concurrent kernels moves 1 / parts of them in part_kernel_ms_per_launch"},
+        "note": "not the headline: the same envs and trajectories, launched as concurrent kernels on streams the env object owns",
+    }
+
+
 def side_workloads(args, device):
     """`workloads` of the default line: each entry measured as side_workload() says; an entry that fails carries the error."""
     out = {}
+    try:
+        out["c2_two_streams"] = split_batch_workload(args.side_sweeps, device)
+    except SystemExit:
+        raise
+    except Exception as exc:  # noqa: BLE001
+        out["c2_two_streams"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     for key, name, mode, inner in SIDE_WORKLOADS:
         try:
             out[key] = side_workload(name, mode, inner, args.side_sweeps, device, args.traffic_json)

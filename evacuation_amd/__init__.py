@@ -2,13 +2,13 @@
 
 Public surface = the reference's ``src.env`` exports (src/env/__init__.py:3-21):
 ``setup_env, EvacuationEnv, EnvConfig, EnvWrappersConfig, Status`` plus the batched form
-``BatchedEvacuationEnv``, its SyncVectorEnv-shaped host face ``HostVectorEnv`` and the sharded form ``ShardedEvacuationEnv``.  Importing the package does
+``BatchedEvacuationEnv``, its SyncVectorEnv-shaped host face ``HostVectorEnv``, the sharded form ``ShardedEvacuationEnv`` (across GPUs) and ``SplitBatchEnv`` (across streams of one GPU).  Importing the package does
 not touch the GPU; constructing an env loads libevac.so and fails loudly without it."""
 from .config import EnvConfig, EnvWrappersConfig
 from .statuses import Status
 
 __all__ = ["EnvConfig", "EnvWrappersConfig", "Status", "setup_env", "EvacuationEnv", "BatchedEvacuationEnv",
-           "ShardedEvacuationEnv", "NormalizedVectorEnv", "HostVectorEnv", "RandomAgent"]
+           "ShardedEvacuationEnv", "SplitBatchEnv", "NormalizedVectorEnv", "HostVectorEnv", "RandomAgent"]
 
 
 def __getattr__(name):   # lazy: keeps `import evacuation_amd` light and torch-free for config users
@@ -21,6 +21,9 @@ def __getattr__(name):   # lazy: keeps `import evacuation_amd` light and torch-f
     if name == "ShardedEvacuationEnv":
         from .distributed import ShardedEvacuationEnv
         return ShardedEvacuationEnv
+    if name == "SplitBatchEnv":
+        from .split_env import SplitBatchEnv
+        return SplitBatchEnv
     if name == "NormalizedVectorEnv":
         from .wrappers import NormalizedVectorEnv
         return NormalizedVectorEnv

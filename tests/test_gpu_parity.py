@@ -454,6 +454,37 @@ def test_sharded_handles_reproduce_single_handle(ea):
         assert (rw[k][:, :E // 2] == rl[k]).all() and (rw[k][:, E // 2:] == rh[k]).all(), k
 
 
+@pytest.mark.parametrize("parts,E,n", [(2, 64, 60), (4, 64, 60), (2, 8, 256)])
+def test_split_batch_equals_one_handle(ea, parts, E, n):
+    """SplitBatchEnv: one batch as `parts` independent handles on streams of their own (env_id_offset keys the random streams by
+    global env id): the concatenated outputs of several launches, an autoreset among them, equal the single handle's bit for bit."""
+    import torch
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=25, is_new_exiting_reward=True, is_new_followers_reward=True)
+    wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
+    whole = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=9)
+    split = ea.SplitBatchEnv(cfg, wrap, num_envs=E, parts=parts, seed=9)
+    assert len(split.parts) == parts and len({s.cuda_stream for s in split.streams}) == parts
+    whole.reset()
+    split.reset()
+    launch, outs = split.rollout_launcher(10)
+    for j in range(4):                                  # 40 steps: every env is truncated and reset once
+        ref = whole.rollout(10)
+        launch()
+        split.synchronize()
+        torch.cuda.synchronize()
+        got = torch.cat([o["slab"] for o in outs], dim=1)
+        assert torch.equal(got, ref["slab"]), f"launch {j}"
+        done = (ref["terminated"] != 0) | (ref["truncated"] != 0)           # (the records' rows are valid where an episode ended)
+        assert torch.equal(torch.cat([o["episode_stats"] for o in outs], dim=1)[done], ref["episode_stats"][done]), f"launch {j}: episode records"
+        assert j != 2 or bool(done.any())
+    one = split.rollout(5)                              # the convenience form: joined on the current stream, concatenated
+    assert torch.equal(one["slab"], whole.rollout(5)["slab"])
+    with pytest.raises(ValueError):
+        ea.SplitBatchEnv(cfg, wrap, num_envs=E + 1, parts=parts)
+    split.close()
+    whole.close()
+
+
 def test_full_size_invariants_c2(ea):
     """BASELINE config 2 (N=60 x 4096 envs, gravity obs): size-independent properties after a long
     on-device rollout -- walls, escaped pinned at the exit, status == classifier(position), step
