@@ -23,6 +23,10 @@ from .vector_env import BatchedEvacuationEnv
 
 
 class SplitBatchEnv:
+    """See the module docstring.  ``parts=2`` is the useful value on an MI355X: +3.4 % at 20 steps per launch, +3.9 % at 100; four or
+    eight parts lose half and more (HIP has four hardware queues: parts that share one take turns, and 64- / 32-workgroup launches
+    leave CUs idle -- profiles/r05_k_one_batch_as_two_halves_on_two_streams_probe.txt)."""
+
     def __init__(self, env_config, wrap_config=None, num_envs: int = 1, parts: int = 2, device=None, seed: int = 0, env_id_offset: int = 0,
                  cu_wide: Optional[bool] = True, **kw):
         from .distributed import side_stream
