@@ -94,7 +94,15 @@ def parse_args(argv=None):
     ap.add_argument("--no-side-workloads", action="store_true",
                     help="skip the short runs of BASELINE configs 3 and 5 (one GPU's shard) and of the 524 288-env per-step run that ride "
                          "along with the default C2 line as `workloads`")
-    ap.add_argument("--side-sweeps", type=int, default=5, help="episode sweeps per side workload (rollout mode)")
+    ap.add_argument("--side-sweeps", type=int, default=20,
+                    help="episode sweeps per side workload (rollout mode); their figure is the median of the LAST half (settled clocks)")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+                    help="after the headline sweeps keep running the same sweeps for this much GPU time (0: skip): `sustained` in the line, "
+                         "and `value` becomes the settled median when it differs from the headline sweeps' by more than 2 %%")
+    ap.add_argument("--rollout-form", default="auto", choices=["auto", "one", "parts"],
+                    help="how the handle issues a rollout (evac_options_t.parts): one = ONE kernel on the launching stream; parts = two "
+                         "half-batch kernels on two streams the handle owns (evac_join closes a sweep); auto = parts where the library "
+                         "says it pays, on a single GPU without gathers -- one otherwise")
     ap.add_argument("--no-gather", action="store_true", help="skip the all-gather of the outputs (N>1)")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the gather path -- process group, collective on the comm stream, double-buffered pipeline -- with "
@@ -427,10 +435,11 @@ SIDE_WORKLOADS = (
 )
 
 
-def side_workload(name: str, mode: str, inner: int, sweeps: int, device, traffic_json: str):
+def side_workload(name: str, mode: str, inner: int, sweeps: int, device, traffic_json: str, options=None):
     """One BASELINE config beside the headline: whole episode sweeps (2000 steps each, launches back to back, bracketed by
     torch.cuda.synchronize and two HIP events on the launching stream) of a fresh batch, after one untimed sweep's worth of
-    warm-up launches (200 steps).  Returns the entry of `workloads` in the bench line.  `value` = envs / (median sweep / 2000),
+    warm-up launches (200 steps).  Returns the entry of `workloads` in the bench line.  `value` = envs / (median of the LAST half of
+    the sweeps / 2000) -- the clocks settle over the first sweeps (C5 slowed 8.9 -> 10.5 ms per sweep over 200 ms) --,
     `roofline` as for the headline: ALGORITHMIC bytes per launch / the mean launch of the median sweep (HIP events), counter
     traffic from profiles/traffic.json under the same guard.  The per-step run of the 524 288-env batch (state 503 MB: every
     step reads and writes it through HBM) is timed over ONE episode sweep of evac_step launches."""
@@ -444,7 +453,7 @@ def side_workload(name: str, mode: str, inner: int, sweeps: int, device, traffic
     cfg = ea.EnvConfig(number_of_pedestrians=n_ped, is_new_exiting_reward=True, is_new_followers_reward=True,
                        intrinsic_reward_coef=0.0, max_timesteps=EPISODE)
     env = ea.BatchedEvacuationEnv(cfg, ea.EnvWrappersConfig(**wrap_kw), num_envs=E, device=device,
-                                  seed=0x5EED0000 + sorted(WORKLOADS).index(name))
+                                  seed=0x5EED0000 + sorted(WORKLOADS).index(name), options=options)
     env.reset()
     stream = torch.cuda.current_stream(device)
     if mode == "rollout":
@@ -467,14 +476,16 @@ def side_workload(name: str, mode: str, inner: int, sweeps: int, device, traffic
         e0.record(stream)
         for _ in range(launches):
             go()
+        env.join(stream)
         e1.record(stream)
         torch.cuda.synchronize()
         wall.append(time.perf_counter() - t0)
         dev.append(e0.elapsed_time(e1) * 1e-3)
     if env.team_error():
         raise SystemExit(f"bench.py: evac_team_error is set in side workload {name}; results discarded")
-    sweep_s = statistics.median(wall)
-    kernel_s = statistics.median(dev) / launches
+    settled = slice(len(wall) // 2, None)                      # the last half of the sweeps
+    sweep_s = statistics.median(wall[settled])
+    kernel_s = statistics.median(dev[settled]) / launches
     variant = env.kernel_variant(mode)
     tr = load_traffic(traffic_json, f"{name}:{mode}", variant, csrc_sha16())
     bytes_per_env_step = env.algorithmic_bytes_per_env_step
@@ -487,8 +498,10 @@ def side_workload(name: str, mode: str, inner: int, sweeps: int, device, traffic
         "workload": desc, "mode": mode, "envs": E, "n_pedestrians": n_ped, "steps_per_launch": inner,
         "value": value, "unit": "env-steps/s", "agent_updates_per_s": value * n_ped, "ms_per_step": sweep_s / EPISODE * 1e3,
         "sweeps": {"timed": sweeps, "launches_per_sweep": launches, "wall_ms": [x * 1e3 for x in wall], "hip_event_ms": [x * 1e3 for x in dev],
+                   "value_from": f"median of sweeps {len(wall) // 2}..{len(wall) - 1} (the last half)", "gpu_ms_timed_total": sum(dev) * 1e3,
+                   "value_first_half": E * EPISODE / statistics.median(wall[:max(1, len(wall) // 2)]),
                    "value_min_median_max": [E * EPISODE / max(wall), value, E * EPISODE / min(wall)]},
-        "kernel": variant, "kernel_ms_per_launch": kernel_s * 1e3,
+        "kernel": variant, "kernels_in_flight": env.num_parts, "kernel_ms_per_launch": kernel_s * 1e3,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": traffic, "traffic_source": tr["source"], "traffic_note": tr["note"],
                      "hbm_traffic_frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
@@ -499,73 +512,18 @@ def side_workload(name: str, mode: str, inner: int, sweeps: int, device, traffic
     }
 
 
-def split_batch_workload(sweeps: int, device, inner: int = 20, parts: int = 2):
-    """The HEADLINE batch (C2: N = 60 x 4096 envs, the driver's 20 steps per launch) as `parts` independent handles on streams of
-    their own (evacuation_amd.SplitBatchEnv: the same global env ids, bit-identical trajectories): whole episode sweeps, launches
-    back to back, the host clock between two device synchronisations.  A side figure, not the headline: the headline prices ONE
-    kernel per launch on ONE stream (the C ABI's contract); here two kernels run concurrently per round, so the entry gives the
-    device-level figure (the batch's algorithmic bytes per round / the round's time) next to each part's own kernel time."""
-    import statistics
-
-    import torch
-
-    import evacuation_amd as ea
-
-    n_ped, E, wrap_kw, desc = WORKLOADS["c2"]
-    cfg = ea.EnvConfig(number_of_pedestrians=n_ped, is_new_exiting_reward=True, is_new_followers_reward=True,
-                       intrinsic_reward_coef=0.0, max_timesteps=EPISODE)
-    env = ea.SplitBatchEnv(cfg, ea.EnvWrappersConfig(**wrap_kw), num_envs=E, parts=parts, device=device, seed=0x5EED0000 + sorted(WORKLOADS).index("c2"))
-    env.reset()
-    launch, _outs = env.rollout_launcher(inner)
-    rounds = EPISODE // inner
-    for _ in range(max(1, 200 // inner)):
-        launch()
-    torch.cuda.synchronize()
-    wall, part_ms = [], [[] for _ in range(parts)]
-    for _ in range(sweeps):
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(parts)]
-        t0 = time.perf_counter()
-        for (a, _b), s in zip(ev, env.streams):
-            a.record(s)
-        for _ in range(rounds):
-            launch()
-        for (_a, b), s in zip(ev, env.streams):
-            b.record(s)
-        torch.cuda.synchronize()
-        wall.append(time.perf_counter() - t0)
-        for k, (a, b) in enumerate(ev):
-            part_ms[k].append(a.elapsed_time(b) / rounds)
-    sweep_s = statistics.median(wall)
-    value = E / (sweep_s / EPISODE)
-    bytes_per_env_step = env.parts[0].algorithmic_bytes_per_env_step
-    round_s = sweep_s / rounds
-    achieved = bytes_per_env_step * E * inner / round_s / 1e9
-    variant = env.kernel_variant("rollout")
-    env.close()
-    return {
-        "workload": desc + f" -- as {parts} independent handles of {E // parts} envs on {parts} streams (SplitBatchEnv)", "mode": "rollout", "envs": E,
-        "parts": parts, "steps_per_launch": inner, "value": value, "unit": "env-steps/s", "ms_per_step": sweep_s / EPISODE * 1e3,
-        "sweeps": {"timed": sweeps, "rounds_per_sweep": rounds, "wall_ms": [x * 1e3 for x in wall],
-                   "value_min_median_max": [E * EPISODE / max(wall), value, E * EPISODE / min(wall)]},
-        "kernel": variant, "kernels_in_flight": parts, "round_ms": round_s * 1e3,
-        "part_kernel_ms_per_launch": [statistics.median(x) for x in part_ms],
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "algorithmic_bytes_per_env_step": bytes_per_env_step, "equivalent_bandwidth": True,
-                     "note": "device level: the whole batch's algorithmic bytes per round of launches / the round's time (host clock over the "
-                             "sweep); each of the concurrent kernels moves 1 / parts of them in part_kernel_ms_per_launch"},
-        "note": "not the headline: the same envs and trajectories, launched as concurrent kernels on streams the env object owns",
-    }
-
-
 def side_workloads(args, device):
     """`workloads` of the default line: each entry measured as side_workload() says; an entry that fails carries the error."""
+    import evacuation_amd as ea
     out = {}
-    try:
-        out["c2_two_streams"] = split_batch_workload(args.side_sweeps, device)
+    try:      # the headline batch, the driver's K steps per launch, issued as ONE kernel per rollout call (what rounds 1-5 timed)
+        out["c2_one_kernel"] = side_workload("c2", "rollout", max(1, min(args.inner, args.steps)), args.side_sweeps, device, args.traffic_json,
+                                             options=ea.KernelOptions(parts=1))
+        out["c2_one_kernel"]["note"] = "the headline's batch and launch shape with evac_options_t.parts = 1: one kernel per rollout call on the launching stream"
     except SystemExit:
         raise
     except Exception as exc:  # noqa: BLE001
-        out["c2_two_streams"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+        out["c2_one_kernel"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     for key, name, mode, inner in SIDE_WORKLOADS:
         try:
             out[key] = side_workload(name, mode, inner, args.side_sweeps, device, args.traffic_json)
@@ -640,7 +598,15 @@ def main(argv=None):
                        intrinsic_reward_coef=0.0, max_timesteps=EPISODE)       # SURVEY.md 8(d) synthetic inputs
     wrap = ea.EnvWrappersConfig(**wrap_kw)
     seed = 0x5EED0000 + sorted(WORKLOADS).index(args.workload)
-    env = ShardedEvacuationEnv(cfg, wrap, total_envs=total_envs, device=device, seed=seed)
+    # How a rollout is issued (evac_options_t.parts; results do not depend on it): with gathers the chunk pipeline orders its
+    # streams by events recorded behind ONE launch per chunk, so those runs keep one kernel per launch.
+    form_req = args.rollout_form
+    if form_req == "auto":
+        form_req = "parts_auto" if (world == 1 and not use_dist and args.mode == "rollout") else "one"
+    if form_req != "one" and use_dist and not args.no_gather:
+        raise SystemExit("bench.py: --rollout-form parts with gathers is not supported (the gather pipeline waits on one launch per chunk)")
+    kopts = ea.KernelOptions(parts={"one": 1, "parts": 2, "parts_auto": -1}[form_req])
+    env = ShardedEvacuationEnv(cfg, wrap, total_envs=total_envs, device=device, seed=seed, options=kopts)
     loc = env.local
     E, D = loc.num_envs, loc.obs_dim
     env.reset()
@@ -888,12 +854,42 @@ def main(argv=None):
         e0.record(compute)
         for b in range(per_sweep):
             pipe.run_block(sizes)                             # EXACTLY K steps (+ one gather per launch), nothing waited for
+        loc.join(compute)                                     # (two parts: `compute` waits for the handle's own streams; else a no-op)
         e1.record(compute)
         pipe.drain()                                          # this rank's compute AND gathers are done
         sweep_wall.append(time.perf_counter() - t0)           # local t1; no collective inside the timed region
         sweep_dev.append(e0.elapsed_time(e1) * 1e-3)
     pipe.flush()
     barrier()
+    # ---- steady state: the SAME sweeps again until --sustain-seconds of GPU time have passed.  The headline's
+    # eleven sweeps are ~50 ms; clocks and power settle over seconds.  All ranks run the same number of sweeps (from the max-over-ranks
+    # median above); nothing else changes: same brackets, same launches, same gathers.
+    sustain_wall, sustain_dev = [], []
+    if args.sustain_seconds > 0:
+        med0 = statistics.median(sweep_wall)
+        if use_dist:
+            tt = torch.tensor([med0], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            med0 = float(tt.item())
+        n_sus = max(10, min(4000, int(math.ceil(args.sustain_seconds / max(med0, 1e-6)))))
+        for sw in range(n_sus):
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record(compute)
+            for b in range(per_sweep):
+                pipe.run_block(sizes)
+            loc.join(compute)
+            e1.record(compute)
+            pipe.drain()
+            sustain_wall.append(time.perf_counter() - t0)
+            sustain_dev.append(e0.elapsed_time(e1) * 1e-3)
+        pipe.flush()
+        barrier()
+        if use_dist:
+            tt = torch.tensor(sustain_wall, dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sustain_wall = [float(x) for x in tt.tolist()]
     if use_dist:
         tt = torch.tensor(sweep_wall, dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)             # per sweep: the slowest rank
@@ -901,7 +897,34 @@ def main(argv=None):
     steps_per_sweep = per_sweep * K
     sweep_s = statistics.median(sweep_wall)
     kernel_s = statistics.median(sweep_dev) / launches_per_sweep      # mean launch of a sweep (kernel + the ~1.5 us launch boundary)
-    sweeps_run = sweeps
+    sweeps_run = sweeps + len(sustain_wall)
+    sustained = None
+    if sustain_wall:
+        allw, alld = sweep_wall + sustain_wall, sweep_dev + sustain_dev          # in the order they ran
+        cum, first, last = 0.0, [], []
+        total_dev = sum(alld)
+        for w_, d_ in zip(allw, alld):
+            if cum < 0.050:
+                first.append(w_)
+            if cum >= total_dev - 0.500:
+                last.append(w_)
+            cum += d_
+        v_first = total_envs * steps_per_sweep / statistics.median(first)
+        v_last = total_envs * steps_per_sweep / statistics.median(last)
+        sustained = {"gpu_seconds": total_dev, "sweeps": len(allw), "first_50ms": v_first, "last_500ms": v_last,
+                     "sweeps_in_first_50ms": len(first), "sweeps_in_last_500ms": len(last), "drift": v_last / v_first - 1.0,
+                     "last_500ms_min_max": [total_envs * steps_per_sweep / max(last), total_envs * steps_per_sweep / min(last)],
+                     "ms_per_sweep_every_50th": [round(x * 1e3, 4) for x in allw[::50]],
+                     "value_is_settled_median": False,
+                     "note": "the headline sweeps followed by the same sweeps until --sustain-seconds of GPU time: env-steps/s over the "
+                             "sweeps of the first 50 ms and of the last 500 ms of GPU time (medians), drift = last / first - 1"}
+        if abs(v_last / (total_envs * steps_per_sweep / sweep_s) - 1.0) > 0.02:
+            # the settled figure is the one that holds: `value`, `ms_per_step` and the roofline's launch time are taken from it
+            sustained["value_is_settled_median"] = True
+            sustained["value_of_the_headline_sweeps"] = total_envs * steps_per_sweep / sweep_s
+            k = len(last)
+            sweep_s = statistics.median(last)
+            kernel_s = statistics.median(alld[-k:]) / launches_per_sweep
 
     # ---- the gather explains itself (N > 1, or --force-gather): one INSTRUMENTED sweep per form -- a timing event pair around
     # every launch (compute stream) and around every gather (comm stream) --, and two plain sweeps of the alternative form.
@@ -1006,6 +1029,7 @@ def main(argv=None):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
             replay_launch(t)
+            loc.join()                                        # (two parts: the pair brackets both kernels of the round)
             ev1.record()
             per_launch.append((b, t, ev0, ev1))
     barrier()
@@ -1026,6 +1050,22 @@ def main(argv=None):
     kernel_s = max(kernel_s, 1e-9)                            # (never divide by a zero span)
     kernel_dense_s = max((sorted(dense_l)[len(dense_l) // 2] - event_overhead_s) if dense_l else kernel_s, 1e-9)
     back_to_back = launches_per_sweep * sweeps
+    # two parts: what each of the two concurrent kernels takes, from an event pair on each of the handle's own streams around one
+    # more sweep (the period of that stream's launches: kernel + its boundary) -- what rocprofv3's kernel trace shows per kernel
+    part_ms = None
+    if loc.num_parts > 1 and args.mode == "rollout":
+        barrier()
+        pev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in loc.part_streams()]
+        for (a_, _z), s_ in zip(pev, loc.part_streams()):
+            a_.record(s_)
+        for b in range(per_sweep):
+            for t in sizes:
+                chunk_bufs(t, 0)["launch"]()
+        for (_a, z_), s_ in zip(pev, loc.part_streams()):
+            z_.record(s_)
+        loc.join()
+        barrier()
+        part_ms = [a_.elapsed_time(z_) / launches_per_sweep for a_, z_ in pev]
     # ---- per-rank account of the gather(s), gathered on rank 0 ----
     gather_info = None
     if gather_rollout:
@@ -1177,7 +1217,9 @@ def main(argv=None):
                                   "gpu_ms_timed_total": sum(sweep_dev) * 1e3,
                                   "value_min_median_max": [total_envs * steps_per_sweep / max(sweep_wall), value,
                                                            total_envs * steps_per_sweep / min(sweep_wall)]},
-                       "timing_method": "r05: median of whole-episode sweeps (11 by default for K-step blocks), back-to-back launches; "
+                       "timing_method": "r06: median of whole-episode sweeps (11 by default for K-step blocks), back-to-back launches, followed "
+                                        "by the same sweeps for --sustain-seconds of GPU time (`sustained`; `value` = the settled median when "
+                                        "the two differ by more than 2 %); "
                                         "roofline.kernel_ms_per_launch = median sweep (HIP events) / launches -- with gathers in the "
                                         "sweeps: the mean launch of a replayed sweep WITHOUT gathers (the sweep's own figure is "
                                         "roofline.launch_ms_with_gather)",
@@ -1194,6 +1236,8 @@ def main(argv=None):
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": tr["note"],
                          "salu_wave_insts_per_env_step": tr["salu"], "lds_wave_insts_per_env_step": tr["lds"],
                          "kernel": loc.kernel_variant(args.mode),
+                         "kernels_in_flight": loc.num_parts, "round_ms": kernel_s * 1e3,
+                         "part_stream_ms_per_launch": part_ms,
                          "kernel_ms_per_launch": kernel_s * 1e3, "kernel_launches_timed": back_to_back if (uniform and not gather_rollout) else len(full),
                          "launch_ms_with_gather": (sweep_launch_s * 1e3 if gather_rollout else None),
                          "kernel_ms_per_launch_event_pairs": sum(full) / max(1, len(full)) * 1e3,
@@ -1219,6 +1263,14 @@ def main(argv=None):
                                  "a SIMD issuing -- a packed-f32 instruction takes 4 of those cycles and counts as one here)"},
             "step_api": step_api,
         }
+        if sustained is not None:
+            out["sustained"] = sustained
+        out["config"]["rollout_form"] = {"requested": args.rollout_form, "parts": loc.num_parts,
+                                         "note": ("evac_options_t.parts = 2: every rollout call issues envs [0, E/2) and [E/2, E) as two kernels on two streams the "
+                                                  "handle owns; a sweep is closed by evac_join on the timing stream; roofline.achieved = the whole batch's "
+                                                  "algorithmic bytes per round of launches / the round's period (round_ms = kernel_ms_per_launch), "
+                                                  "part_stream_ms_per_launch = the launch period of each of the two streams") if loc.num_parts > 1 else
+                                                 "one kernel per rollout call on the launching stream"}
         out["cpu_baseline"] = cpu_base
         if side is not None:
             out["workloads"] = side

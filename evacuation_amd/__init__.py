@@ -8,7 +8,7 @@ from .config import EnvConfig, EnvWrappersConfig
 from .statuses import Status
 
 __all__ = ["EnvConfig", "EnvWrappersConfig", "Status", "setup_env", "EvacuationEnv", "BatchedEvacuationEnv",
-           "ShardedEvacuationEnv", "SplitBatchEnv", "NormalizedVectorEnv", "HostVectorEnv", "RandomAgent"]
+           "ShardedEvacuationEnv", "SplitBatchEnv", "NormalizedVectorEnv", "HostVectorEnv", "RandomAgent", "KernelOptions", "kernel_options"]
 
 
 def __getattr__(name):   # lazy: keeps `import evacuation_amd` light and torch-free for config users
@@ -30,6 +30,9 @@ def __getattr__(name):   # lazy: keeps `import evacuation_amd` light and torch-f
     if name == "HostVectorEnv":
         from .host_env import HostVectorEnv
         return HostVectorEnv
+    if name in ("KernelOptions", "kernel_options"):
+        from . import options as _options
+        return getattr(_options, name)
     if name == "RandomAgent":
         from .agents import RandomAgent
         return RandomAgent

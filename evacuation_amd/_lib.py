@@ -15,7 +15,7 @@ POS = {"abs": 0, "rel": 1, "grav": 2}
 STAT = {"no": 0, "ohe": 1, "cat": 2}
 TYPE = {"Dict": 0, "Box": 1}
 MAX_PEDESTRIANS = 1024
-VERSION = 140
+VERSION = 150
 EPISODE_STATS_WORDS = 10       # evac_episode_stats_t: 8 floats + 2 int32
 
 
@@ -30,6 +30,11 @@ class EvacConfig(C.Structure):
         ("max_timesteps", C.c_int32), ("positions", C.c_int32), ("statuses", C.c_int32),
         ("type", C.c_int32), ("alpha", C.c_float), ("nan_guard", C.c_int32), ("clip_action", C.c_int32),
     ]
+
+
+class EvacOptions(C.Structure):
+    """evac_options_t: which kernels a handle launches (never what they compute); -1 = automatic"""
+    _fields_ = [(f, C.c_int32) for f in ("subwave", "cells", "cu_wide", "team", "specialize", "parts", "team_coop", "team_fault")]
 
 
 class EvacError(RuntimeError):
@@ -47,6 +52,11 @@ SIGNATURES = {
     "evac_config_validate": (C.c_int, [C.POINTER(EvacConfig)]),
     "evac_config_obs_dim": (C.c_int64, [C.POINTER(EvacConfig)]),
     "evac_create": (C.c_int, [C.POINTER(EvacConfig), C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(_P)]),
+    "evac_create_ex": (C.c_int, [C.POINTER(EvacConfig), C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(EvacOptions), C.POINTER(_P)]),
+    "evac_get_options": (C.c_int, [_P, C.POINTER(EvacOptions)]),
+    "evac_join": (C.c_int, [_P, _P]),
+    "evac_num_parts": (C.c_int32, [_P]),
+    "evac_part_stream": (_P, [_P, C.c_int32]),
     "evac_destroy": (C.c_int, [_P]),
     "evac_obs_dim": (C.c_int64, [_P]),
     "evac_num_envs": (C.c_int32, [_P]),

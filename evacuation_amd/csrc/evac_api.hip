@@ -84,7 +84,17 @@ struct evac_handle {
     volatile unsigned* team_flag_host;
     unsigned* team_flag_dev;
     std::string err;
-    std::string variant[3];   // evac_step | evac_rollout with one workgroup (or less) per env | evac_rollout by teams
+    std::string variant[4];   // evac_step | evac_rollout with one workgroup (or less) per env | evac_rollout by teams | ... as two parts
+    // evac_options_t.parts = 2: the handle's rollouts go out as two half-batch kernels on two streams it owns (include/evac.h,
+    // evac_join).  part[k] is a complete handle of its own over envs [k E / 2, (k + 1) E / 2) of THIS handle's buffers (state
+    // pointers and workspace slices offset, Params::slab_envs = E, env_id_offset + k E / 2: the same global env ids), so a part
+    // launches exactly what a handle of that size launches -- schedule, in-kernel deal and generation counter of its own.
+    int n_parts;              // 1 or 2
+    evac_handle* part[2];
+    hipStream_t part_stream[2];
+    hipEvent_t part_done[2], fork_ev;
+    bool parts_pending;       // the part streams hold work the caller's stream has not been made to wait for (evac_join)
+    evac_options_t opt;       // as resolved at creation (evac_get_options)
 };
 
 namespace {
@@ -229,8 +239,19 @@ int64_t evac_config_obs_dim(const evac_config_t* cfg) {
     return obs_dim_of(cfg);
 }
 
-int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint64_t seed, uint64_t env_id_offset,
-                evac_handle_t* out) {
+}  // extern "C"
+
+namespace {
+// A create-time option: the diagnostic environment variable wins when it is set (A/B runs of an unmodified caller), then the
+// caller's evac_options_t field, then -1 = automatic.
+int option_value(const char* env_name, int option) {
+    const char* v = std::getenv(env_name);
+    if (v && v[0]) return std::atoi(v);
+    return option;
+}
+
+int create_impl(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint64_t seed, uint64_t env_id_offset,
+                const evac_options_t& o, evac_handle_t* out) {
     if (!out) { g_create_error = "out is NULL"; return EVAC_ERR_INVALID_ARGUMENT; }
     *out = nullptr;
     std::string err;
@@ -250,19 +271,27 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
     h->cfg = *cfg;
     h->device = device;
     h->bound = false;
-    {   // small rooms share a wave: 4 envs per wave for N <= 16, 2 for N <= 32 (EVAC_SUBWAVE=0 disables, for A/B tests)
-        const char* sw = std::getenv("EVAC_SUBWAVE");
-        const bool allow = !(sw && sw[0] == '0');
+    h->n_parts = 1;
+    h->part[0] = h->part[1] = nullptr;
+    h->part_stream[0] = h->part_stream[1] = nullptr;
+    h->part_done[0] = h->part_done[1] = h->fork_ev = nullptr;
+    h->parts_pending = false;
+    const int o_subwave = option_value("EVAC_SUBWAVE", o.subwave), o_cells = option_value("EVAC_CELLS", o.cells);
+    const int o_cu_wide = option_value("EVAC_CU_WIDE", o.cu_wide), o_team = option_value("EVAC_TEAM", o.team);
+    const int o_specialize = option_value("EVAC_SPECIALIZE", o.specialize);
+    const int o_team_coop = option_value("EVAC_TEAM_COOP", o.team_coop), o_team_fault = option_value("EVAC_TEAM_FAULT", o.team_fault);
+    {   // small rooms share a wave: 4 envs per wave for N <= 16, 2 for N <= 32 (subwave = 0 disables, for A/B tests)
+        const bool allow = o_subwave != 0;
         const int n = cfg->number_of_pedestrians;
         h->sub_lanes = !allow ? 0 : (n <= 16 ? 16 : (n <= 32 ? 32 : 0));
-        // rooms of more than 512 pedestrians use the cell list; EVAC_CELLS=1 / 0 forces it on (for every room of more
+        // rooms of more than 512 pedestrians use the cell list; cells = 1 / 0 forces it on (for every room of more
         // than one wave) / off, for A/B tests
-        const char* cl = std::getenv("EVAC_CELLS");
-        h->cells = n > evac::kWave && (cl && cl[0] == '1' ? true : (cl && cl[0] == '0' ? false : n > 512));
+        h->cells = n > evac::kWave && (o_cells == 1 ? true : (o_cells == 0 ? false : n > 512));
     }
     evac::Params& p = h->p;
     std::memset(&p, 0, sizeof(p));
     p.n_envs = num_envs;
+    p.slab_envs = num_envs;
     p.n_ped = cfg->number_of_pedestrians;
     p.width = cfg->width;
     p.height = cfg->height;
@@ -317,9 +346,8 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
         h->cus = cus;
-        const char* cw = std::getenv("EVAC_CU_WIDE");
         const bool one_wave = h->sub_lanes == 0 && cfg->number_of_pedestrians <= evac::kWave;
-        h->cu_wide = one_wave && (cw && cw[0] == '1' ? true : (cw && cw[0] == '0' ? false : (num_envs >= 16 * cus && num_envs <= 64 * cus)));
+        h->cu_wide = one_wave && (o_cu_wide == 1 ? true : (o_cu_wide == 0 ? false : (num_envs >= 16 * cus && num_envs <= 64 * cus)));
         // priority rotation (rollout_body) evens out the waves of a SIMD in launches of one or two rounds; deeper launches
         // even out by themselves and run ~2 % faster without it
         const int wpe = waves_per_env(cfg->number_of_pedestrians);
@@ -327,9 +355,8 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         h->p.fair = waves <= 2ll * 16 * cus ? 1 : 0;
         // four-wave envs (N = 129..256, all pairs): 4 envs per CU-wide workgroup with per-env LDS barriers, pace and schedule
         h->cu_wide4 = h->sub_lanes == 0 && wpe == 4 && !h->cells &&
-                      (cw && cw[0] == '1' ? true : (cw && cw[0] == '0' ? false : (num_envs >= 4 * cus && num_envs <= 16 * cus)));
-        const char* sp = std::getenv("EVAC_SPECIALIZE");     // EVAC_SPECIALIZE=0: always the generic kernels (A/B runs)
-        h->default_cfg = !(sp && sp[0] == '0');              // (completed below, once Params is filled)
+                      (o_cu_wide == 1 ? true : (o_cu_wide == 0 ? false : (num_envs >= 4 * cus && num_envs <= 16 * cus)));
+        h->default_cfg = o_specialize != 0;                  // specialize = 0: always the generic kernels (A/B runs)
         const bool obs_default = cfg->positions == EVAC_POS_GRAV
                                      ? p.grav_pow_int == 5
                                      : (cfg->positions == EVAC_POS_REL && cfg->statuses == EVAC_STAT_OHE && cfg->type == EVAC_TYPE_BOX);
@@ -348,12 +375,11 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         h->team_flag_host = nullptr;
         h->team_flag_dev = nullptr;
         if (cfg->number_of_pedestrians > 512) {
-            const char* tm = std::getenv("EVAC_TEAM");
-            const int want = tm ? std::atoi(tm) : -1;
+            const int want = o_team;
             const int rows = (num_envs + 7) / 8 * 8;
             for (int k = 16; k >= 2; k >>= 1)
                 if ((want < 0 || want == k) && rows * k <= cus) { h->team_k = k; break; }
-            if (want == 0 || (want < 0 && std::getenv("EVAC_CELLS"))) h->team_k = 0;   // an A/B run of the one-workgroup families
+            if (want == 0 || (want < 0 && o_cells >= 0)) h->team_k = 0;   // an A/B run of the one-workgroup families
         }
         if (h->team_k) {
             DeviceGuard g(device);
@@ -368,11 +394,9 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
                 h->team_flag_host = (volatile unsigned*)host;
                 h->team_flag_dev = (unsigned*)dev;
                 int coop = 0;
-                const char* tc = std::getenv("EVAC_TEAM_COOP");
                 if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) != hipSuccess) coop = 0;
-                h->team_coop = coop != 0 && tc && tc[0] == '1';      // opt-in: see evac_rollout
-                const char* tf = std::getenv("EVAC_TEAM_FAULT");
-                h->team_fault = tf && tf[0] == '1';
+                h->team_coop = coop != 0 && o_team_coop == 1;        // opt-in: see evac_rollout
+                h->team_fault = o_team_fault == 1;
             }
         }
     }
@@ -394,18 +418,163 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         if (h->team_k) fam = h->team_k == 16 ? evac::Team<16>::kName : (h->team_k == 8 ? evac::Team<8>::kName : (h->team_k == 4 ? evac::Team<4>::kName : evac::Team<2>::kName));
         h->variant[2] = std::string("k_rollout") + kind + fam + (grav ? ", grav obs>" : ", generic obs>");
     }
+    h->opt = evac_options_t{h->sub_lanes ? 1 : 0, h->cells ? 1 : 0, (h->cu_wide || h->cu_wide4) ? 1 : 0, h->team_k, h->default_cfg ? 1 : 0,
+                            1, h->team_coop ? 1 : 0, h->team_fault ? 1 : 0};
     *out = h;
     return EVAC_OK;
 }
 
+// ---- evac_options_t.parts = 2: two streams of the handle's own that really run BESIDE each other.  HIP deals its streams onto a
+// handful of hardware queues (four by default) in the order of their first use, and two streams that share a queue execute
+// strictly one after the other (round 4 found the gather stream on the rollout's queue).  So every candidate is timed
+// against the first stream with two one-thread spin kernels of ~100 us: a pair that takes about as long as one of them overlaps.
+__global__ void k_spin_100us(unsigned long long ticks, unsigned* sink) {
+    unsigned long long t0, t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    unsigned n = 0;
+    do {                                           // (100 MHz constant clock; bounded whatever the clock reads)
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    } while (t - t0 < ticks && ++n < (1u << 22));
+    if (sink) *sink = n;
+}
+float spin_pair_ms(hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent_t e1, hipEvent_t eb) {
+    float ms = -1.0f;
+    (void)hipEventRecord(e0, a);
+    hipLaunchKernelGGL(k_spin_100us, dim3(1), dim3(1), 0, a, 10000ull, (unsigned*)nullptr);
+    if (b) {
+        hipLaunchKernelGGL(k_spin_100us, dim3(1), dim3(1), 0, b, 10000ull, (unsigned*)nullptr);
+        (void)hipEventRecord(eb, b);
+        (void)hipStreamWaitEvent(a, eb, 0);
+    }
+    (void)hipEventRecord(e1, a);
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { (void)hipGetLastError(); return -1.0f; }
+    return ms;
+}
+bool make_part_streams(evac_handle* h) {
+    DeviceGuard g(h->device);
+    hipEvent_t e0 = nullptr, e1 = nullptr, eb = nullptr;
+    bool ok = hipStreamCreateWithFlags(&h->part_stream[0], hipStreamNonBlocking) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+              hipEventCreate(&e1) == hipSuccess && hipEventCreate(&eb) == hipSuccess;
+    if (ok) {
+        (void)spin_pair_ms(h->part_stream[0], nullptr, e0, e1, eb);                 // (first launch: the code object is loaded)
+        const float one = spin_pair_ms(h->part_stream[0], nullptr, e0, e1, eb);
+        hipStream_t dropped[8];
+        int n_dropped = 0;
+        for (int c = 0; ok && c < 8; ++c) {
+            hipStream_t cand = nullptr;
+            if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) { ok = false; break; }
+            (void)spin_pair_ms(h->part_stream[0], cand, e0, e1, eb);                // (first use: the stream gets its queue here)
+            const float pair = spin_pair_ms(h->part_stream[0], cand, e0, e1, eb);
+            if (c == 7 || (one > 0.0f && pair > 0.0f && pair < 1.5f * one)) { h->part_stream[1] = cand; break; }
+            dropped[n_dropped++] = cand;          // (kept until the search ends: its queue assignment stays used up, which moves the next candidate on)
+        }
+        for (int k = 0; k < n_dropped; ++k) (void)hipStreamDestroy(dropped[k]);
+        ok = ok && h->part_stream[1] != nullptr;
+    }
+    for (int k = 0; ok && k < 2; ++k) ok = hipEventCreateWithFlags(&h->part_done[k], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming) == hipSuccess;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (eb) (void)hipEventDestroy(eb);
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
+void destroy_parts(evac_handle* h) {
+    DeviceGuard g(h->device);
+    for (int k = 0; k < 2; ++k) {
+        if (h->part_stream[k]) { (void)hipStreamSynchronize(h->part_stream[k]); (void)hipStreamDestroy(h->part_stream[k]); }
+        if (h->part_done[k]) (void)hipEventDestroy(h->part_done[k]);
+        if (h->part[k]) {
+            if (h->part[k]->team_flag_host) (void)hipHostFree((void*)h->part[k]->team_flag_host);
+            delete h->part[k];
+        }
+        h->part_stream[k] = nullptr; h->part_done[k] = nullptr; h->part[k] = nullptr;
+    }
+    if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
+    h->fork_ev = nullptr;
+    h->n_parts = 1;
+    h->parts_pending = false;
+}
+// `stream` waits for everything the part streams have been given so far (evac_join; implied by every call that is not a plain rollout)
+int join_parts(evac_handle* h, hipStream_t stream) {
+    if (h->n_parts < 2 || !h->parts_pending) return EVAC_OK;
+    DeviceGuard g(h->device);
+    for (int k = 0; k < h->n_parts; ++k)
+        if (hipEventRecord(h->part_done[k], h->part_stream[k]) != hipSuccess || hipStreamWaitEvent(stream, h->part_done[k], 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(h, EVAC_ERR_HIP, "evac_join: event record / wait failed");
+        }
+    h->parts_pending = false;
+    return EVAC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint64_t seed, uint64_t env_id_offset,
+                evac_handle_t* out) {
+    return evac_create_ex(cfg, num_envs, device, seed, env_id_offset, nullptr, out);
+}
+
+int evac_create_ex(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint64_t seed, uint64_t env_id_offset,
+                   const evac_options_t* options, evac_handle_t* out) {
+    evac_options_t o = EVAC_OPTIONS_AUTO;
+    if (options) o = *options; else o.parts = 1;         // (evac_create: the stream contract existing callers rely on)
+    const int32_t* f = &o.subwave;
+    for (int k = 0; k < (int)(sizeof(o) / sizeof(int32_t)); ++k)
+        if (f[k] < -1 || f[k] > 16) { g_create_error = "evac_options_t: every field must be -1 (automatic) or a small non-negative value"; if (out) *out = nullptr; return EVAC_ERR_INVALID_ARGUMENT; }
+    if (o.parts == 0 || o.parts > 2) { g_create_error = "evac_options_t.parts must be -1, 1 or 2"; if (out) *out = nullptr; return EVAC_ERR_INVALID_ARGUMENT; }
+    const int rc = create_impl(cfg, num_envs, device, seed, env_id_offset, o, out);
+    if (rc != EVAC_OK) return rc;
+    evac_handle* h = *out;
+    // Two parts: where it pays by itself (-1) -- CU-wide rollouts whose halves are whole CU-wide workgroups; the halves keep the
+    // CU-wide form although each alone would not fill the device (pace keeping and the in-kernel deal are what they are to keep) --
+    // or on request (2) for every handle but the teams' (their grids run one at a time: evac_rollout).
+    const int per_wg = h->cu_wide4 ? 4 : 16;
+    const int parts_opt = option_value("EVAC_PARTS", o.parts);
+    const bool can = h->team_k == 0 && num_envs >= 2 && num_envs % 2 == 0;
+    const bool pays = (h->cu_wide || h->cu_wide4) && num_envs % (2 * per_wg) == 0;
+    if (!(can && (parts_opt == 2 || (parts_opt < 0 && pays)))) return EVAC_OK;
+    evac_options_t po = h->opt;                        // the parts take the parent's resolved choices
+    po.parts = 1;
+    const int32_t half = num_envs / 2;
+    bool ok = make_part_streams(h);
+    for (int k = 0; ok && k < 2; ++k) {
+        evac_handle_t c = nullptr;
+        ok = create_impl(cfg, half, device, seed, env_id_offset + (uint64_t)k * (uint64_t)half, po, &c) == EVAC_OK;
+        h->part[k] = c;
+        if (ok) c->p.slab_envs = num_envs;
+    }
+    if (!ok) { destroy_parts(h); return EVAC_OK; }     // (no second queue, no parts: the handle works as one)
+    h->n_parts = 2;
+    h->opt.parts = 2;
+    h->variant[3] = h->part[0]->variant[1] + " x 2 streams";
+    return EVAC_OK;
+}
+
+int evac_get_options(evac_handle_t h, evac_options_t* out) {
+    if (!h || !out) return EVAC_ERR_INVALID_ARGUMENT;
+    *out = h->opt;
+    return EVAC_OK;
+}
+
+int evac_join(evac_handle_t h, void* stream) {
+    if (!h) return EVAC_ERR_INVALID_ARGUMENT;
+    return join_parts(h, (hipStream_t)stream);
+}
+int32_t evac_num_parts(evac_handle_t h) { return h ? h->n_parts : -1; }
+void* evac_part_stream(evac_handle_t h, int32_t part) { return (h && h->n_parts > 1 && part >= 0 && part < h->n_parts) ? (void*)h->part_stream[part] : nullptr; }
+
 const char* evac_kernel_variant(evac_handle_t h, int32_t rollout) {
     if (!h) return "";
     if (!rollout) return h->variant[0].c_str();
+    if (h->n_parts > 1) return h->variant[3].c_str();
     // the path evac_rollout takes right now: teams only with their exchange areas bound and a grid that fits the device
     return h->variant[(h->team_k && h->team_bound && h->team_fit != 0) ? 2 : 1].c_str();
 }
 
 int evac_destroy(evac_handle_t h) {
+    if (h && (h->n_parts > 1 || h->part_stream[0])) destroy_parts(h);
     if (h && h->team_flag_host) {
         DeviceGuard g(h->device);
         (void)hipHostFree((void*)h->team_flag_host);
@@ -435,6 +604,11 @@ int evac_bind_state(evac_handle_t h, float* ped, uint8_t* status, float* agent, 
     h->p.clock = (int4*)clock;
     h->p.acc = (float4*)acc;
     h->bound = true;
+    for (int k = 0; k < (h->n_parts > 1 ? h->n_parts : 0); ++k) {      // the parts: the same buffers from their first env on
+        const size_t first = (size_t)k * (size_t)h->part[k]->p.n_envs, N = (size_t)h->p.n_ped;
+        const int rc = evac_bind_state(h->part[k], ped + first * N * 4, status + first * N, agent + first * 4, clock + first * 4, acc + first * 4);
+        if (rc != EVAC_OK) return fail(h, rc, std::string("evac_bind_state (part): ") + h->part[k]->err);
+    }
     return EVAC_OK;
 }
 
@@ -459,13 +633,32 @@ WorkspaceLayout workspace_layout(const evac_handle* h) {
 }
 }  // namespace
 
-int64_t evac_workspace_bytes(evac_handle_t h) { return h ? (int64_t)workspace_layout(h).total : -1; }
+int64_t evac_workspace_bytes(evac_handle_t h) {
+    if (!h) return -1;
+    size_t total = workspace_layout(h).total, parts = 0;
+    for (int k = 0; k < (h->n_parts > 1 ? h->n_parts : 0); ++k) parts += workspace_layout(h->part[k]).total;   // (the parts carve it up between them)
+    return (int64_t)(parts > total ? parts : total);
+}
 
 int evac_bind_workspace(evac_handle_t h, void* workspace, int64_t bytes) {
     if (!h) return EVAC_ERR_INVALID_ARGUMENT;
     h->sched = nullptr;
     h->sched_gen = -1;
     h->team_bound = false;
+    if (h->n_parts > 1) {
+        // the parts schedule themselves: each gets a slice (moving[2][E/2] | perm[2][E/2] of its own); this handle's own rollouts --
+        // the diagnostic face only -- run without a schedule
+        if (workspace && (bytes < evac_workspace_bytes(h) || ((uintptr_t)workspace & 255u)))
+            return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_bind_workspace: workspace smaller than evac_workspace_bytes() or not 256-byte aligned");
+        size_t o = 0;
+        for (int k = 0; k < h->n_parts; ++k) {
+            const size_t t = workspace_layout(h->part[k]).total;
+            const int rc = evac_bind_workspace(h->part[k], workspace ? (char*)workspace + o : nullptr, (int64_t)t);
+            if (rc != EVAC_OK) return fail(h, rc, std::string("evac_bind_workspace (part): ") + h->part[k]->err);
+            o += t;
+        }
+        return EVAC_OK;
+    }
     if (!workspace) return EVAC_OK;
     const WorkspaceLayout w = workspace_layout(h);
     if (bytes < (int64_t)w.total) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_bind_workspace: workspace smaller than evac_workspace_bytes()");
@@ -499,13 +692,22 @@ void deal_now(evac_handle_t h, hipStream_t s, bool both) {
 
 int evac_reschedule(evac_handle_t h, void* stream) {
     if (!h) return EVAC_ERR_INVALID_ARGUMENT;
+    if (h->n_parts > 1) {                              // (on the caller's stream, behind everything the parts have been given)
+        if (const int rc = join_parts(h, (hipStream_t)stream); rc != EVAC_OK) return rc;
+        for (int k = 0; k < h->n_parts; ++k)
+            if (const int rc = evac_reschedule(h->part[k], stream); rc != EVAC_OK) return fail(h, rc, h->part[k]->err);
+        return EVAC_OK;
+    }
     if (!h->sched || !(h->cu_wide || h->cu_wide4)) return EVAC_OK;       // nothing to deal
     DeviceGuard g(h->device);
     deal_now(h, (hipStream_t)stream, true);
     return check_launch(h, "evac_reschedule");
 }
 
-int32_t evac_schedule_generation(evac_handle_t h) { return (h && h->sched && (h->cu_wide || h->cu_wide4)) ? h->sched_gen : -1; }
+int32_t evac_schedule_generation(evac_handle_t h) {
+    if (h && h->n_parts > 1) return evac_schedule_generation(h->part[0]);
+    return (h && h->sched && (h->cu_wide || h->cu_wide4)) ? h->sched_gen : -1;
+}
 
 int evac_peer_gather(const float* src, int64_t rows, int32_t row_words, int32_t take_words, float* const* peer_dst, int32_t world,
                      int32_t my_rank, int32_t wgs_per_peer, void* stream) {
@@ -563,13 +765,18 @@ int evac_team_clear_error(evac_handle_t h) {
     return EVAC_OK;
 }
 
+// (a handle with two parts: whatever is not a plain rollout first makes the caller's stream wait for the parts' streams)
 #define EVAC_REQUIRE_BOUND(h, name)                                               \
     if (!(h)) return EVAC_ERR_INVALID_ARGUMENT;                                  \
     if (!(h)->bound) return fail((h), EVAC_ERR_NOT_BOUND, name ": call evac_bind_state first"); \
     if (const int ta_ = team_aborted((h), name); ta_ != EVAC_OK) return ta_
+#define EVAC_JOIN_FIRST(h, stream)                                                \
+    if ((h)->parts_pending)                                                       \
+        if (const int jn_ = join_parts((h), (hipStream_t)(stream)); jn_ != EVAC_OK) return jn_
 
 int evac_reset(evac_handle_t h, const uint8_t* mask, const float* draws, float* obs_out, void* stream) {
     EVAC_REQUIRE_BOUND(h, "evac_reset");
+    EVAC_JOIN_FIRST(h, stream);
     if (draws && ((uintptr_t)draws & 15u)) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_reset: draws must be 16-byte aligned");
     DeviceGuard g(h->device);
     EVAC_DISPATCH(h, k_reset, stream, h->p, mask, (const float4*)draws, obs_out);
@@ -596,6 +803,7 @@ int evac_step(evac_handle_t h, const float* actions, const float* noise, float* 
               uint8_t* terminated_out, uint8_t* truncated_out, int32_t autoreset, float* final_obs,
               evac_episode_stats_t* final_stats, void* stream) {
     EVAC_REQUIRE_BOUND(h, "evac_step");
+    EVAC_JOIN_FIRST(h, stream);
     return step_common(h, "evac_step", actions, noise, obs_out, reward_out, terminated_out, truncated_out, autoreset, final_obs,
                        final_stats, evac::NormArgs{nullptr, 0.f, 0.f, 0.f, 0.f}, stream);
 }
@@ -605,6 +813,7 @@ int evac_step_normalized(evac_handle_t h, const float* actions, const float* noi
                          evac_episode_stats_t* final_stats, double* norm_state, float gamma, float obs_clip,
                          float reward_clip, float epsilon, void* stream) {
     EVAC_REQUIRE_BOUND(h, "evac_step_normalized");
+    EVAC_JOIN_FIRST(h, stream);
     if (!norm_state) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_step_normalized: norm_state is NULL");
     return step_common(h, "evac_step_normalized", actions, noise, obs_out, reward_out, terminated_out, truncated_out, autoreset,
                        final_obs, final_stats, evac::NormArgs{norm_state, gamma, obs_clip, reward_clip, epsilon}, stream);
@@ -621,6 +830,32 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
     DeviceGuard g(h->device);
     if (capture && (capture_envs < 1 || capture_envs > h->p.n_envs))
         return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_rollout: capture_envs must be in [1, num_envs] when capture is given");
+    if (h->n_parts > 1 && !(capture || actions_out || noise)) {
+        // two half-batch kernels on the handle's own streams, both behind what `stream` holds so far; `stream` is NOT made to
+        // wait for them (evac_join): consecutive rollout calls must not meet, or the halves would run in lock-step
+        hipStream_t s_ = (hipStream_t)stream;
+        // (the fork costs a barrier packet in front of each kernel -- 7-10 us on this platform whether or not the event has fired,
+        // DESIGN.md 6 -- which is more than the parts gain: when the caller's stream is idle, as in a loop that only launches
+        // rollouts, there is nothing to wait for and the kernels are enqueued bare.  A stream under capture cannot be queried: fork.)
+        const bool fork = hipStreamQuery(s_) != hipSuccess;
+        if (fork) {
+            (void)hipGetLastError();
+            if (hipEventRecord(h->fork_ev, s_) != hipSuccess) { (void)hipGetLastError(); return fail(h, EVAC_ERR_HIP, "evac_rollout: hipEventRecord failed"); }
+        }
+        const size_t row = (size_t)h->p.obs_dim + 3;
+        for (int k = 0; k < h->n_parts; ++k) {
+            evac_handle* c = h->part[k];
+            const size_t first = (size_t)k * (size_t)c->p.n_envs;
+            if (fork && hipStreamWaitEvent(h->part_stream[k], h->fork_ev, 0) != hipSuccess) { (void)hipGetLastError(); return fail(h, EVAC_ERR_HIP, "evac_rollout: hipStreamWaitEvent failed"); }
+            h->parts_pending = true;
+            const int rc = evac_rollout(c, n_steps, actions ? actions + first * 2 : nullptr, nullptr, slab_out + first * row,
+                                        final_stats ? final_stats + first : nullptr, 0, nullptr, nullptr, h->part_stream[k]);
+            if (rc != EVAC_OK) return fail(h, rc, std::string("evac_rollout (part): ") + c->err);
+        }
+        return EVAC_OK;
+    }
+    if (h->parts_pending)
+        if (const int jn = join_parts(h, (hipStream_t)stream); jn != EVAC_OK) return jn;
     if (capture || actions_out || noise)
         EVAC_DISPATCH(h, k_rollout_diag, stream, h->p, (int)n_steps, (const float2*)actions, (float2*)actions_out, slab_out,
                       final_stats, (int)capture_envs, capture, noise);
@@ -724,6 +959,7 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
 
 int evac_observe(evac_handle_t h, float* obs_out, void* stream) {
     EVAC_REQUIRE_BOUND(h, "evac_observe");
+    EVAC_JOIN_FIRST(h, stream);
     if (!obs_out) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_observe: obs_out is NULL");
     DeviceGuard g(h->device);
     EVAC_DISPATCH(h, k_observe, stream, h->p, obs_out);
@@ -739,6 +975,7 @@ static unsigned state_grid(const evac::Params& p) {
 int evac_get_state(evac_handle_t h, float* pos, float* dir, uint8_t* status, float* agent_pos, float* agent_dir,
                    int32_t* now, void* stream) {
     EVAC_REQUIRE_BOUND(h, "evac_get_state");
+    EVAC_JOIN_FIRST(h, stream);
     DeviceGuard g(h->device);
     hipLaunchKernelGGL(evac::k_get_state, dim3(state_grid(h->p)), dim3(256), 0, (hipStream_t)stream, h->p, (float2*)pos,
                        (float2*)dir, status, (float2*)agent_pos, (float2*)agent_dir, now);
@@ -748,6 +985,7 @@ int evac_get_state(evac_handle_t h, float* pos, float* dir, uint8_t* status, flo
 int evac_set_state(evac_handle_t h, const float* pos, const float* dir, const uint8_t* status, const float* agent_pos,
                    const float* agent_dir, const int32_t* now, void* stream) {
     EVAC_REQUIRE_BOUND(h, "evac_set_state");
+    EVAC_JOIN_FIRST(h, stream);
     DeviceGuard g(h->device);
     hipLaunchKernelGGL(evac::k_set_state, dim3(state_grid(h->p)), dim3(256), 0, (hipStream_t)stream, h->p,
                        (const float2*)pos, (const float2*)dir, status, (const float2*)agent_pos,

@@ -97,6 +97,9 @@ constexpr uint32_t kStreamAction = 0x41435449u;  // 'ACTI'
 
 struct Params {
     int32_t n_envs, n_ped;
+    // envs per time step of the caller's time-major buffers (slab [T][slab_envs][D+3], episode stats, given actions): n_envs, or the
+    // whole batch's when this handle is one PART of it (evac_options_t.parts: the part's pointers are offset to its first env)
+    int32_t slab_envs;
     float width, height, step_size, noise_coef, eps;
     float ens, one_minus_ens;
     float init_reward, intrinsic_coef;

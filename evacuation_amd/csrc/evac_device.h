@@ -609,7 +609,7 @@ __device__ __forceinline__ void rollout_body(
         }
     }
     const uint32_t gid = p.env_id_offset + (uint32_t)w.env;
-    const size_t E = (size_t)p.n_envs;
+    const size_t E = (size_t)p.slab_envs;
     const int row = p.obs_dim + 3;
     // The four noise words of Philox block `noise_group` (-1: none), ROTATED every step so that nzw[0] is the word of the step
     // at hand: three register moves per step where picking word `total & 3` took three scalar compare / select pairs and

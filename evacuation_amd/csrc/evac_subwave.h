@@ -148,7 +148,7 @@ __device__ __forceinline__ void rollout_body_sub(typename Sub<G>::Smem& sm, cons
     Env e;
     load_env(p, w.env, w.i, active, q, e);
     const uint32_t gid = p.env_id_offset + (uint32_t)w.env;
-    const size_t E = (size_t)p.n_envs;
+    const size_t E = (size_t)p.slab_envs;
     const int row = p.obs_dim + 3;
     uint4 nzr = make_uint4(0, 0, 0, 0);
     bool have = false;

@@ -406,7 +406,7 @@ class ShardedEvacuationEnv:
     shard with a BatchedEvacuationEnv and the packed outputs are all-gathered."""
 
     def __init__(self, env_config, wrap_config=None, total_envs: int = 1, device=None, seed: int = 0, group=None,
-                 autoreset: bool = True, force_collective: bool = False):
+                 autoreset: bool = True, force_collective: bool = False, options=None):
         """``force_collective``: run the collective (comm stream, event hand-off, ``all_gather_into_tensor``) also in a group of
         ONE rank -- the multi-GPU code path exercised on a single GPU (tests/test_gpu_rccl_world1.py)."""
         from .vector_env import BatchedEvacuationEnv
@@ -419,7 +419,7 @@ class ShardedEvacuationEnv:
         if device is None:
             device = f"cuda:{torch.cuda.current_device()}"
         self.local = BatchedEvacuationEnv(env_config, wrap_config, num_envs=self.local_envs, device=device, seed=seed,
-                                          env_id_offset=self.offset, autoreset=autoreset)
+                                          env_id_offset=self.offset, autoreset=autoreset, options=options)
         self.obs_dim = self.local.obs_dim
         self.comm_stream = side_stream(self.local.device) if self.collective else None      # (one that overlaps the compute stream)
 

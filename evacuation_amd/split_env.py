@@ -11,10 +11,13 @@ Part k owns the envs [k E / P, (k + 1) E / P) of the batch and is created with t
 (reset draws, RandomAgent actions, pedestrian noise) are keyed by the GLOBAL env id, so the parts reproduce the single handle's
 trajectories bit for bit (tests/test_gpu_parity.py::test_split_batch_equals_one_handle) -- the same property
 ShardedEvacuationEnv uses across GPUs.  The price: the outputs are P slabs ``[T, E / P, D + 3]`` (``rollout()`` returns them and,
-on request, their concatenation), and whoever consumes them must wait for all P streams (``join`` / ``synchronize``)."""
+on request, their concatenation), and whoever consumes them must wait for all P streams (``join`` / ``synchronize``).
+
+Since round 6 the same thing exists INSIDE the library for two parts -- ``KernelOptions(parts=2)`` / ``evac_options_t.parts``: one
+handle, one slab ``[T, E, D + 3]``, two streams the handle owns (``BatchedEvacuationEnv.join``); that form is what bench.py times.
+This class stays for P separate slabs and for experiments with other part counts."""
 from __future__ import annotations
 
-import os
 from typing import List, Optional
 
 import torch
@@ -37,21 +40,17 @@ class SplitBatchEnv:
         if device is None:
             device = f"cuda:{torch.cuda.current_device()}"
         self.device = torch.device(device)
-        # (a part alone would not fill the device, and evac_create would give it 256-thread workgroups: the CU-wide form -- pace
-        # keeping, the in-kernel deal -- is what the parts are meant to keep; the switch is an environment variable read at creation)
-        old = os.environ.get("EVAC_CU_WIDE")
+        # (a part alone would not fill the device, and the automatic choice would give it 256-thread workgroups: the CU-wide form --
+        # pace keeping, the in-kernel deal -- is what the parts are meant to keep: a create-time option of every part, evac_options_t)
+        from .options import current_default
+        opts = kw.pop("options", None) or current_default()
         if cu_wide is not None:
-            os.environ["EVAC_CU_WIDE"] = "1" if cu_wide else "0"
-        try:
-            self.parts: List[BatchedEvacuationEnv] = [
-                BatchedEvacuationEnv(env_config, wrap_config, num_envs=per, device=self.device, seed=seed, env_id_offset=env_id_offset + k * per, **kw)
-                for k in range(self.n_parts)]
-        finally:
-            if cu_wide is not None:
-                if old is None:
-                    os.environ.pop("EVAC_CU_WIDE", None)
-                else:
-                    os.environ["EVAC_CU_WIDE"] = old
+            opts = opts.replace(cu_wide=1 if cu_wide else 0)
+        opts = opts.replace(parts=1)
+        self.parts: List[BatchedEvacuationEnv] = [
+            BatchedEvacuationEnv(env_config, wrap_config, num_envs=per, device=self.device, seed=seed, env_id_offset=env_id_offset + k * per,
+                                 options=opts, **kw)
+            for k in range(self.n_parts)]
         self.obs_dim, self.stats_words = self.parts[0].obs_dim, self.parts[0].stats_words
         main = torch.cuda.current_stream(self.device)
         self.streams = [main]
@@ -72,12 +71,25 @@ class SplitBatchEnv:
         if outs is None:
             outs = [{"slab": torch.empty((T, p.num_envs, p.obs_dim + 3), dtype=torch.float32, device=self.device),
                      "episode_stats": torch.zeros((T, p.num_envs, p.stats_words), dtype=torch.float32, device=self.device)} for p in self.parts]
+        # The outputs were allocated (and zero-filled) on the CURRENT stream, and a caller's ``outs`` were last touched on it: the
+        # parts' streams must not start writing before that work is done (on a busy current stream the zero-fill could
+        # land after a part's rollout and wipe its episode records).
+        self.order_after_current()
         calls = [p.rollout_launcher(T, o, stream=s) for p, o, s in zip(self.parts, outs, self.streams)]
 
         def launch():
             for c in calls:
                 c()
         return launch, outs
+
+    def order_after_current(self):
+        """Make every part's stream wait for what the current stream holds so far (output buffers allocated, filled or last read
+        there).  ``rollout_launcher`` calls it once; callers that refill or reuse ``outs`` on their own stream call it again before
+        the next ``launch()``."""
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            if s != cur:
+                s.wait_stream(cur)
 
     def join(self, stream=None):
         """Make ``stream`` (default: the current stream) wait for everything the parts' streams have been given so far."""

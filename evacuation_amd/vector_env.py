@@ -12,7 +12,6 @@ HIP stream; all compute is in libevac.so (csrc/), reached through ctypes (includ
 from __future__ import annotations
 
 import ctypes as C
-import os
 from collections import OrderedDict
 from typing import Dict as TDict, Optional
 
@@ -21,6 +20,7 @@ import torch
 
 from . import _lib
 from .config import EnvConfig, EnvWrappersConfig, obs_dim, to_c_config
+from .options import KernelOptions, current_default
 from .spaces import Box, Dict
 
 # evac_episode_stats_t (include/evac.h): the nine keys of the reference's per-episode logging dict (env.py:115-125)
@@ -138,10 +138,13 @@ class BatchedEvacuationEnv:
 
     Parameters mirror ``setup_env(env_config, wrap_config)`` (src/env/__init__.py:18-21) plus the
     batch size, the device, the Philox ``seed`` and ``env_id_offset`` (global id of env 0, so that
-    a sharded run draws the same random numbers as a single-GPU run)."""
+    a sharded run draws the same random numbers as a single-GPU run).  ``options`` (``KernelOptions`` = ``evac_options_t``)
+    selects which kernels the handle launches -- results do not depend on it; ``options.parts = 2`` (or -1: where it pays) makes
+    ``rollout`` two concurrent half-batch kernels on streams the handle owns: see ``join``."""
 
     def __init__(self, env_config: EnvConfig, wrap_config: Optional[EnvWrappersConfig] = None, num_envs: int = 1,
-                 device="cuda:0", seed: int = 0, env_id_offset: int = 0, autoreset: bool = True):
+                 device="cuda:0", seed: int = 0, env_id_offset: int = 0, autoreset: bool = True,
+                 options: Optional[KernelOptions] = None):
         self.lib = _lib.load()                       # raises if the HIP library is missing
         self.env_config = env_config
         self.wrap_config = wrap_config or EnvWrappersConfig()
@@ -160,8 +163,11 @@ class BatchedEvacuationEnv:
         self._h = C.c_void_p()
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._dev_index = dev_index
-        _lib.check(self.lib.evac_create(C.byref(self._cfg), self.num_envs, dev_index, C.c_uint64(self.seed_value),
-                                        C.c_uint64(self.env_id_offset), C.byref(self._h)))
+        self.options = options if options is not None else current_default()
+        c_opt = self.options.to_c()
+        _lib.check(self.lib.evac_create_ex(C.byref(self._cfg), self.num_envs, dev_index, C.c_uint64(self.seed_value),
+                                           C.c_uint64(self.env_id_offset), C.byref(c_opt), C.byref(self._h)))
+        self.num_parts = int(self.lib.evac_num_parts(self._h))
         self.obs_dim = int(self.lib.evac_obs_dim(self._h))
         assert self.obs_dim == obs_dim(env_config, self.wrap_config)
         E, N, dev = self.num_envs, self.n_ped, self.device
@@ -174,16 +180,16 @@ class BatchedEvacuationEnv:
         _lib.check(self.lib.evac_bind_state(self._h, _ptr(self.ped), _ptr(self.status), _ptr(self.agent),
                                             _ptr(self.clock), _ptr(self.acc)), self._h)
         # workspace of evac_rollout (include/evac.h): the load schedule of large batches of one-wave envs and the exchange
-        # areas of the team kernels; performance devices, results do not depend on them (EVAC_WORKSPACE=0 leaves it unbound,
-        # for A/B runs)
+        # areas of the team kernels; performance devices, results do not depend on them (options.workspace = False leaves it
+        # unbound, for A/B runs)
         self.workspace = None
         self.schedule = None
-        if os.environ.get("EVAC_WORKSPACE", "1") != "0":
+        if self.options.workspace:
             nbytes = int(self.lib.evac_workspace_bytes(self._h))
             self.workspace = torch.zeros((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=dev)
             assert self.workspace.data_ptr() % 256 == 0
             _lib.check(self.lib.evac_bind_workspace(self._h, _ptr(self.workspace), C.c_int64(nbytes)), self._h)
-            if nbytes >= 16 * E:
+            if nbytes >= 16 * E and self.num_parts == 1:     # (two parts: each schedules itself inside a slice of its own)
                 self.schedule = self.workspace[:16 * E].view(torch.int32).view(4, E)    # moving[2][E] | perm[2][E] (include/evac.h)
         # step outputs (reused every step; callers that keep them must clone, like the reference's
         # live-reference observations, env.py:98-104)
@@ -247,6 +253,26 @@ class BatchedEvacuationEnv:
         """``perm[slot] = env`` that the NEXT rollout launch runs under, or None before the first deal."""
         g = self.schedule_generation()
         return None if self.schedule is None or g < 0 else self.schedule[2 + (g & 1)]
+
+    def resolved_options(self) -> KernelOptions:
+        """The options the handle ended up with: automatic choices resolved, diagnostic ``EVAC_*`` overrides applied."""
+        o = _lib.EvacOptions()
+        _lib.check(self.lib.evac_get_options(self._h, C.byref(o)), self._h)
+        return KernelOptions(workspace=self.workspace is not None, **{f: int(getattr(o, f)) for f, _ in _lib.EvacOptions._fields_})
+
+    def join(self, stream=None) -> None:
+        """``options.parts = 2``: make ``stream`` (default: the current stream) wait for everything the handle's own two streams
+        have been given so far (``evac_join``).  ``rollout_launcher`` launches do NOT do this by themselves -- consecutive launches
+        must not meet at a common point, or the two halves would run in lock-step again -- so call it before anything consumes a
+        slab.  ``rollout()`` and every other method join by themselves.  A no-op for ``parts = 1``."""
+        if self.num_parts > 1:
+            st = self._stream() if stream is None else C.c_void_p(stream.cuda_stream)
+            _lib.check(self.lib.evac_join(self._h, st), self._h)
+
+    def part_streams(self):
+        """The handle's own streams (``options.parts = 2``) as ``torch.cuda.ExternalStream`` objects, for timing events; else ``[]``."""
+        return [torch.cuda.ExternalStream(int(self.lib.evac_part_stream(self._h, k)), device=self.device) for k in range(self.num_parts)] \
+            if self.num_parts > 1 else []
 
     def team_error(self, sync: bool = True) -> int:
         """Non-zero if a barrier of a team rollout (N > 512, few envs) timed out: the outputs of that launch -- and of the
@@ -453,6 +479,8 @@ class BatchedEvacuationEnv:
         """A zero-argument callable that enqueues ``rollout(n_steps, out=out)`` (RandomAgent actions) with all ctypes
         arguments prepared once: for loops that launch the same shape many times.  On the stream that is current at
         each call, or always on ``stream`` (a torch stream) if one is given -- which saves the lookup, ~1.5 us per call.
+        With ``options.parts = 2`` the two half-batch kernels go to the handle's own streams behind what the launching stream holds,
+        and NOTHING waits for them until ``join()``.
         The call only ENQUEUES: for rooms of more than 512 pedestrians (team kernels) poll ``team_error(sync=False)`` after waiting
         for the launch and before consuming its slab -- a launch that lost a team member still returns success here."""
         T, E, D = int(n_steps), self.num_envs, self.obs_dim
@@ -514,6 +542,7 @@ class BatchedEvacuationEnv:
         nz = self._as_device(noise, (T, E, self.n_ped), torch.float32, "noise")
         _lib.check(self.lib.evac_rollout(self._h, T, _ptr(act), _ptr(out.get("actions")), _ptr(slab),
                                          _ptr(out.get("episode_stats")), k_cap, _ptr(traj), _ptr(nz), self._stream()), self._h)
+        self.join()                   # (two parts: the returned tensors are ordered behind the launch on the current stream, as ever)
         return out
 
     def observe(self, out: Optional[torch.Tensor] = None):

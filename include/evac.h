@@ -15,7 +15,9 @@
  *  - one handle per (device, set of state buffers); a handle is not thread-safe, distinct
  *    handles are independent.
  *
- * Environment switches (diagnostics only): EVAC_SUBWAVE=0 read by evac_create() selects the one-wave-per-env
+ * Kernel-family selection is a CREATE-TIME OPTION (evac_options_t, evac_create_ex); every field defaults to -1 = automatic.  The
+ * environment switches below are kept as DIAGNOSTIC OVERRIDES only (A/B runs of an unmodified caller): a variable that is set wins
+ * over the option.  EVAC_SUBWAVE=0 selects the one-wave-per-env
  * kernels also for N <= 32 (default: 4 envs per wave for N <= 16, 2 for N <= 32; same results, see
  * tests/test_gpu_parity.py::test_subwave_kernels_match_one_wave_per_env); EVAC_CELLS=1 / 0 forces the cell-list
  * kernels on (for every N > 64) / off (default: N > 512; the all-pairs kernels give the same neighbour sets); EVAC_CU_WIDE=1 / 0
@@ -53,7 +55,7 @@
 extern "C" {
 #endif
 
-#define EVAC_VERSION 140          /* 0.1.4: the deal of the next launch made inside the rollout kernel, evac_schedule_generation */
+#define EVAC_VERSION 150          /* 0.1.5: evac_options_t / evac_create_ex, rollouts of one handle as two concurrent kernels (parts), evac_join */
 #define EVAC_MAX_PEDESTRIANS 1024 /* one workgroup (<=16 waves) per env */
 
 typedef enum evac_status {
@@ -132,7 +134,51 @@ int64_t evac_config_obs_dim(const evac_config_t* cfg);
  * streams; env e uses stream id `env_id_offset + e`, so a sharded run reproduces the single-GPU run. */
 int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint64_t seed,
                 uint64_t env_id_offset, evac_handle_t* out);
+
+/* Create-time options: WHICH kernels a handle launches, never WHAT they compute -- every combination gives bit-identical results
+ * (tests/test_gpu_variants_sweep.py, tools/soak_variants.py).  No reference analogue (the reference steps its envs one after another
+ * in Python, rpo_agent.py:123-126).  Every field: -1 = automatic (what evac_create does).
+ *   subwave     0: one wave per env also for N <= 32; 1: 4 / 2 envs per wave for N <= 16 / 32 (automatic)
+ *   cells       1 / 0: the 16 x 16 cell-list kernels for every N > 64 / never (automatic: N > 512)
+ *   cu_wide     1 / 0: CU-wide rollout workgroups (16 one-wave or 4 four-wave envs per 1024-thread workgroup) always / never
+ *               (automatic: batches of 16..64 one-wave envs, 4..16 four-wave envs per CU)
+ *   team        0 / 2 / 4 / 8 / 16: workgroups (CUs) per env of the team rollout kernels, N > 512 (automatic: what the batch leaves free)
+ *   specialize  0: never the k_*_default_config instantiations (automatic: when the configuration matches)
+ *   parts       1 / 2: evac_rollout issues the batch as ONE kernel on the caller's stream / as TWO half-batch kernels on two streams
+ *               the handle owns (see evac_join).  -1: 2 where it pays (CU-wide handles whose halves still fill their CUs), else 1.
+ *               evac_create() -- the entry point existing callers use -- always takes 1: its stream contract is unchanged.
+ *   team_coop   1: team grids are launched with hipLaunchCooperativeKernel (3-4 % slower; automatic: plain launches)
+ *   team_fault  1: fault injection for tests (the team grid is launched one workgroup short) */
+typedef struct evac_options {
+    int32_t subwave, cells, cu_wide, team, specialize, parts, team_coop, team_fault;
+} evac_options_t;
+#define EVAC_OPTIONS_AUTO {-1, -1, -1, -1, -1, -1, -1, -1}
+/* evac_create with options (NULL: all automatic, parts = 1: exactly evac_create). */
+int evac_create_ex(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint64_t seed, uint64_t env_id_offset,
+                   const evac_options_t* options_or_null, evac_handle_t* out);
+/* The options a handle ended up with (automatic choices resolved, diagnostic environment overrides applied). */
+int evac_get_options(evac_handle_t h, evac_options_t* out);
 int evac_destroy(evac_handle_t h);
+
+/* Handles created with parts = 2 (no reference analogue).  A rollout launch lasts as long as the heaviest env it carries, and
+ * between two launches of one stream lie the queue's kernel boundary and the kernel's prologue; the envs of a batch do not depend
+ * on each other, only consecutive launches of the SAME env do.  So such a handle keeps two streams of its own (on two hardware
+ * queues) and evac_rollout enqueues envs [0, E/2) and [E/2, E) as two kernels, one per stream: each half waits only for ITS
+ * heaviest workgroup and its boundary and prologue run under the other half's steps (N = 60 x 4096 envs, 20 steps per launch:
+ * +3.4-5 %).  One call, one slab [T][E][D+3], the same bits as parts = 1 (the Philox streams are keyed by the
+ * global env id).  Stream contract of such a handle:
+ *   - evac_rollout(h, ..., stream): both kernels start after everything enqueued on `stream` so far (an event recorded on
+ *     `stream`), but `stream` does NOT wait for them -- consecutive evac_rollout calls must not meet at a common point, or the
+ *     halves would run in lock-step again;
+ *   - evac_join(h, stream): `stream` waits for everything the handle's own streams have been given so far.  Call it before
+ *     anything on `stream` (or the host, after synchronising `stream`) consumes a slab, and before ending a stream capture;
+ *   - every other call on the handle (evac_reset, evac_step*, evac_observe, evac_get_state, evac_set_state, evac_reschedule,
+ *     rollouts with capture / recorded actions / injected noise) joins first by itself and runs as one kernel on `stream`.
+ * evac_num_parts: 1 or 2.  evac_part_stream: the hipStream_t of part k (for timing events and profilers; NULL if k is out of
+ * range or parts = 1).  evac_join on a handle with parts = 1 is a no-op. */
+int evac_join(evac_handle_t h, void* stream);
+int32_t evac_num_parts(evac_handle_t h);
+void* evac_part_stream(evac_handle_t h, int32_t part);
 
 /* Floats per env in the observation buffer for this handle's observation mode. */
 int64_t evac_obs_dim(evac_handle_t h);

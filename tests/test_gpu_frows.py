@@ -203,7 +203,7 @@ def test_gravity_powers_beyond_the_common_ones(ea, alpha):
 
 
 @pytest.mark.parametrize("n", [65, 100, 128, 200, 256, 300, 512, 600, 1024])
-def test_cell_list_and_all_pairs_kernels_agree(ea, n, monkeypatch):
+def test_cell_list_and_all_pairs_kernels_agree(ea, n):
     """EVAC_CELLS=1 / 0 select the cell-list / all-pairs kernels for every N > 64.  Teacher-forced (the all-pairs env
     is set to the cell-list env's state before every step, same actions and noise): identical neighbour sets, so the
     same positions to summation rounding and exactly the same statuses and flags; then a short free-running rollout."""
@@ -212,9 +212,8 @@ def test_cell_list_and_all_pairs_kernels_agree(ea, n, monkeypatch):
     cfg = ea.EnvConfig(number_of_pedestrians=n, is_new_exiting_reward=True, noise_coef=0.4, max_timesteps=15)
     envs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("EVAC_CELLS", mode)
         for key, wrap_kw in (("grav", dict(positions="grav", alpha=3)), ("box", dict(positions="rel", statuses="ohe", type="Box"))):
-            env = ea.BatchedEvacuationEnv(cfg, ea.EnvWrappersConfig(**wrap_kw), num_envs=E, seed=n)
+            env = ea.BatchedEvacuationEnv(cfg, ea.EnvWrappersConfig(**wrap_kw), num_envs=E, seed=n, options=ea.KernelOptions(cells=int(mode)))
             assert ("cell list" in env.kernel_variant()) == (mode == "1") and ("cell list" in env.kernel_variant("step")) == (mode == "1")
             env.reset()
             envs[(mode, key)] = env

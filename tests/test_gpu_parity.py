@@ -485,6 +485,62 @@ def test_split_batch_equals_one_handle(ea, parts, E, n):
     whole.close()
 
 
+@pytest.mark.parametrize("n,E,wrap_kw,parts", [
+    (60, 512, dict(positions="grav", alpha=3), 2),                            # CU-wide one-wave envs, forced (the batch would not ask for it)
+    (60, 4096, dict(positions="grav", alpha=3), -1),                          # BASELINE config 2: the automatic choice IS two parts
+    (200, 64, dict(positions="grav", alpha=3), 2),                            # four-wave envs
+    (60, 100, dict(positions="rel", statuses="ohe", type="Box"), 2),          # 256-thread workgroups, generic observation
+    (20, 90, dict(positions="abs", statuses="cat", type="Dict"), 2),          # sub-wave kernels (their own rollout scaffolding)
+])
+def test_two_parts_on_the_handles_own_streams_equal_one_kernel(ea, n, E, wrap_kw, parts):
+    """evac_options_t.parts = 2: ONE handle, ONE slab, evac_rollout issued as two half-batch kernels on two
+    streams the handle owns; bit-identical to the single-kernel handle over several launches with an autoreset among them, with
+    RandomAgent and with given actions; evac_join orders the caller's stream behind both; every other call joins by itself."""
+    import torch
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=25, is_new_exiting_reward=True, is_new_followers_reward=True)
+    wrap = ea.EnvWrappersConfig(**wrap_kw)
+    one = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=9, options=ea.KernelOptions(parts=1))
+    two = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=9, options=ea.KernelOptions(parts=parts))
+    assert one.num_parts == 1 and one.part_streams() == [] and "streams" not in one.kernel_variant()
+    assert two.num_parts == 2 and two.resolved_options().parts == 2 and two.kernel_variant().endswith("x 2 streams")
+    s0, s1 = two.part_streams()
+    assert s0.cuda_stream != s1.cuda_stream and torch.cuda.current_stream().cuda_stream not in (s0.cuda_stream, s1.cuda_stream)
+    one.reset(); two.reset()
+    T, D = 10, one.obs_dim
+    out = {"slab": torch.empty((T, E, D + 3), device=two.device), "episode_stats": torch.zeros((T, E, two.stats_words), device=two.device)}
+    launch = two.rollout_launcher(T, out)
+    for j in range(4):                                   # 40 steps: every env is truncated and reset once
+        ref = one.rollout(T)
+        launch()                                         # (asynchronous to the current stream until join)
+        two.join()
+        torch.cuda.current_stream().synchronize()        # ONLY the caller's stream: it was made to wait for both parts
+        assert torch.equal(out["slab"], ref["slab"]), f"launch {j}"
+        done = (ref["terminated"] != 0) | (ref["truncated"] != 0)
+        assert torch.equal(out["episode_stats"][done], ref["episode_stats"][done]), f"launch {j}: episode records"
+        assert j != 2 or bool(done.any())
+    acts = torch.rand((7, E, 2), device=two.device) * 2 - 1
+    a, b = one.rollout(7, actions=acts), two.rollout(7, actions=acts)      # rollout() joins by itself
+    assert torch.equal(a["slab"], b["slab"])
+    # back-to-back launches without a join between them, then a call that is not a plain rollout: it joins by itself
+    o3 = {"slab": torch.empty((3, E, D + 3), device=two.device)}
+    l3 = two.rollout_launcher(3, o3)
+    for _ in range(5):
+        one.rollout(3)
+        l3()
+    sa, sb = one.get_state(), two.get_state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    # the per-step API and the diagnostic rollout face run as one kernel on the caller's stream, on the same state
+    act1 = torch.rand((E, 2), device=two.device) * 2 - 1
+    ra, rb = one.step(act1), two.step(act1)
+    for x, y in zip(ra[:4], rb[:4]):
+        assert torch.equal(x, y)
+    ca, cb = one.rollout(4, record_actions=True, capture_envs=2), two.rollout(4, record_actions=True, capture_envs=2)
+    assert torch.equal(ca["slab"], cb["slab"]) and torch.equal(ca["trajectory"], cb["trajectory"]) and torch.equal(ca["actions"], cb["actions"])
+    assert torch.equal(one.rollout(6)["slab"], two.rollout(6)["slab"])
+    one.close(); two.close()
+
+
 def test_full_size_invariants_c2(ea):
     """BASELINE config 2 (N=60 x 4096 envs, gravity obs): size-independent properties after a long
     on-device rollout -- walls, escaped pinned at the exit, status == classifier(position), step
@@ -849,17 +905,8 @@ def test_subwave_kernels_match_one_wave_per_env(ea, n, wrap_kw):
     E, T, seed = 11, 90, 2024                       # E not a multiple of the envs per wave / block
     cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=40, is_new_exiting_reward=True, intrinsic_reward_coef=0.5)
     wrap = ea.EnvWrappersConfig(**wrap_kw)
-    old = os.environ.get("EVAC_SUBWAVE")
-    try:
-        os.environ["EVAC_SUBWAVE"] = "1"
-        a = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed)
-        os.environ["EVAC_SUBWAVE"] = "0"
-        b = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed)
-    finally:
-        if old is None:
-            os.environ.pop("EVAC_SUBWAVE", None)
-        else:
-            os.environ["EVAC_SUBWAVE"] = old
+    a = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed, options=ea.KernelOptions(subwave=1))
+    b = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed, options=ea.KernelOptions(subwave=0))
     oa, _ = a.reset(); ob, _ = b.reset()
     torch.testing.assert_close(oa, ob, rtol=2e-6, atol=1e-6)
     ra = a.rollout(T, record_actions=True, capture_envs=E)

@@ -37,22 +37,10 @@ def ea():
     return evacuation_amd
 
 
-class _Env:
-    """Set environment switches of evac_create for the handles made inside the block."""
-
-    def __init__(self, **kv):
-        self.kv = kv
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        os.environ.update(self.kv)
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+def _Env(**kv):
+    """Create-time options (evac_options_t, by the names of their diagnostic switches) for the handles made inside the block."""
+    from evacuation_amd.options import from_switches, kernel_options
+    return kernel_options(from_switches(**kv))
 
 
 def oracle_episode(p, wrap, seed, gid, T):

@@ -19,17 +19,8 @@ def ea():
 
 
 def _make(ea, cfg, wrap, E, seed, cu_wide, schedule):
-    old = {k: os.environ.get(k) for k in ("EVAC_CU_WIDE", "EVAC_WORKSPACE")}
-    try:
-        os.environ["EVAC_CU_WIDE"] = "1" if cu_wide else "0"
-        os.environ["EVAC_WORKSPACE"] = "1" if schedule else "0"
-        return ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    return ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed,
+                                   options=ea.KernelOptions(cu_wide=1 if cu_wide else 0, workspace=bool(schedule)))
 
 
 @pytest.mark.parametrize("n,E,wrap_kw", [
@@ -136,15 +127,9 @@ def test_default_config_kernel_is_bit_identical(ea, n, E, cu_wide, box):
                        clip_action=bool(E % 3 == 0))
     wrap = ea.EnvWrappersConfig(positions="rel", statuses="ohe", type="Box") if box else ea.EnvWrappersConfig(positions="grav", alpha=3)
     envs = []
-    for spec in ("0", "1"):
-        old = {k: os.environ.get(k) for k in ("EVAC_SPECIALIZE", "EVAC_CU_WIDE")}
-        try:
-            os.environ["EVAC_SPECIALIZE"] = spec
-            os.environ["EVAC_CU_WIDE"] = "1" if cu_wide else "0"
-            envs.append(ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=21))
-        finally:
-            for k, v in old.items():
-                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    for spec in (0, 1):
+        envs.append(ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=21,
+                                            options=ea.KernelOptions(specialize=spec, cu_wide=1 if cu_wide else 0)))
     gen, spec = envs
     gen.reset(); spec.reset()
     for T in (40, 100, 3, 64):

@@ -19,15 +19,8 @@ def ea():
 
 
 def _make(ea, cfg, wrap, E, seed, team):
-    old = os.environ.get("EVAC_TEAM")
-    try:
-        os.environ["EVAC_TEAM"] = str(team)
-        return ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed)
-    finally:
-        if old is None:
-            os.environ.pop("EVAC_TEAM", None)
-        else:
-            os.environ["EVAC_TEAM"] = old
+    from evacuation_amd.options import current_default          # (inside a `with _env_var(...)` block: that block's options + the team size)
+    return ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed, options=current_default().replace(team=int(team)))
 
 
 @pytest.mark.parametrize("n,E,team,wrap_kw,ens", [
@@ -153,16 +146,9 @@ def test_workspace_binding_errors_and_sizes(ea):
 
 
 def _env_var(name, value):
-    class _Ctx:
-        def __enter__(self):
-            self.old = os.environ.get(name)
-            os.environ[name] = value
-        def __exit__(self, *a):
-            if self.old is None:
-                os.environ.pop(name, None)
-            else:
-                os.environ[name] = self.old
-    return _Ctx()
+    """The create-time option behind the diagnostic switch `name`, for the handles made inside the block."""
+    from evacuation_amd.options import from_switches, kernel_options
+    return kernel_options(from_switches(**{name: value}))
 
 
 def test_team_that_loses_a_member_is_reported_and_keeps_its_state(ea):

@@ -2,8 +2,6 @@
 the plain kernels (everything off), over random room sizes, batch sizes, observation modes, enslaving degrees, launch
 lengths, with and without caller-provided actions.  States, flags, episode records, observations and rewards must be
 bit-identical."""
-import os
-
 import numpy as np
 import pytest
 
@@ -22,18 +20,9 @@ def ea():
 
 
 def _make(ea, cfg, wrap, E, seed, **env):
-    old = {k: os.environ.get(k) for k in SWITCHES}
-    try:
-        for k in SWITCHES:
-            os.environ.pop(k, None)
-        os.environ.update({k: str(v) for k, v in env.items()})
-        return ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    from evacuation_amd.options import from_switches
+    assert set(env) <= set(SWITCHES)
+    return ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed, options=from_switches(**env))
 
 
 CASES = []

@@ -11,15 +11,8 @@ SW = ("EVAC_CU_WIDE", "EVAC_TEAM", "EVAC_WORKSPACE")
 
 
 def make(cfg, wrap, E, **env):
-    old = {k: os.environ.get(k) for k in SW}
-    for k in SW:
-        os.environ.pop(k, None)
-    os.environ.update({k: str(v) for k, v in env.items()})
-    try:
-        return ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=123)
-    finally:
-        for k, v in old.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    from evacuation_amd.options import from_switches       # (create-time options by the names of their diagnostic switches)
+    return ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=123, options=from_switches(**env))
 
 
 ok = True

@@ -24,13 +24,11 @@ def run(name, envs, streams):
         print(f"{name}: sweep {rep}: {dt * 1e6 / n:6.2f} us per {T} steps of {tot} envs = {tot * 2000 / dt:.3e} env-steps/s  [{envs[0].kernel_variant('rollout')}]", flush=True)
 s1 = torch.cuda.current_stream(); s2 = side_stream(torch.device("cuda:0"), beside=s1)
 run("one handle, 4096 envs, one stream        ", [ea.BatchedEvacuationEnv(cfg, wrap, num_envs=4096, seed=1)], [s1])
-os.environ["EVAC_CU_WIDE"] = "1"
-halves = [ea.BatchedEvacuationEnv(cfg, wrap, num_envs=2048, seed=1, env_id_offset=o) for o in (0, 2048)]
+halves = [ea.BatchedEvacuationEnv(cfg, wrap, num_envs=2048, seed=1, env_id_offset=o, options=ea.KernelOptions(cu_wide=1)) for o in (0, 2048)]
 run("two handles of 2048 envs, one stream     ", halves, [s1, s1])
 run("two handles of 2048 envs, two streams    ", halves, [s1, s2])
-os.environ["EVAC_CU_WIDE"] = "0"
-halves = [ea.BatchedEvacuationEnv(cfg, wrap, num_envs=2048, seed=1, env_id_offset=o) for o in (0, 2048)]
+halves = [ea.BatchedEvacuationEnv(cfg, wrap, num_envs=2048, seed=1, env_id_offset=o, options=ea.KernelOptions(cu_wide=0)) for o in (0, 2048)]
 run("... 256-thread workgroups, two streams   ", halves, [s1, s2])
-quarters = [ea.BatchedEvacuationEnv(cfg, wrap, num_envs=1024, seed=1, env_id_offset=o) for o in (0, 1024, 2048, 3072)]
+quarters = [ea.BatchedEvacuationEnv(cfg, wrap, num_envs=1024, seed=1, env_id_offset=o, options=ea.KernelOptions(cu_wide=0)) for o in (0, 1024, 2048, 3072)]
 s3 = side_stream(torch.device("cuda:0"), beside=s2); s4 = torch.cuda.Stream()
 run("... four handles of 1024, four streams   ", quarters, [s1, s2, s3, s4])

@@ -1,0 +1,68 @@
+"""The headline geometry in its STEADY STATE (episode phases mixed: tools/phase_drift.py), 20 steps per launch:
+  a) one handle, one kernel per launch          b) one handle, two parts on its own streams
+  c) TWO independent 4096-env batches alternating on two streams (what filling every CU all the time is worth)
+  d) 65 536 envs in one handle (the chip's throughput bound for this kernel: 16 rounds of workgroups per launch)
+Every batch is first run for `warm` sweeps so that its envs' phases have spread.  GPU box: python tools/steady_probe.py [warm] [K]"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import evacuation_amd as ea
+from evacuation_amd.distributed import side_stream
+
+WARM = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+cfg = ea.EnvConfig(number_of_pedestrians=60, is_new_exiting_reward=True, is_new_followers_reward=True, max_timesteps=2000)
+wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
+dev = torch.device("cuda:0")
+
+
+def make(E, seed, **opt):
+    env = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=seed, options=ea.KernelOptions(**opt))
+    env.reset()
+    out = {"slab": torch.empty((T, E, env.obs_dim + 3), device=dev), "episode_stats": torch.zeros((T, E, env.stats_words), device=dev)}
+    return env, out
+
+
+def timed(name, envs_launch, joins, E_total, sweeps=12, warm=WARM):
+    n = 2000 // T
+    res = []
+    for sw in range(warm + sweeps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            for go in envs_launch:
+                go()
+        for j in joins:
+            j()
+        e1.record()
+        torch.cuda.synchronize()
+        if sw in (0, 1, 2) or sw >= warm:
+            res.append(e0.elapsed_time(e1))
+        if sw in (0, 1, 2):
+            print(f"   {name}: sweep {sw}: {res[-1] * 1e3 / n:6.2f} us per {T}-step round", flush=True)
+    tail = sorted(res[3:])
+    med = tail[len(tail) // 2]
+    print(f"{name}: synchronised phases (first sweeps) {sorted(res[:3])[1] * 1e3 / n:6.2f} us per round -> steady state (after {warm} sweeps) "
+          f"{med * 1e3 / n:6.2f} us per round = {E_total * 2000 / (med * 1e-3):.3e} env-steps/s", flush=True)
+
+
+which = sys.argv[3] if len(sys.argv) > 3 else "abcd"
+if "a" in which:
+    env, out = make(4096, 0x5EED0001, parts=1)
+    timed("a) one handle, one kernel per launch      ", [env.rollout_launcher(T, out)], [env.join], 4096)
+    env.close()
+if "b" in which:
+    env, out = make(4096, 0x5EED0001, parts=2)
+    timed("b) one handle, two parts (own streams)    ", [env.rollout_launcher(T, out)], [env.join], 4096)
+    env.close()
+if "c" in which:
+    s1 = torch.cuda.current_stream(); s2 = side_stream(dev, beside=s1)
+    (ea_, oa), (eb, ob) = make(4096, 1, parts=1), make(4096, 2, parts=1)
+    la, lb = ea_.rollout_launcher(T, oa, stream=s1), eb.rollout_launcher(T, ob, stream=s2)
+    timed("c) TWO batches of 4096 on two streams     ", [la, lb], [lambda: s1.wait_stream(s2)], 8192)
+    ea_.close(); eb.close()
+if "d" in which:
+    env, out = make(65536, 3, parts=1)
+    timed("d) 65 536 envs, one handle                ", [env.rollout_launcher(T, out)], [env.join], 65536, sweeps=5, warm=min(WARM, 250))
+    env.close()

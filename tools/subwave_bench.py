@@ -7,9 +7,8 @@ import evacuation_amd as ea
 for n, E in ((10, 16384), (16, 16384), (30, 8192), (32, 8192)):
     row = []
     for flag in ("0", "1"):
-        os.environ["EVAC_SUBWAVE"] = flag
         env = ea.BatchedEvacuationEnv(ea.EnvConfig(number_of_pedestrians=n, is_new_exiting_reward=True),
-                                      ea.EnvWrappersConfig(positions="grav", alpha=3), num_envs=E, seed=1)
+                                      ea.EnvWrappersConfig(positions="grav", alpha=3), num_envs=E, seed=1, options=ea.KernelOptions(subwave=int(flag)))
         env.reset()
         out = env.rollout(100)
         env.rollout(100, out=out); torch.cuda.synchronize()

@@ -7,12 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import evacuation_amd as ea
 
 def make(E, team, seed=3):
-    os.environ["EVAC_TEAM"] = str(team)
-    try:
-        return ea.BatchedEvacuationEnv(ea.EnvConfig(number_of_pedestrians=1024, is_new_exiting_reward=True, is_new_followers_reward=True, max_timesteps=2000),
-                                       ea.EnvWrappersConfig(positions="rel", statuses="ohe", type="Box"), num_envs=E, seed=seed)
-    finally:
-        os.environ.pop("EVAC_TEAM")
+    return ea.BatchedEvacuationEnv(ea.EnvConfig(number_of_pedestrians=1024, is_new_exiting_reward=True, is_new_followers_reward=True, max_timesteps=2000),
+                                   ea.EnvWrappersConfig(positions="rel", statuses="ohe", type="Box"), num_envs=E, seed=seed,
+                                   options=ea.KernelOptions(team=int(team)))
 
 def us_per_step(env, T=100, reps=3):
     out = env.rollout(T)

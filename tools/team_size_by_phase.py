@@ -12,9 +12,9 @@ import evacuation_amd as ea  # noqa: E402
 
 
 def run(team, E=32, N=1024, inner=100, episodes=3):
-    os.environ["EVAC_TEAM"] = str(team)
     env = ea.BatchedEvacuationEnv(ea.EnvConfig(number_of_pedestrians=N, max_timesteps=2000),
-                                  ea.EnvWrappersConfig(positions="rel", statuses="ohe", type="Box"), num_envs=E, seed=1)
+                                  ea.EnvWrappersConfig(positions="rel", statuses="ohe", type="Box"), num_envs=E, seed=1,
+                                  options=ea.KernelOptions(team=int(team)))
     env.reset()
     out = env.rollout(inner)
     n = 2000 // inner
