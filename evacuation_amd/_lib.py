@@ -34,7 +34,7 @@ class EvacConfig(C.Structure):
 
 class EvacOptions(C.Structure):
     """evac_options_t: which kernels a handle launches (never what they compute); -1 = automatic"""
-    _fields_ = [(f, C.c_int32) for f in ("subwave", "cells", "cu_wide", "team", "specialize", "parts", "team_coop", "team_fault")]
+    _fields_ = [(f, C.c_int32) for f in ("subwave", "cells", "cu_wide", "team", "specialize", "parts", "team_coop", "team_fault", "chain")]
 
 
 class EvacError(RuntimeError):
@@ -56,6 +56,7 @@ SIGNATURES = {
     "evac_get_options": (C.c_int, [_P, C.POINTER(EvacOptions)]),
     "evac_join": (C.c_int, [_P, _P]),
     "evac_num_parts": (C.c_int32, [_P]),
+    "evac_own_streams": (C.c_int32, [_P]),
     "evac_part_stream": (_P, [_P, C.c_int32]),
     "evac_destroy": (C.c_int, [_P]),
     "evac_obs_dim": (C.c_int64, [_P]),

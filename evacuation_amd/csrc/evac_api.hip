@@ -95,6 +95,20 @@ struct evac_handle {
     hipEvent_t part_done[2], fork_ev;
     bool parts_pending;       // the part streams hold work the caller's stream has not been made to wait for (evac_join)
     evac_options_t opt;       // as resolved at creation (evac_get_options)
+    // evac_options_t.chain = 1: rollout launch g goes to part_stream[g & 1] and waits PER ENV for launch g - 1 on the device
+    // (include/evac.h, evac_common.h ChainArgs).  The schedule is four deep here: launch g reads perm[g & 3], leaves its loads in
+    // moving[g & 3] and deals perm[(g + 2) & 3] -- read by the next launch of ITS stream -- from moving[(g - 2) & 3], the last
+    // launch of its stream: everything a launch reads was written by a launch its queue has completed.
+    bool chain;               // (requested and possible; used only with the workspace bound)
+    bool chain_bound;
+    int chain_gen;            // rollout launches of the chain so far = the generation the next launch waits for
+    int chain_start;          // the launch at which the chain (re)started: deals begin two launches later
+    bool chain_restart;       // the state was written by something else than the chain's last launch: fill the generation words first
+    int32_t* chain_sched;     // moving[4][E] | perm[4][E]
+    char* chain_xchg;         // [E] exchange records (evac_common.h): the state between the chain's launches
+    unsigned* chain_abort;    // device word: a wait timed out
+    bool chain_dirty;         // the records are ahead of the caller's state arrays (k_chain_export at the next join)
+    hipEvent_t chain_ev;
 };
 
 namespace {
@@ -107,6 +121,12 @@ int fail(evac_handle_t h, int code, const std::string& msg) {
 // A team rollout of this handle lost a member (evac_team.h): the outputs of that launch are void.  Sticky until
 // evac_team_clear_error; the handle runs the one-workgroup-per-env kernels from then on.
 int team_aborted(evac_handle_t h, const char* what) {
+    if (h->team_flag_host && *h->team_flag_host != 0u && h->chain) {
+        h->chain = false;
+        return fail(h, EVAC_ERR_TEAM_ABORTED,
+                    std::string(what) + ": a chained rollout launch waited in vain for an env's state (a launch of the chain was lost); the "
+                    "outputs since are void -- call evac_team_clear_error(), then reset or restore the batch; the handle issues plain launches from now on");
+    }
     if (h->team_flag_host && *h->team_flag_host != 0u) {
         h->team_k = 0;
         return fail(h, EVAC_ERR_TEAM_ABORTED,
@@ -276,6 +296,14 @@ int create_impl(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
     h->part_stream[0] = h->part_stream[1] = nullptr;
     h->part_done[0] = h->part_done[1] = h->fork_ev = nullptr;
     h->parts_pending = false;
+    h->chain = h->chain_bound = false;
+    h->chain_gen = h->chain_start = 1;          // (never 0: a zero-filled workspace must not look like a published generation)
+    h->chain_restart = true;
+    h->chain_sched = nullptr;
+    h->chain_xchg = nullptr;
+    h->chain_abort = nullptr;
+    h->chain_dirty = false;
+    h->chain_ev = nullptr;
     const int o_subwave = option_value("EVAC_SUBWAVE", o.subwave), o_cells = option_value("EVAC_CELLS", o.cells);
     const int o_cu_wide = option_value("EVAC_CU_WIDE", o.cu_wide), o_team = option_value("EVAC_TEAM", o.team);
     const int o_specialize = option_value("EVAC_SPECIALIZE", o.specialize);
@@ -418,8 +446,9 @@ int create_impl(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
         if (h->team_k) fam = h->team_k == 16 ? evac::Team<16>::kName : (h->team_k == 8 ? evac::Team<8>::kName : (h->team_k == 4 ? evac::Team<4>::kName : evac::Team<2>::kName));
         h->variant[2] = std::string("k_rollout") + kind + fam + (grav ? ", grav obs>" : ", generic obs>");
     }
+    if (!h->team_k) h->team_fault = o_team_fault == 1;       // (chained launches: fault injection of their own, evac_rollout)
     h->opt = evac_options_t{h->sub_lanes ? 1 : 0, h->cells ? 1 : 0, (h->cu_wide || h->cu_wide4) ? 1 : 0, h->team_k, h->default_cfg ? 1 : 0,
-                            1, h->team_coop ? 1 : 0, h->team_fault ? 1 : 0};
+                            1, h->team_coop ? 1 : 0, h->team_fault ? 1 : 0, 0};
     *out = h;
     return EVAC_OK;
 }
@@ -491,20 +520,27 @@ void destroy_parts(evac_handle* h) {
         h->part_stream[k] = nullptr; h->part_done[k] = nullptr; h->part[k] = nullptr;
     }
     if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
-    h->fork_ev = nullptr;
+    if (h->chain_ev) (void)hipEventDestroy(h->chain_ev);
+    h->fork_ev = h->chain_ev = nullptr;
+    h->chain = false;
     h->n_parts = 1;
     h->parts_pending = false;
 }
 // `stream` waits for everything the part streams have been given so far (evac_join; implied by every call that is not a plain rollout)
 int join_parts(evac_handle* h, hipStream_t stream) {
-    if (h->n_parts < 2 || !h->parts_pending) return EVAC_OK;
+    if (!h->part_stream[0] || !h->parts_pending) return EVAC_OK;
     DeviceGuard g(h->device);
-    for (int k = 0; k < h->n_parts; ++k)
+    for (int k = 0; k < 2; ++k)
         if (hipEventRecord(h->part_done[k], h->part_stream[k]) != hipSuccess || hipStreamWaitEvent(stream, h->part_done[k], 0) != hipSuccess) {
             (void)hipGetLastError();
             return fail(h, EVAC_ERR_HIP, "evac_join: event record / wait failed");
         }
     h->parts_pending = false;
+    if (h->chain && h->chain_dirty && h->chain_xchg) {     // the chain's launches kept the state in the exchange records: back to the caller's arrays
+        hipLaunchKernelGGL(evac::k_chain_export, dim3((unsigned)((h->p.n_envs + 3) / 4)), dim3(256), 0, stream, h->p, (const char*)h->chain_xchg);
+        h->chain_dirty = false;
+        if (hipGetLastError() != hipSuccess) return fail(h, EVAC_ERR_HIP, "evac_join: export of the chain's state failed");
+    }
     return EVAC_OK;
 }
 }  // namespace
@@ -523,10 +559,42 @@ int evac_create_ex(const evac_config_t* cfg, int32_t num_envs, int32_t device, u
     const int32_t* f = &o.subwave;
     for (int k = 0; k < (int)(sizeof(o) / sizeof(int32_t)); ++k)
         if (f[k] < -1 || f[k] > 16) { g_create_error = "evac_options_t: every field must be -1 (automatic) or a small non-negative value"; if (out) *out = nullptr; return EVAC_ERR_INVALID_ARGUMENT; }
+    if (!options) o.chain = 0;
     if (o.parts == 0 || o.parts > 2) { g_create_error = "evac_options_t.parts must be -1, 1 or 2"; if (out) *out = nullptr; return EVAC_ERR_INVALID_ARGUMENT; }
+    if (o.chain > 1) { g_create_error = "evac_options_t.chain must be -1, 0 or 1"; if (out) *out = nullptr; return EVAC_ERR_INVALID_ARGUMENT; }
     const int rc = create_impl(cfg, num_envs, device, seed, env_id_offset, o, out);
     if (rc != EVAC_OK) return rc;
     evac_handle* h = *out;
+    // Chained launches (include/evac.h): the CU-wide kernels of one-wave envs, whole workgroups only (a wave that gives up must not
+    // leave others at a barrier: that family has none), and a host-mapped error word like the teams'.  Wins over parts.
+    const int chain_opt = option_value("EVAC_CHAIN", o.chain);
+    if (chain_opt != 0 && h->cu_wide && num_envs % 16 == 0 && num_envs >= 32) {
+        bool ok = make_part_streams(h);
+        {
+            DeviceGuard g(device);
+            void* host = nullptr;
+            void* dev = nullptr;
+            ok = ok && hipEventCreateWithFlags(&h->chain_ev, hipEventDisableTiming) == hipSuccess;
+            if (ok && (hipHostMalloc(&host, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dev, host, 0) != hipSuccess)) {
+                if (host) (void)hipHostFree(host);
+                ok = false;
+            }
+            if (ok) {
+                std::memset(host, 0, 64);
+                h->team_flag_host = (volatile unsigned*)host;
+                h->team_flag_dev = (unsigned*)dev;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (ok) {
+            h->chain = true;
+            h->opt.chain = 1;
+            h->variant[3] = h->variant[1] + ", chained launches on 2 streams";
+            return EVAC_OK;
+        }
+        destroy_parts(h);                              // (no second queue: plain launches)
+    }
     // Two parts: where it pays by itself (-1) -- CU-wide rollouts whose halves are whole CU-wide workgroups; the halves keep the
     // CU-wide form although each alone would not fill the device (pace keeping and the in-kernel deal are what they are to keep) --
     // or on request (2) for every handle but the teams' (their grids run one at a time: evac_rollout).
@@ -537,6 +605,7 @@ int evac_create_ex(const evac_config_t* cfg, int32_t num_envs, int32_t device, u
     if (!(can && (parts_opt == 2 || (parts_opt < 0 && pays)))) return EVAC_OK;
     evac_options_t po = h->opt;                        // the parts take the parent's resolved choices
     po.parts = 1;
+    po.chain = 0;
     const int32_t half = num_envs / 2;
     bool ok = make_part_streams(h);
     for (int k = 0; ok && k < 2; ++k) {
@@ -563,18 +632,19 @@ int evac_join(evac_handle_t h, void* stream) {
     return join_parts(h, (hipStream_t)stream);
 }
 int32_t evac_num_parts(evac_handle_t h) { return h ? h->n_parts : -1; }
-void* evac_part_stream(evac_handle_t h, int32_t part) { return (h && h->n_parts > 1 && part >= 0 && part < h->n_parts) ? (void*)h->part_stream[part] : nullptr; }
+int32_t evac_own_streams(evac_handle_t h) { return h ? ((h->n_parts > 1 || h->chain) && h->part_stream[0] ? 2 : 0) : -1; }
+void* evac_part_stream(evac_handle_t h, int32_t part) { return (h && evac_own_streams(h) == 2 && part >= 0 && part < 2) ? (void*)h->part_stream[part] : nullptr; }
 
 const char* evac_kernel_variant(evac_handle_t h, int32_t rollout) {
     if (!h) return "";
     if (!rollout) return h->variant[0].c_str();
-    if (h->n_parts > 1) return h->variant[3].c_str();
+    if (h->n_parts > 1 || (h->chain && h->chain_bound)) return h->variant[3].c_str();
     // the path evac_rollout takes right now: teams only with their exchange areas bound and a grid that fits the device
     return h->variant[(h->team_k && h->team_bound && h->team_fit != 0) ? 2 : 1].c_str();
 }
 
 int evac_destroy(evac_handle_t h) {
-    if (h && (h->n_parts > 1 || h->part_stream[0])) destroy_parts(h);
+    if (h && (h->n_parts > 1 || h->part_stream[0] || h->chain)) destroy_parts(h);
     if (h && h->team_flag_host) {
         DeviceGuard g(h->device);
         (void)hipHostFree((void*)h->team_flag_host);
@@ -604,6 +674,7 @@ int evac_bind_state(evac_handle_t h, float* ped, uint8_t* status, float* agent, 
     h->p.clock = (int4*)clock;
     h->p.acc = (float4*)acc;
     h->bound = true;
+    h->chain_restart = true;
     for (int k = 0; k < (h->n_parts > 1 ? h->n_parts : 0); ++k) {      // the parts: the same buffers from their first env on
         const size_t first = (size_t)k * (size_t)h->part[k]->p.n_envs, N = (size_t)h->p.n_ped;
         const int rc = evac_bind_state(h->part[k], ped + first * N * 4, status + first * N, agent + first * 4, clock + first * 4, acc + first * 4);
@@ -614,7 +685,7 @@ int evac_bind_state(evac_handle_t h, float* ped, uint8_t* status, float* agent, 
 
 namespace {
 struct WorkspaceLayout {
-    size_t sched, stats, team_rec, team_tile, team_xchg_end, total;
+    size_t sched, stats, team_rec, team_tile, team_xchg_end, chain_sched, chain_xchg, chain_abort, total;
 };
 WorkspaceLayout workspace_layout(const evac_handle* h) {
     const size_t E = (size_t)h->p.n_envs;
@@ -623,6 +694,11 @@ WorkspaceLayout workspace_layout(const evac_handle* h) {
     size_t o = 0;
     w.sched = o; o = up(o + 4 * E * sizeof(int32_t));          // moving[2][E] | perm[2][E]
     w.stats = o; o = up(o + 64);
+    if (h->chain) {                                            // moving[4][E] | perm[4][E] | the exchange records | the abort word
+        w.chain_sched = o; o = up(o + 8 * E * sizeof(int32_t));
+        w.chain_xchg = o; o = up(o + E * (size_t)evac::kXchgBytes);
+        w.chain_abort = o; o = up(o + 128);
+    }
     if (h->team_k) {
         w.team_rec = o; o = up(o + evac::kTeamSets * E * 32 * 16);          // (two slot sets: evac_team.h, exchange)
         w.team_tile = o; o = up(o + evac::kTeamSets * E * 1024 * 16);
@@ -645,6 +721,12 @@ int evac_bind_workspace(evac_handle_t h, void* workspace, int64_t bytes) {
     h->sched = nullptr;
     h->sched_gen = -1;
     h->team_bound = false;
+    if (h->chain && (h->parts_pending || h->chain_dirty)) {      // (the chain's launches in flight still use the old workspace, and the state lives in it)
+        DeviceGuard g(h->device);
+        (void)join_parts(h, nullptr);
+        (void)hipDeviceSynchronize();
+    }
+    h->chain_bound = false;
     if (h->n_parts > 1) {
         // the parts schedule themselves: each gets a slice (moving[2][E/2] | perm[2][E/2] of its own); this handle's own rollouts --
         // the diagnostic face only -- run without a schedule
@@ -665,6 +747,15 @@ int evac_bind_workspace(evac_handle_t h, void* workspace, int64_t bytes) {
     if ((uintptr_t)workspace & 255u) return fail(h, EVAC_ERR_INVALID_ARGUMENT, "evac_bind_workspace: workspace must be 256-byte aligned");
     char* base = (char*)workspace;
     h->sched = (int32_t*)(base + w.sched);
+    h->chain_bound = false;
+    if (h->chain) {
+        h->chain_sched = (int32_t*)(base + w.chain_sched);
+        h->chain_xchg = base + w.chain_xchg;
+        h->chain_abort = (unsigned*)(base + w.chain_abort);
+        h->chain_dirty = false;
+        h->chain_bound = true;
+        h->chain_restart = true;
+    }
     if (h->team_k) {
         h->p.team_err = h->team_flag_dev;           // (host-mapped memory of the handle, not part of the workspace)
         h->p.team_rec = base + w.team_rec;
@@ -692,6 +783,10 @@ void deal_now(evac_handle_t h, hipStream_t s, bool both) {
 
 int evac_reschedule(evac_handle_t h, void* stream) {
     if (!h) return EVAC_ERR_INVALID_ARGUMENT;
+    if (h->chain) {                                    // (the chain deals itself again when it restarts)
+        h->chain_restart = true;
+        return join_parts(h, (hipStream_t)stream);
+    }
     if (h->n_parts > 1) {                              // (on the caller's stream, behind everything the parts have been given)
         if (const int rc = join_parts(h, (hipStream_t)stream); rc != EVAC_OK) return rc;
         for (int k = 0; k < h->n_parts; ++k)
@@ -759,7 +854,7 @@ int evac_team_error_nosync(evac_handle_t h, int32_t* out) {
 int evac_team_clear_error(evac_handle_t h) {
     if (!h) return EVAC_ERR_INVALID_ARGUMENT;
     if (h->team_flag_host) {
-        if (*h->team_flag_host != 0u) h->team_k = 0;      // the handle stays on one workgroup per env
+        if (*h->team_flag_host != 0u) { h->team_k = 0; h->chain = false; }     // the handle stays on one workgroup per env / on plain launches
         *h->team_flag_host = 0u;
     }
     return EVAC_OK;
@@ -771,6 +866,7 @@ int evac_team_clear_error(evac_handle_t h) {
     if (!(h)->bound) return fail((h), EVAC_ERR_NOT_BOUND, name ": call evac_bind_state first"); \
     if (const int ta_ = team_aborted((h), name); ta_ != EVAC_OK) return ta_
 #define EVAC_JOIN_FIRST(h, stream)                                                \
+    (h)->chain_restart = true;      /* (whatever follows may write the state: the chain starts afresh behind it) */ \
     if ((h)->parts_pending)                                                       \
         if (const int jn_ = join_parts((h), (hipStream_t)(stream)); jn_ != EVAC_OK) return jn_
 
@@ -854,6 +950,63 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
         }
         return EVAC_OK;
     }
+    if (h->chain && h->chain_bound && !(capture || actions_out || noise)) {
+        hipStream_t s_ = (hipStream_t)stream;
+        hipStreamCaptureStatus ccap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s_, &ccap) != hipSuccess) { (void)hipGetLastError(); ccap = hipStreamCaptureStatusNone; }
+        if (ccap == hipStreamCaptureStatusNone) {
+            // CHAINED: launch g on stream g & 1, ordered per env on the device (include/evac.h).  Both streams start behind what the
+            // caller's stream holds -- only if it holds anything: a barrier packet costs more than the chain gains.
+            using FW = evac::Wave<1, 1024>;
+            const int E = h->p.n_envs, c = h->chain_gen;
+            hipStream_t S = h->part_stream[c & 1], O = h->part_stream[(c + 1) & 1];
+            const bool fork = h->chain_restart || hipStreamQuery(s_) != hipSuccess;
+            (void)hipGetLastError();
+            if (fork) {
+                if (hipEventRecord(h->fork_ev, s_) != hipSuccess || hipStreamWaitEvent(S, h->fork_ev, 0) != hipSuccess ||
+                    hipStreamWaitEvent(O, h->fork_ev, 0) != hipSuccess) { (void)hipGetLastError(); return fail(h, EVAC_ERR_HIP, "evac_rollout: fork of the chain failed"); }
+            }
+            int32_t* moving = h->chain_sched;
+            int32_t* perm = h->chain_sched + 4 * (size_t)E;
+            if (h->chain_restart) {
+                // the state in memory is whatever the caller's stream left: every env at generation c, one deal in all four
+                // permutation buffers, the other stream behind both
+                hipLaunchKernelGGL(evac::k_chain_import, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, S, h->p, h->chain_xchg, c, h->chain_abort);
+                hipLaunchKernelGGL(evac::k_schedule, dim3(1), dim3(1024), 0, S, E, (const int*)(moving + ((c + 3) & 3) * (size_t)E),
+                                   perm + (c & 3) * (size_t)E, (int32_t*)nullptr, 16, 1);
+                hipLaunchKernelGGL(evac::k_copy_perm3, dim3(64), dim3(256), 0, S, E, (const int*)(perm + (c & 3) * (size_t)E),
+                                   perm + ((c + 1) & 3) * (size_t)E, perm + ((c + 2) & 3) * (size_t)E, perm + ((c + 3) & 3) * (size_t)E);
+                if (hipEventRecord(h->chain_ev, S) != hipSuccess || hipStreamWaitEvent(O, h->chain_ev, 0) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return fail(h, EVAC_ERR_HIP, "evac_rollout: restart of the chain failed");
+                }
+                h->chain_start = c;
+                h->chain_restart = false;
+            }
+            const bool deals = c - h->chain_start >= 2;          // (the loads of launch c - 2, the last launch of this stream)
+            const int32_t* deal_loads = deals ? moving + ((c + 2) & 3) * (size_t)E : nullptr;
+            int32_t* deal_perm = deals ? perm + ((c + 2) & 3) * (size_t)E : nullptr;
+            evac::ChainArgs ca{h->chain_xchg, c, h->chain_abort, h->team_flag_dev};
+            evac::Params pp = h->p;
+            if (h->team_fault && c == h->chain_start + 1) pp.n_envs = E - 16;        // fault injection: the last workgroup of ONE launch is never run
+#define EVAC_CHAIN_ARGS pp, (int)n_steps, (const float2*)actions, slab_out, final_stats, (const int*)(perm + (c & 3) * (size_t)E), (int*)(moving + (c & 3) * (size_t)E), (const int*)deal_loads, (int*)deal_perm, ca
+            const dim3 grid((unsigned)(E / FW::kEnvsPerBlock));
+            if (h->default_cfg && h->p.obs_pos == EVAC_POS_GRAV)
+                hipLaunchKernelGGL((evac::k_rollout_chain_default_config<FW, true>), grid, dim3(FW::kBlock), 0, S, EVAC_CHAIN_ARGS);
+            else if (h->default_cfg)
+                hipLaunchKernelGGL((evac::k_rollout_chain_default_config<FW, false>), grid, dim3(FW::kBlock), 0, S, EVAC_CHAIN_ARGS);
+            else if (h->p.obs_pos == EVAC_POS_GRAV)
+                hipLaunchKernelGGL((evac::k_rollout_chain<FW, true>), grid, dim3(FW::kBlock), 0, S, EVAC_CHAIN_ARGS);
+            else
+                hipLaunchKernelGGL((evac::k_rollout_chain<FW, false>), grid, dim3(FW::kBlock), 0, S, EVAC_CHAIN_ARGS);
+#undef EVAC_CHAIN_ARGS
+            h->chain_gen = c + 1;
+            h->parts_pending = true;
+            h->chain_dirty = true;
+            return check_launch(h, "evac_rollout (chained)");
+        }
+    }
+    h->chain_restart = true;
     if (h->parts_pending)
         if (const int jn = join_parts(h, (hipStream_t)stream); jn != EVAC_OK) return jn;
     if (capture || actions_out || noise)

@@ -714,6 +714,93 @@ __device__ __forceinline__ void store_env(const Params& p, int env, int i, bool 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// CHAINED rollout launches (evac_options_t.chain; rollout_body<..., CHAIN>): consecutive launches of one handle go to two
+// hardware queues alternately and OVERLAP -- a wave of launch g + 1 starts as soon as ITS env's state of launch g is in memory,
+// not when launch g's slowest env is done (the in-order queue's kernel boundary).  Launches that overlap share no kernel
+// boundary, so nothing flushes or invalidates caches between them, and the XCDs' L2s are not coherent with each other: the
+// state travels through an EXCHANGE RECORD per env in the caller's workspace, by the hand-off form measured valid on gfx950
+// without fences (MI355X_MICROARCH.md, inter-workgroup visibility: every store of the bytes `sc1` -- write-through, the line is
+// dropped from the writer's L2 --, each 128-byte line written WHOLE by one store instruction of one wave, the storing wave's
+// `s_waitcnt vmcnt(0)`, then its signal; every load of the bytes a `global_load ... sc1` to registers; nothing on the scalar
+// path).  The caller's own state arrays cannot serve: neighbouring envs share their lines (960 bytes of pedestrians, 60 status
+// bytes per env), and a line that two waves on two XCDs each write a part of came back wrong in 6 % of the envs
+// (tools/chain_debug.py on the first version).  A record's reader is also its next writer, and an `sc1` store drops the line,
+// so no L2 keeps a copy across launches.
+//   record(env), 12 lines of 128 bytes:  [0, 1024) (x, y, dx, dy) of lane i as one dwordx4 per lane (8 lines, one instruction)
+//                                         [1024, 1280) status of lane i as a dword (2 lines, one instruction)
+//                                         [1280, 1408) leader | clock | episode sums, 16 bytes each, by lanes 0..7 (1 line)
+//                                         [1408, 1536) dword 0: the GENERATION of the record (a line of its own: no false sharing)
+// Launch g waits for generation g, and publishes g + 1 behind its record stores.  k_chain_import fills the records from the
+// caller's arrays when a chain (re)starts; k_chain_export writes them back when the caller's stream joins (evac_join).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_dev(void* ptr, f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_dev_i32(void* ptr, int v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
+__device__ __forceinline__ void load_dev(f4& v, const void* ptr) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory"); }
+__device__ __forceinline__ void load_dev_i32(int& v, const void* ptr) { asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory"); }
+__device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ int load_dev_i32_now(const void* ptr) {      // (issued and waited for: a poll)
+    int v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+constexpr int kXchgBytes = 1536, kXchgStatus = 1024, kXchgEnv = 1280, kXchgGen = 1408;
+struct ChainArgs {
+    char* xchg;          // [E] exchange records (kXchgBytes each, 128-byte aligned)
+    int gen;             // this launch: waits for generation `gen`, publishes `gen + 1`
+    unsigned* abort;     // device word (workspace, a line of its own): a wait of some launch timed out -- every later wait gives up at once
+    unsigned* err;       // the handle's host-mapped error word (as the teams')
+};
+constexpr int kChainMaxPolls = 1 << 19;     // bounded wait: ~0.3 s of polls with the back-off below; a launch that gives up voids the run
+// Wait until the env's record holds generation `gen`.  Wave-uniform (all lanes poll the same word).  false: timed out.
+__device__ __forceinline__ bool chain_wait(const ChainArgs& ch, int env) {
+    const char* addr = ch.xchg + (size_t)env * kXchgBytes + kXchgGen;
+    int pause = 0;
+    for (int polls = 0; polls < kChainMaxPolls; ++polls) {
+        const int v = __builtin_amdgcn_readfirstlane(load_dev_i32_now(addr));
+        if (v == ch.gen) return true;
+        if ((polls & 255) == 255 && __builtin_amdgcn_readfirstlane(load_dev_i32_now(ch.abort)) != 0) return false;
+        // back off: the first polls come fast (a hand-off in flight); a long wait -- a workgroup dispatched well before its
+        // heavy env is done -- must not keep the fabric busy (many pollers slow everybody's round trips: evac_team.h)
+        if (pause < 4) __builtin_amdgcn_s_sleep(2); else if (pause < 16) __builtin_amdgcn_s_sleep(6); else __builtin_amdgcn_s_sleep(20);
+        pause += 1;
+    }
+    return false;
+}
+__device__ __forceinline__ void chain_give_up(const ChainArgs& ch, int lane) {
+    if (lane == 0) {
+        store_dev_i32(ch.abort, 1);
+        __hip_atomic_store(ch.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// the env's record -> registers (every lane loads; the per-env words come from lanes 0..2 of the env-word line)
+__device__ __forceinline__ void load_record(const char* rec, int lane, bool active, Ped& q, Env& e) {
+    f4 v, w;
+    int st;
+    load_dev(v, rec + lane * 16);
+    load_dev_i32(st, rec + kXchgStatus + lane * 4);
+    load_dev(w, rec + kXchgEnv + (lane & 7) * 16);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v), "+v"(w), "+v"(st)::"memory");
+    const float wx = w.x, wy = w.y, wz = w.z, ww = w.w;
+    e.ax = readlane_const<0>(wx); e.ay = readlane_const<0>(wy); e.adx = readlane_const<0>(wz); e.ady = readlane_const<0>(ww);
+    e.now = __builtin_bit_cast(int, readlane_const<1>(wx)); e.n_resets = __builtin_bit_cast(int, readlane_const<1>(wy));
+    e.total = __builtin_bit_cast(uint32_t, readlane_const<1>(wz));
+    e.acc_ret = readlane_const<2>(wx); e.acc_intr = readlane_const<2>(wy); e.acc_stat = readlane_const<2>(wz);
+    q.x = active ? v.x : 0.0f; q.y = active ? v.y : 0.0f; q.dx = active ? v.z : 0.0f; q.dy = active ? v.w : 0.0f;
+    q.st = active ? st : 0;
+}
+// registers -> the env's record: three store instructions, every line written whole by one of them (all 64 lanes store)
+__device__ __forceinline__ void store_record(char* rec, int lane, bool active, const Ped& q, const Env& e) {
+    store_dev(rec + lane * 16, active ? f4{q.x, q.y, q.dx, q.dy} : f4{0.0f, 0.0f, 0.0f, 0.0f});
+    store_dev_i32(rec + kXchgStatus + lane * 4, active ? q.st : 0);
+    if (lane < 8) {
+        const f4 a = f4{e.ax, e.ay, e.adx, e.ady};
+        const f4 c = f4{__builtin_bit_cast(float, e.now), __builtin_bit_cast(float, e.n_resets), __builtin_bit_cast(float, (int)e.total), 0.0f};
+        const f4 k = f4{e.acc_ret, e.acc_intr, e.acc_stat, 0.0f};
+        store_dev(rec + kXchgEnv + lane * 16, lane == 0 ? a : (lane == 1 ? c : (lane == 2 ? k : f4{0.0f, 0.0f, 0.0f, 0.0f})));
+    }
+}
+
 // the episode record: env.py:115-125 (nine keys) + Time.n_episodes
 __device__ __forceinline__ void write_stats(evac_episode_stats_t* dst, const Env& e, const StepOut& o) {
     dst->episode_reward = e.acc_ret;

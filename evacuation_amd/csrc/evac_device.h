@@ -563,12 +563,15 @@ EVAC_STEP_KERNEL_DEFAULT(k_step_norm_default_config, true)
 // third of the step before: profiles/r01_e_*).
 // DIAG: the diagnostic face (trajectory capture, action recording, injected noise); the default face carries none
 // of that code.
-template <class F, bool GRAV, bool DIAG>
+// CHAIN: the launch is one of a chain of overlapping launches on two queues (evac_common.h, ChainArgs): every wave first waits
+// for ITS env's generation word, exchanges the state by device-scope accesses and publishes the next generation at its end.
+template <class F, bool GRAV, bool DIAG, bool CHAIN = false>
 __device__ __forceinline__ void rollout_body(
     typename F::Smem& sm, const Params& p, int n_steps, const float2* __restrict__ actions, float2* __restrict__ actions_out,
     float* __restrict__ slab_out, evac_episode_stats_t* __restrict__ final_stats, int capture_envs,
     float* __restrict__ capture, const float* __restrict__ noise_in, const int* __restrict__ perm = nullptr,
-    int* __restrict__ moving_out = nullptr, const int* __restrict__ deal_loads = nullptr, int* __restrict__ deal_perm = nullptr) {
+    int* __restrict__ moving_out = nullptr, const int* __restrict__ deal_loads = nullptr, int* __restrict__ deal_perm = nullptr,
+    ChainArgs chain = ChainArgs{nullptr, 0, nullptr, nullptr}) {
 #ifdef EVAC_STEP_TIMES
     unsigned long long mark_entry_, mark_loop_ = 0, mark_done_, mark_perm_, mark_init_, mark_act_, mark_state_;
 #define EVAC_MARK(M) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(M)::"memory")
@@ -590,7 +593,7 @@ __device__ __forceinline__ void rollout_body(
     const bool active = w.i < p.n_ped;
     Ped q;
     Env e;
-    load_env(p, w.env, w.i, active, q, e);
+    if constexpr (!CHAIN) load_env(p, w.env, w.i, active, q, e);
     // THE DEAL OF THE NEXT LAUNCH IS MADE INSIDE THIS ONE, by workgroup 0 before it starts stepping: it carries the lightest
     // envs of the batch (schedule_slot), which are done 20-30 % before the launch ends (tools/step_times.py) -- the ~3 us of the
     // sort disappear in that slack.  It sorts by the loads the PREVIOUS launch left (complete, unlike this launch's) into the
@@ -607,6 +610,16 @@ __device__ __forceinline__ void rollout_body(
             if (4 * lightest <= 3 * p.n_ped)
                 schedule_envs_by_workgroup(sm.deal_hist, (int)threadIdx.x, p.n_envs, deal_loads, deal_perm, F::kEnvsPerBlock, F::WPE == 1 ? 1 : 4);
         }
+    }
+    if constexpr (CHAIN) {
+        // (a chained launch deals -- above -- BEFORE it waits: the sort of workgroup 0 runs under the hand-off of its envs.  The
+        // permutation it writes is read two launches later, by the next launch of THIS queue: in order, no flag needed.)
+        static_assert(F::WPE == 1 && !F::kHelpers, "chained launches: one-wave envs (no barrier that a wave giving up could leave others at)");
+        if (!chain_wait(chain, w.env)) {      // (wave-uniform) the env's state never came: void run, the host is told
+            chain_give_up(chain, w.lane);
+            return;
+        }
+        load_record(chain.xchg + (size_t)w.env * kXchgBytes, w.lane, active, q, e);
     }
     const uint32_t gid = p.env_id_offset + (uint32_t)w.env;
     const size_t E = (size_t)p.slab_envs;
@@ -860,7 +873,14 @@ __device__ __forceinline__ void rollout_body(
     if constexpr (F::kHelpers) {
         if (F::aborted(w)) return;      // a team that lost a member: void results, the env keeps its pre-launch state
     }
-    store_env(p, w.env, w.i, active, w.owner, q, e);
+    if constexpr (CHAIN) {
+        char* rec = chain.xchg + (size_t)w.env * kXchgBytes;
+        store_record(rec, w.lane, active, q, e);
+        wait_vmem();                                       // every lane's record stores are acknowledged ...
+        if (w.lane == 0) store_dev_i32(rec + kXchgGen, chain.gen + 1);      // ... before the next launch's wave may load them
+    } else {
+        store_env(p, w.env, w.i, active, w.owner, q, e);
+    }
 #ifdef EVAC_STEP_TIMES
     if (w.lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && threadIdx.x < 1024 && n_steps > 0) {
         unsigned long long mark_exit_;
@@ -910,6 +930,69 @@ __global__ __launch_bounds__(F::kBlock, 4) void k_rollout_default_config(
     const Params q = default_config_constants<GRAV>(p);
     rollout_body<F, GRAV, false>(sm, q, n_steps, actions, nullptr, slab_out, final_stats, 0, nullptr, nullptr, perm, moving_out,
                                  deal_loads, deal_perm);
+}
+
+// Chained launches (evac_options_t.chain): the same two kernels with the generation hand-off of rollout_body<..., CHAIN>.
+template <class F, bool GRAV>
+__global__ __launch_bounds__(F::kBlock, 4) void k_rollout_chain(
+    Params p, int n_steps, const float2* __restrict__ actions, float* __restrict__ slab_out,
+    evac_episode_stats_t* __restrict__ final_stats, const int* __restrict__ perm, int* __restrict__ moving_out,
+    const int* __restrict__ deal_loads, int* __restrict__ deal_perm, ChainArgs chain) {
+    __shared__ typename F::Smem sm;
+    rollout_body<F, GRAV, false, true>(sm, p, n_steps, actions, nullptr, slab_out, final_stats, 0, nullptr, nullptr, perm, moving_out,
+                                       deal_loads, deal_perm, chain);
+}
+template <class F, bool GRAV>
+__global__ __launch_bounds__(F::kBlock, 4) void k_rollout_chain_default_config(
+    Params p, int n_steps, const float2* __restrict__ actions, float* __restrict__ slab_out,
+    evac_episode_stats_t* __restrict__ final_stats, const int* __restrict__ perm, int* __restrict__ moving_out,
+    const int* __restrict__ deal_loads, int* __restrict__ deal_perm, ChainArgs chain) {
+    __shared__ typename F::Smem sm;
+    const Params q = default_config_constants<GRAV>(p);
+    rollout_body<F, GRAV, false, true>(sm, q, n_steps, actions, nullptr, slab_out, final_stats, 0, nullptr, nullptr, perm, moving_out,
+                                       deal_loads, deal_perm, chain);
+}
+// (re)start of a chain: every env's generation word (device-scope stores, like the launches' own), and one permutation copied to
+// the three other buffers of the four-deep rotation
+// one wave per env: the caller's state arrays -> the env's exchange record at generation `gen` (a chain starts) ...
+__global__ __launch_bounds__(256) void k_chain_import(Params p, char* __restrict__ xchg, int gen, unsigned* __restrict__ abort_word) {
+    const int env = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) store_dev_i32(abort_word, 0);
+    if (env >= p.n_envs) return;
+    const bool active = lane < p.n_ped;
+    Ped q;
+    Env e;
+    load_env(p, env, lane, active, q, e);
+    char* rec = xchg + (size_t)env * kXchgBytes;
+    // PLAIN stores, made visible by the kernel boundary like any kernel's output.  (`sc1` stores here were wrong: the workspace comes
+    // zero-filled by plain stores, and in the first launch after an import ~1.5 of a record's 12 lines read back as zeros -- a copy a
+    // plain store left in some XCD's L2 is not refreshed by another XCD's write-through store; tools/chain_debug.py.  Inside the chain
+    // a record's reader is its next writer and its `sc1` store drops the line, so no such copy exists: 10^6 chained steps against the
+    // plain kernels, with restarts and joins in between, bit for bit -- tools/soak_variants.py.)
+    *(f4*)(rec + lane * 16) = active ? f4{q.x, q.y, q.dx, q.dy} : f4{0.0f, 0.0f, 0.0f, 0.0f};
+    *(int*)(rec + kXchgStatus + lane * 4) = active ? q.st : 0;
+    if (lane == 0) {
+        *(f4*)(rec + kXchgEnv) = f4{e.ax, e.ay, e.adx, e.ady};
+        *(f4*)(rec + kXchgEnv + 16) = f4{__builtin_bit_cast(float, e.now), __builtin_bit_cast(float, e.n_resets), __builtin_bit_cast(float, (int)e.total), 0.0f};
+        *(f4*)(rec + kXchgEnv + 32) = f4{e.acc_ret, e.acc_intr, e.acc_stat, 0.0f};
+        *(int*)(rec + kXchgGen) = gen;
+    }
+}
+// ... and back (the caller's stream joins: its arrays are the state again)
+__global__ __launch_bounds__(256) void k_chain_export(Params p, const char* __restrict__ xchg) {
+    const int env = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (env >= p.n_envs) return;
+    const bool active = lane < p.n_ped;
+    Ped q;
+    Env e;
+    load_record(xchg + (size_t)env * kXchgBytes, lane, active, q, e);
+    store_env(p, env, lane, active, lane == 0, q, e);
+}
+__global__ void k_copy_perm3(int n_envs, const int* __restrict__ src, int* __restrict__ a, int* __restrict__ b, int* __restrict__ c) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_envs; e += gridDim.x * blockDim.x) {
+        const int v = src[e];
+        a[e] = v; b[e] = v; c[e] = v;
+    }
 }
 
 // The same deal as a launch of its own (one workgroup): the first deal of a handle, and evac_reschedule.

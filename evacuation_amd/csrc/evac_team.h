@@ -49,10 +49,9 @@ constexpr int kTeamFirstPoll = 12;   // s_sleep units (64 cycles) between the me
 constexpr int kTeamPollGap = 2;      // ... between two polls
 constexpr int kTeamMinPoll = 4;      // round 5: the first poll adapts to where the last round's data arrived (exchange()); never earlier than this
 
-__device__ __forceinline__ void store_dev(void* ptr, f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
-__device__ __forceinline__ void store_dev_i32(void* ptr, int v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
+// (store_dev / store_dev_i32 / load_dev / wait_vmem -- the device-scope accesses of the exchange -- are in evac_common.h: the chained
+// rollout launches use the same idiom)
 __device__ __forceinline__ void lds_add(int* ptr, int v) { (void)__hip_atomic_fetch_add(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // The self-validating exchange, round 5: every 8-byte half of a published entry / record carries the TAG of its round
 // (round mod 31, five spare bits of a word that has them: the flag byte of the integer headings, the top bits of the packed counts);
 // the host fills the area with 0xff before a launch, which reads as tag 31 -- never a round's.  A slot is fresh when all its tags
@@ -69,7 +68,6 @@ constexpr int kEntryTagShift = 24;                          // heading words: 24
 constexpr int kEntryNull = 1 << 29, kEntryNan = 1 << 30;   // flag bits of an entry's heading-x word: no pedestrian that moves here / NaN heading
 constexpr int kCountTagShift = 27;                          // packed-count words: two counts of at most 1024 in bits 0-10 and 16-26 | tag << 27
 __device__ __forceinline__ bool tagged(float w, int shift, int tag) { return ((__builtin_bit_cast(int, w) >> shift) & ((1 << kTagBits) - 1)) == tag; }
-__device__ __forceinline__ void load_dev(f4& v, const void* ptr) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory"); }
 __device__ __forceinline__ void land(f4& a, f4& b, f4& c) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)::"memory"); }   // the loads into a, b and c have returned
 
 template <int K_>

@@ -31,6 +31,8 @@ class KernelOptions:
                              # (``BatchedEvacuationEnv.join``); -1: 2 where it pays.  (1, not -1: the stream contract of existing callers)
     team_coop: int = AUTO    # 1: cooperative launches of the team grids
     team_fault: int = AUTO   # 1: fault injection (tests)
+    chain: int = 0           # 1: chained rollout launches on the handle's own two streams (include/evac.h; ``join`` as for parts = 2);
+                             # -1: where it pays.  (0, not -1: the stream contract of existing callers)
     workspace: bool = True   # bind the rollout workspace (load schedule, team exchange areas); False: A/B runs without it
 
     def replace(self, **kw) -> "KernelOptions":
@@ -43,7 +45,7 @@ class KernelOptions:
 # the diagnostic switch of each option (include/evac.h) -- so that tools written against those names can say
 # from_switches(EVAC_CU_WIDE=1, EVAC_WORKSPACE=0) and get plain options
 SWITCH_FIELDS = {"EVAC_SUBWAVE": "subwave", "EVAC_CELLS": "cells", "EVAC_CU_WIDE": "cu_wide", "EVAC_TEAM": "team",
-                 "EVAC_SPECIALIZE": "specialize", "EVAC_PARTS": "parts", "EVAC_TEAM_COOP": "team_coop", "EVAC_TEAM_FAULT": "team_fault",
+                 "EVAC_SPECIALIZE": "specialize", "EVAC_PARTS": "parts", "EVAC_TEAM_COOP": "team_coop", "EVAC_TEAM_FAULT": "team_fault", "EVAC_CHAIN": "chain",
                  "EVAC_WORKSPACE": "workspace"}
 
 

@@ -168,6 +168,7 @@ class BatchedEvacuationEnv:
         _lib.check(self.lib.evac_create_ex(C.byref(self._cfg), self.num_envs, dev_index, C.c_uint64(self.seed_value),
                                            C.c_uint64(self.env_id_offset), C.byref(c_opt), C.byref(self._h)))
         self.num_parts = int(self.lib.evac_num_parts(self._h))
+        self.own_streams = int(self.lib.evac_own_streams(self._h))    # 2: parts = 2 or chained launches (kernels in flight per rollout round)
         self.obs_dim = int(self.lib.evac_obs_dim(self._h))
         assert self.obs_dim == obs_dim(env_config, self.wrap_config)
         E, N, dev = self.num_envs, self.n_ped, self.device
@@ -189,7 +190,7 @@ class BatchedEvacuationEnv:
             self.workspace = torch.zeros((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=dev)
             assert self.workspace.data_ptr() % 256 == 0
             _lib.check(self.lib.evac_bind_workspace(self._h, _ptr(self.workspace), C.c_int64(nbytes)), self._h)
-            if nbytes >= 16 * E and self.num_parts == 1:     # (two parts: each schedules itself inside a slice of its own)
+            if nbytes >= 16 * E and self.own_streams == 0:   # (two parts: each schedules itself inside a slice of its own; chained: four deep)
                 self.schedule = self.workspace[:16 * E].view(torch.int32).view(4, E)    # moving[2][E] | perm[2][E] (include/evac.h)
         # step outputs (reused every step; callers that keep them must clone, like the reference's
         # live-reference observations, env.py:98-104)
@@ -261,18 +262,17 @@ class BatchedEvacuationEnv:
         return KernelOptions(workspace=self.workspace is not None, **{f: int(getattr(o, f)) for f, _ in _lib.EvacOptions._fields_})
 
     def join(self, stream=None) -> None:
-        """``options.parts = 2``: make ``stream`` (default: the current stream) wait for everything the handle's own two streams
+        """``options.parts = 2`` / ``options.chain = 1``: make ``stream`` (default: the current stream) wait for everything the handle's own two streams
         have been given so far (``evac_join``).  ``rollout_launcher`` launches do NOT do this by themselves -- consecutive launches
         must not meet at a common point, or the two halves would run in lock-step again -- so call it before anything consumes a
         slab.  ``rollout()`` and every other method join by themselves.  A no-op for ``parts = 1``."""
-        if self.num_parts > 1:
+        if self.own_streams:
             st = self._stream() if stream is None else C.c_void_p(stream.cuda_stream)
             _lib.check(self.lib.evac_join(self._h, st), self._h)
 
     def part_streams(self):
         """The handle's own streams (``options.parts = 2``) as ``torch.cuda.ExternalStream`` objects, for timing events; else ``[]``."""
-        return [torch.cuda.ExternalStream(int(self.lib.evac_part_stream(self._h, k)), device=self.device) for k in range(self.num_parts)] \
-            if self.num_parts > 1 else []
+        return [torch.cuda.ExternalStream(int(self.lib.evac_part_stream(self._h, k)), device=self.device) for k in range(self.own_streams)]
 
     def team_error(self, sync: bool = True) -> int:
         """Non-zero if a barrier of a team rollout (N > 512, few envs) timed out: the outputs of that launch -- and of the

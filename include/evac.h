@@ -65,7 +65,8 @@ typedef enum evac_status {
     EVAC_ERR_UNSUPPORTED = -3, /* e.g. positions=grav with type=Box: wrappers/config.py:79-80 raises NotImplementedError */
     EVAC_ERR_HIP = -4,
     EVAC_ERR_NO_DEVICE = -5,
-    EVAC_ERR_TEAM_ABORTED = -6 /* an earlier team rollout lost a member: see evac_team_error / evac_team_clear_error */
+    EVAC_ERR_TEAM_ABORTED = -6 /* an earlier team rollout lost a member, or a chained rollout (evac_options_t.chain) waited in vain for an
+                                  env's state: see evac_team_error / evac_team_clear_error */
 } evac_status_t;
 
 enum { EVAC_POS_ABS = 0, EVAC_POS_REL = 1, EVAC_POS_GRAV = 2 };   /* wrappers/config.py:19-24 */
@@ -148,11 +149,14 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
  *               the handle owns (see evac_join).  -1: 2 where it pays (CU-wide handles whose halves still fill their CUs), else 1.
  *               evac_create() -- the entry point existing callers use -- always takes 1: its stream contract is unchanged.
  *   team_coop   1: team grids are launched with hipLaunchCooperativeKernel (3-4 % slower; automatic: plain launches)
- *   team_fault  1: fault injection for tests (the team grid is launched one workgroup short) */
+ *   team_fault  1: fault injection for tests (the team grid is launched one workgroup short; chained launches: the last env's
+ *               generation word is never published)
+ *   chain       1: CHAINED rollout launches (CU-wide one-wave handles with a bound workspace; see below); 0: never; -1: where it
+ *               pays (those handles).  Wins over `parts`.  evac_create() always takes 0, like parts = 1. */
 typedef struct evac_options {
-    int32_t subwave, cells, cu_wide, team, specialize, parts, team_coop, team_fault;
+    int32_t subwave, cells, cu_wide, team, specialize, parts, team_coop, team_fault, chain;
 } evac_options_t;
-#define EVAC_OPTIONS_AUTO {-1, -1, -1, -1, -1, -1, -1, -1}
+#define EVAC_OPTIONS_AUTO {-1, -1, -1, -1, -1, -1, -1, -1, -1}
 /* evac_create with options (NULL: all automatic, parts = 1: exactly evac_create). */
 int evac_create_ex(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint64_t seed, uint64_t env_id_offset,
                    const evac_options_t* options_or_null, evac_handle_t* out);
@@ -175,9 +179,25 @@ int evac_destroy(evac_handle_t h);
  *   - every other call on the handle (evac_reset, evac_step*, evac_observe, evac_get_state, evac_set_state, evac_reschedule,
  *     rollouts with capture / recorded actions / injected noise) joins first by itself and runs as one kernel on `stream`.
  * evac_num_parts: 1 or 2.  evac_part_stream: the hipStream_t of part k (for timing events and profilers; NULL if k is out of
- * range or parts = 1).  evac_join on a handle with parts = 1 is a no-op. */
+ * range or the handle owns no streams).  evac_join on a handle that owns no streams is a no-op.
+ *
+ * CHAINED LAUNCHES (chain = 1; no reference analogue).  With the driver's 20 steps per call a launch lasts as long as its
+ * heaviest env, and in the steady state of a batch -- episode phases spread out by early terminations -- every launch carries
+ * freshly reset, dense envs: most CUs idle behind them for a quarter of every launch (tools/steady_probe.py: 49.6 us per
+ * 4096-env round where the same kernel sustains 36 with every CU kept busy).  Only consecutive launches of the SAME env depend on
+ * each other.  A chained handle therefore sends its rollout launches to its two streams ALTERNATELY (launch g to stream g & 1)
+ * and orders them per env on the device: a generation word per env in the workspace -- launch g waits for ready[env] == g before
+ * it loads the env's state and publishes g + 1 behind its state stores (device-scope accesses; bounded waits) -- so launch
+ * g + 1's workgroups take the CUs launch g's light workgroups leave and each wave starts the moment ITS env is ready.  At most
+ * two launches overlap (launch g + 2 follows launch g in its stream).  Same bits as every other form.  Stream contract: exactly
+ * that of parts = 2 (evac_join; everything that is not a plain rollout joins by itself and restarts the chain behind it).  A wait
+ * that times out (it cannot, unless a launch is lost: every launch a wave waits for was dispatched in full before its own) voids
+ * the run like a lost team member: the handle's error word is raised, evac_* calls return EVAC_ERR_TEAM_ABORTED until
+ * evac_team_clear_error(), and the handle issues plain launches from then on.
+ * evac_own_streams: 0, or 2 for handles with parts = 2 or chain = 1 (the kernels in flight per rollout round). */
 int evac_join(evac_handle_t h, void* stream);
 int32_t evac_num_parts(evac_handle_t h);
+int32_t evac_own_streams(evac_handle_t h);
 void* evac_part_stream(evac_handle_t h, int32_t part);
 
 /* Floats per env in the observation buffer for this handle's observation mode. */

@@ -69,8 +69,8 @@ def test_create_time_options_through_the_abi(lib):
     """evac_options_t / evac_create_ex: the options struct is eight int32, invalid values are refused before
     any device is looked for, valid ones fail loudly without a device; nothing in the product steers the library through the
     process environment (the EVAC_* variables are diagnostic overrides read by the library itself)."""
-    assert C.sizeof(_lib.EvacOptions) == 8 * 4
-    assert [f for f, _ in _lib.EvacOptions._fields_] == ["subwave", "cells", "cu_wide", "team", "specialize", "parts", "team_coop", "team_fault"]
+    assert C.sizeof(_lib.EvacOptions) == 9 * 4
+    assert [f for f, _ in _lib.EvacOptions._fields_] == ["subwave", "cells", "cu_wide", "team", "specialize", "parts", "team_coop", "team_fault", "chain"]
     c = to_c_config(ea.EnvConfig(number_of_pedestrians=60), ea.EnvWrappersConfig(positions="grav"))
     h = C.c_void_p()
     for bad in (dict(parts=0), dict(parts=3), dict(team=-2), dict(cu_wide=99)):
@@ -78,7 +78,7 @@ def test_create_time_options_through_the_abi(lib):
         assert lib.evac_create_ex(C.byref(c), 8, 0, 0, 0, C.byref(o), C.byref(h)) == _lib.ERR_INVALID_ARGUMENT, bad
         assert not h.value and b"evac_options_t" in lib.evac_last_error(None)
     o = ea.KernelOptions(parts=2, cu_wide=1).to_c()
-    assert [getattr(o, f) for f, _ in o._fields_] == [-1, -1, 1, -1, -1, 2, -1, -1]
+    assert [getattr(o, f) for f, _ in o._fields_] == [-1, -1, 1, -1, -1, 2, -1, -1, 0]
     rc = lib.evac_create_ex(C.byref(c), 64, 0, 0, 0, C.byref(o), C.byref(h))
     assert rc == _lib.ERR_NO_DEVICE or (rc == 0 and h.value)           # (this container has no GPU: loud, no CPU path)
     if rc == 0:
@@ -86,7 +86,7 @@ def test_create_time_options_through_the_abi(lib):
     assert lib.evac_num_parts(None) == -1 and lib.evac_part_stream(None, 0) is None and lib.evac_join(None, None) == _lib.ERR_INVALID_ARGUMENT
     # the thread-local default of the host side, and the names of the diagnostic switches
     from evacuation_amd.options import current_default, from_switches, kernel_options
-    assert current_default() == ea.KernelOptions() and ea.KernelOptions().parts == 1
+    assert current_default() == ea.KernelOptions() and ea.KernelOptions().parts == 1 and ea.KernelOptions().chain == 0
     with kernel_options(cu_wide=1, workspace=False) as k:
         assert current_default() is k and (k.cu_wide, k.workspace, k.team) == (1, False, -1)
         with kernel_options(team=8):

@@ -541,6 +541,87 @@ def test_two_parts_on_the_handles_own_streams_equal_one_kernel(ea, n, E, wrap_kw
     one.close(); two.close()
 
 
+@pytest.mark.parametrize("n,E,wrap_kw,T", [
+    (60, 4096, dict(positions="grav", alpha=3), 20),                          # BASELINE config 2 with the driver's launch length
+    (60, 512, dict(positions="grav", alpha=3), 7),                            # CU-wide forced on a small batch, odd launch length
+    (33, 64, dict(positions="rel", statuses="ohe", type="Box"), 10),          # generic observation, four workgroups
+    (64, 160, dict(positions="abs", statuses="cat", type="Dict"), 5),         # the env fills its wave; generic kernels (not the default configuration)
+])
+def test_chained_launches_equal_plain_launches(ea, n, E, wrap_kw, T):
+    """evac_options_t.chain = 1: consecutive rollout launches on two queues, ordered per env by generation
+    words on the device.  Slabs, episode records and the final state of many back-to-back launches -- autoresets among them --
+    equal the plain handle's bit for bit; calls that are not plain rollouts join and restart the chain behind them."""
+    import torch
+    cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=45, is_new_exiting_reward=True, is_new_followers_reward=True)
+    wrap = ea.EnvWrappersConfig(**wrap_kw)
+    one = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=11, options=ea.KernelOptions(cu_wide=1))
+    ch = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=11, options=ea.KernelOptions(cu_wide=1, chain=1))
+    assert ch.own_streams == 2 and ch.num_parts == 1 and ch.resolved_options().chain == 1 and "chained" in ch.kernel_variant()
+    assert one.own_streams == 0
+    one.reset(); ch.reset()
+    D = one.obs_dim
+    R = 12                                               # launches in flight back to back, each into a buffer of its own
+    outs = [{"slab": torch.empty((T, E, D + 3), device=ch.device), "episode_stats": torch.zeros((T, E, ch.stats_words), device=ch.device)} for _ in range(R)]
+    goes = [ch.rollout_launcher(T, o) for o in outs]
+    for rep in range(3):
+        refs = [one.rollout(T) for _ in range(R)]
+        for g in goes:
+            g()                                          # nothing waits between them: launch j + 1 overlaps launch j
+        ch.join()
+        torch.cuda.current_stream().synchronize()
+        assert ch.team_error(sync=False) == 0
+    # (the reference rollouts above reuse no buffer: compare the LAST repetition launch by launch)
+    for j, (o, r) in enumerate(zip(outs, refs)):
+        assert torch.equal(o["slab"], r["slab"]), f"launch {j}"
+        done = (r["terminated"] != 0) | (r["truncated"] != 0)
+        assert torch.equal(o["episode_stats"][done], r["episode_stats"][done]), f"launch {j}: episode records"
+    sa, sb = one.get_state(), ch.get_state()             # (joins by itself)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    # a step in between (one kernel on the caller's stream), then the chain again: it restarts behind the step
+    act1 = torch.rand((E, 2), device=ch.device) * 2 - 1
+    for x, y in zip(one.step(act1)[:4], ch.step(act1)[:4]):
+        assert torch.equal(x, y)
+    for _ in range(5):
+        one.rollout(T); goes[0]()
+    assert torch.equal(one.rollout(T)["slab"], ch.rollout(T)["slab"])          # rollout() joins by itself
+    acts = torch.rand((T, E, 2), device=ch.device) * 2 - 1
+    assert torch.equal(one.rollout(T, actions=acts)["slab"], ch.rollout(T, actions=acts)["slab"])
+    assert ch.team_error() == 0
+    one.close(); ch.close()
+
+
+def test_a_chained_launch_that_is_lost_is_reported(ea):
+    """Fault injection (team_fault = 1: the last workgroup of the chain's second launch is never run): the third launch waits in
+    vain for those envs, its bounded waits give up, the error word is raised and every later call returns ERR_TEAM_ABORTED until
+    it is cleared; the handle then issues plain launches and works again after a reset."""
+    import torch
+    from evacuation_amd import _lib
+    cfg = ea.EnvConfig(number_of_pedestrians=60, max_timesteps=100)
+    wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
+    ch = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=64, seed=3, options=ea.KernelOptions(cu_wide=1, chain=1, team_fault=1))
+    ch.reset()
+    out = {"slab": torch.empty((4, 64, ch.obs_dim + 3), device=ch.device)}
+    go = ch.rollout_launcher(4, out)
+    for _ in range(4):
+        go()
+    torch.cuda.synchronize()                            # (the waits are bounded: well under a second)
+    assert ch.team_error() == 1
+    with pytest.raises(_lib.EvacError) as ei:
+        ch.get_state()
+    assert ei.value.code == _lib.ERR_TEAM_ABORTED and "chained" in str(ei.value)
+    ch.team_clear_error()
+    assert ch.team_error() == 0 and "chained" not in ch.kernel_variant()
+    ch.reset()
+    ref = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=64, seed=3)
+    ref.reset()
+    # (the faulty handle has reset one more time: compare invariants, not bits -- it works and is finite)
+    a = ch.rollout(6)
+    torch.cuda.synchronize()
+    assert torch.isfinite(a["slab"]).all() and a["slab"].shape == ref.rollout(6)["slab"].shape
+    ch.close(); ref.close()
+
+
 def test_full_size_invariants_c2(ea):
     """BASELINE config 2 (N=60 x 4096 envs, gravity obs): size-independent properties after a long
     on-device rollout -- walls, escaped pinned at the exit, status == classifier(position), step

@@ -56,6 +56,11 @@ if "b" in which:
     env, out = make(4096, 0x5EED0001, parts=2)
     timed("b) one handle, two parts (own streams)    ", [env.rollout_launcher(T, out)], [env.join], 4096)
     env.close()
+if "e" in which:
+    env, out = make(4096, 0x5EED0001, chain=1)
+    timed("e) one handle, CHAINED launches           ", [env.rollout_launcher(T, out)], [env.join], 4096)
+    print("   team/chain error word:", env.team_error(), env.kernel_variant())
+    env.close()
 if "c" in which:
     s1 = torch.cuda.current_stream(); s2 = side_stream(dev, beside=s1)
     (ea_, oa), (eb, ob) = make(4096, 1, parts=1), make(4096, 2, parts=1)
