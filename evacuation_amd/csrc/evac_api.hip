@@ -94,6 +94,7 @@ struct evac_handle {
     hipStream_t part_stream[2];
     hipEvent_t part_done[2], fork_ev;
     bool parts_pending;       // the part streams hold work the caller's stream has not been made to wait for (evac_join)
+    bool forked;              // the own streams have been put behind the caller's stream since the last join (evac_rollout forks once per join)
     evac_options_t opt;       // as resolved at creation (evac_get_options)
     // evac_options_t.chain = 1: rollout launch g goes to part_stream[g & 1] and waits PER ENV for launch g - 1 on the device
     // (include/evac.h, evac_common.h ChainArgs).  The schedule is four deep here: launch g reads perm[g & 3], leaves its loads in
@@ -108,6 +109,7 @@ struct evac_handle {
     char* chain_xchg;         // [E] exchange records (evac_common.h): the state between the chain's launches
     unsigned* chain_abort;    // device word: a wait timed out
     bool chain_dirty;         // the records are ahead of the caller's state arrays (k_chain_export at the next join)
+    unsigned long long chain_wgs;   // workgroups of the chain's launches enqueued since its last restart (the gate's target)
     hipEvent_t chain_ev;
 };
 
@@ -296,6 +298,7 @@ int create_impl(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
     h->part_stream[0] = h->part_stream[1] = nullptr;
     h->part_done[0] = h->part_done[1] = h->fork_ev = nullptr;
     h->parts_pending = false;
+    h->forked = false;
     h->chain = h->chain_bound = false;
     h->chain_gen = h->chain_start = 1;          // (never 0: a zero-filled workspace must not look like a published generation)
     h->chain_restart = true;
@@ -303,6 +306,7 @@ int create_impl(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
     h->chain_xchg = nullptr;
     h->chain_abort = nullptr;
     h->chain_dirty = false;
+    h->chain_wgs = 0;
     h->chain_ev = nullptr;
     const int o_subwave = option_value("EVAC_SUBWAVE", o.subwave), o_cells = option_value("EVAC_CELLS", o.cells);
     const int o_cu_wide = option_value("EVAC_CU_WIDE", o.cu_wide), o_team = option_value("EVAC_TEAM", o.team);
@@ -536,6 +540,7 @@ int join_parts(evac_handle* h, hipStream_t stream) {
             return fail(h, EVAC_ERR_HIP, "evac_join: event record / wait failed");
         }
     h->parts_pending = false;
+    h->forked = false;
     if (h->chain && h->chain_dirty && h->chain_xchg) {     // the chain's launches kept the state in the exchange records: back to the caller's arrays
         hipLaunchKernelGGL(evac::k_chain_export, dim3((unsigned)((h->p.n_envs + 3) / 4)), dim3(256), 0, stream, h->p, (const char*)h->chain_xchg);
         h->chain_dirty = false;
@@ -568,7 +573,9 @@ int evac_create_ex(const evac_config_t* cfg, int32_t num_envs, int32_t device, u
     // Chained launches (include/evac.h): the CU-wide kernels of one-wave envs, whole workgroups only (a wave that gives up must not
     // leave others at a barrier: that family has none), and a host-mapped error word like the teams'.  Wins over parts.
     const int chain_opt = option_value("EVAC_CHAIN", o.chain);
-    if (chain_opt != 0 && h->cu_wide && num_envs % 16 == 0 && num_envs >= 32) {
+    int can_wait_value = 0;
+    if (hipDeviceGetAttribute(&can_wait_value, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess) { (void)hipGetLastError(); can_wait_value = 0; }
+    if (chain_opt != 0 && can_wait_value && h->cu_wide && num_envs % 16 == 0 && num_envs >= 32) {
         bool ok = make_part_streams(h);
         {
             DeviceGuard g(device);
@@ -753,6 +760,7 @@ int evac_bind_workspace(evac_handle_t h, void* workspace, int64_t bytes) {
         h->chain_xchg = base + w.chain_xchg;
         h->chain_abort = (unsigned*)(base + w.chain_abort);
         h->chain_dirty = false;
+        h->chain_wgs = 0;                             // (the workspace comes zero-filled: include/evac.h)
         h->chain_bound = true;
         h->chain_restart = true;
     }
@@ -931,12 +939,14 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
         // wait for them (evac_join): consecutive rollout calls must not meet, or the halves would run in lock-step
         hipStream_t s_ = (hipStream_t)stream;
         // (the fork costs a barrier packet in front of each kernel -- 7-10 us on this platform whether or not the event has fired,
-        // DESIGN.md 6 -- which is more than the parts gain: when the caller's stream is idle, as in a loop that only launches
-        // rollouts, there is nothing to wait for and the kernels are enqueued bare.  A stream under capture cannot be queried: fork.)
-        const bool fork = hipStreamQuery(s_) != hipSuccess;
+        // DESIGN.md 6 -- which is more than the parts gain.  So the own streams are put behind the caller's stream ONCE per join: at
+        // the first rollout call after evac_join / any other call on the handle, and at every call that brings inputs (actions).
+        // Asking the stream instead -- hipStreamQuery -- was tried: the query leaves a marker in the stream, the next query finds it
+        // busy, and the handle falls into forking at every call: a second, 15-40 % slower mode of the same program.)
+        const bool fork = !h->forked || actions != nullptr;
         if (fork) {
-            (void)hipGetLastError();
             if (hipEventRecord(h->fork_ev, s_) != hipSuccess) { (void)hipGetLastError(); return fail(h, EVAC_ERR_HIP, "evac_rollout: hipEventRecord failed"); }
+            h->forked = true;
         }
         const size_t row = (size_t)h->p.obs_dim + 3;
         for (int k = 0; k < h->n_parts; ++k) {
@@ -956,15 +966,27 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
         if (hipStreamIsCapturing(s_, &ccap) != hipSuccess) { (void)hipGetLastError(); ccap = hipStreamCaptureStatusNone; }
         if (ccap == hipStreamCaptureStatusNone) {
             // CHAINED: launch g on stream g & 1, ordered per env on the device (include/evac.h).  Both streams start behind what the
-            // caller's stream holds -- only if it holds anything: a barrier packet costs more than the chain gains.
+            // caller's stream holds -- once per join (below): a barrier packet per launch costs more than the chain gains.
             using FW = evac::Wave<1, 1024>;
             const int E = h->p.n_envs, c = h->chain_gen;
             hipStream_t S = h->part_stream[c & 1], O = h->part_stream[(c + 1) & 1];
-            const bool fork = h->chain_restart || hipStreamQuery(s_) != hipSuccess;
-            (void)hipGetLastError();
+            // THE INVARIANT OF THE CHAIN: launch g + 1 must not start being dispatched before every workgroup of launch g has a CU.
+            // A workgroup of g + 1 holds its CU while it waits for envs of launch g; were workgroups of g still waiting for CUs then,
+            // the dispatcher -- which deals a grid's workgroups to the XCDs in order -- could find an XCD's CUs all held by waiting
+            // workgroups of g + 1 and launch g would never be placed (seen: both streams released by ONE event started launches g and
+            // g + 1 together and the second launch of a sweep timed out once in ~2000 sweeps; another kernel holding CUs while the
+            // chain runs does the same; short of a deadlock the interleaved start left the pipeline in a 15-40 % slower rhythm for
+            // the whole sweep).  So every workgroup of a chained launch counts itself in `started` when it gets its CU, and the QUEUE
+            // of launch g + 1 waits -- hipStreamWaitValue64: a packet, no CU held -- until the counter says that all workgroups of
+            // launches <= g have started (+0.5 us per launch: tools/microbench/waitvalue.hip).  With it every wait inside a kernel is
+            // for a workgroup that is resident or done, by induction down to the oldest launch in flight, which waits for nothing.
+            const bool fork = h->chain_restart || !h->forked || actions != nullptr;      // (once per join, and with every new input: see the parts' fork above)
             if (fork) {
-                if (hipEventRecord(h->fork_ev, s_) != hipSuccess || hipStreamWaitEvent(S, h->fork_ev, 0) != hipSuccess ||
-                    hipStreamWaitEvent(O, h->fork_ev, 0) != hipSuccess) { (void)hipGetLastError(); return fail(h, EVAC_ERR_HIP, "evac_rollout: fork of the chain failed"); }
+                if (hipEventRecord(h->fork_ev, s_) != hipSuccess || hipStreamWaitEvent(S, h->fork_ev, 0) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return fail(h, EVAC_ERR_HIP, "evac_rollout: fork of the chain failed");
+                }
+                h->forked = true;
             }
             int32_t* moving = h->chain_sched;
             int32_t* perm = h->chain_sched + 4 * (size_t)E;
@@ -976,17 +998,20 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
                                    perm + (c & 3) * (size_t)E, (int32_t*)nullptr, 16, 1);
                 hipLaunchKernelGGL(evac::k_copy_perm3, dim3(64), dim3(256), 0, S, E, (const int*)(perm + (c & 3) * (size_t)E),
                                    perm + ((c + 1) & 3) * (size_t)E, perm + ((c + 2) & 3) * (size_t)E, perm + ((c + 3) & 3) * (size_t)E);
-                if (hipEventRecord(h->chain_ev, S) != hipSuccess || hipStreamWaitEvent(O, h->chain_ev, 0) != hipSuccess) {
-                    (void)hipGetLastError();
-                    return fail(h, EVAC_ERR_HIP, "evac_rollout: restart of the chain failed");
-                }
                 h->chain_start = c;
                 h->chain_restart = false;
             }
             const bool deals = c - h->chain_start >= 2;          // (the loads of launch c - 2, the last launch of this stream)
             const int32_t* deal_loads = deals ? moving + ((c + 2) & 3) * (size_t)E : nullptr;
             int32_t* deal_perm = deals ? perm + ((c + 2) & 3) * (size_t)E : nullptr;
-            evac::ChainArgs ca{h->chain_xchg, c, h->chain_abort, h->team_flag_dev};
+            unsigned long long* started = (unsigned long long*)(h->chain_abort + 8);      // (the same line as the abort word: bytes 32..39)
+            // (the counter is never reset while the workspace is bound: a restart's first launch is gated too -- on the launches before
+            // the restart, long done -- and the launch after it on the restart's own workgroups, hence behind its import and deal)
+            if (h->chain_wgs > 0 && hipStreamWaitValue64(S, started, h->chain_wgs, hipStreamWaitValueGte, ~0ull) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(h, EVAC_ERR_HIP, "evac_rollout: hipStreamWaitValue64 (the chain's dispatch gate) failed");
+            }
+            evac::ChainArgs ca{h->chain_xchg, c, h->chain_abort, h->team_flag_dev, started};
             evac::Params pp = h->p;
             if (h->team_fault && c == h->chain_start + 1) pp.n_envs = E - 16;        // fault injection: the last workgroup of ONE launch is never run
 #define EVAC_CHAIN_ARGS pp, (int)n_steps, (const float2*)actions, slab_out, final_stats, (const int*)(perm + (c & 3) * (size_t)E), (int*)(moving + (c & 3) * (size_t)E), (const int*)deal_loads, (int*)deal_perm, ca
@@ -1000,10 +1025,12 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
             else
                 hipLaunchKernelGGL((evac::k_rollout_chain<FW, false>), grid, dim3(FW::kBlock), 0, S, EVAC_CHAIN_ARGS);
 #undef EVAC_CHAIN_ARGS
+            if (const int lc = check_launch(h, "evac_rollout (chained)"); lc != EVAC_OK) return lc;      // (a launch that never starts must not be waited for)
+            h->chain_wgs += (unsigned long long)grid.x;
             h->chain_gen = c + 1;
             h->parts_pending = true;
             h->chain_dirty = true;
-            return check_launch(h, "evac_rollout (chained)");
+            return EVAC_OK;
         }
     }
     h->chain_restart = true;
@@ -1187,6 +1214,21 @@ int evac_norm_step(evac_handle_t h, float* obs, float* final_obs, float* reward,
 }
 
 #ifdef EVAC_STEP_TIMES
+// diagnostic build only: the shader clock right now -- a one-wave kernel on `stream` that reads s_memtime (shader clock) and
+// s_memrealtime (100 MHz) at both ends of ~20 us; out2[0] = shader cycles, out2[1] = 100 MHz ticks (device memory, 16 bytes)
+__global__ void k_debug_clock(unsigned long long* out2) {
+    unsigned long long c0, c1, r0, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0)::"memory");
+    unsigned n = 0;
+    do { asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1)::"memory"); } while (r1 - r0 < 2000ull && ++n < (1u << 20));
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+    out2[0] = c1 - c0;
+    out2[1] = r1 - r0;
+}
+int evac_debug_clock(unsigned long long* out2_dev, void* stream) {
+    hipLaunchKernelGGL(k_debug_clock, dim3(1), dim3(64), 0, (hipStream_t)stream, out2_dev);
+    return hipGetLastError() == hipSuccess ? EVAC_OK : EVAC_ERR_HIP;
+}
 int evac_debug_step_times(unsigned long long* out2048) {
     if (hipMemcpyFromSymbol(out2048, HIP_SYMBOL(g_step_times), 16 * 128 * sizeof(unsigned long long)) != hipSuccess) return EVAC_ERR_HIP;
     return EVAC_OK;

@@ -750,6 +750,8 @@ struct ChainArgs {
     int gen;             // this launch: waits for generation `gen`, publishes `gen + 1`
     unsigned* abort;     // device word (workspace, a line of its own): a wait of some launch timed out -- every later wait gives up at once
     unsigned* err;       // the handle's host-mapped error word (as the teams')
+    unsigned long long* started;   // workgroups of the chain's launches that have started (since the chain's last restart): what the
+                                   // NEXT launch's queue waits for before it dispatches (evac_api.hip, "the invariant of the chain")
 };
 constexpr int kChainMaxPolls = 1 << 19;     // bounded wait: ~0.3 s of polls with the back-off below; a launch that gives up voids the run
 // Wait until the env's record holds generation `gen`.  Wave-uniform (all lanes poll the same word).  false: timed out.
@@ -767,8 +769,14 @@ __device__ __forceinline__ bool chain_wait(const ChainArgs& ch, int env) {
     }
     return false;
 }
-__device__ __forceinline__ void chain_give_up(const ChainArgs& ch, int lane) {
+// (the abort line keeps what the last wave to give up waited for: word 1 the generation, word 2 the env -- diagnostics of a run that
+// is void anyway.  Kept this small on purpose: a version that also carried the last value polled out of chain_wait -- one more live
+// scalar through the prologue -- left the kernel, instruction for instruction the same in its step loop, 15-45 % slower in its steps
+// in every run (tools/chain_rhythm.py; profiles/r06_*_chain_bisect.txt): this kernel's register allocation is at its limits.)
+__device__ __forceinline__ void chain_give_up(const ChainArgs& ch, int lane, int env) {
     if (lane == 0) {
+        store_dev_i32(ch.abort + 1, ch.gen);
+        store_dev_i32(ch.abort + 2, env);
         store_dev_i32(ch.abort, 1);
         __hip_atomic_store(ch.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }

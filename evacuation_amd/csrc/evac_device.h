@@ -577,6 +577,9 @@ __device__ __forceinline__ void rollout_body(
 #define EVAC_MARK(M) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(M)::"memory")
     EVAC_MARK(mark_entry_);
 #endif
+    if constexpr (CHAIN) {      // this workgroup has its CU: counted for the gate in front of the next launch (system scope: the queue's processor reads it)
+        if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(chain.started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     typename F::Ctx w(sm);
     if (w.env >= p.n_envs) return;
     // the schedule of the CU-wide workgroups: which env this wave carries; any permutation gives the same results
@@ -616,7 +619,7 @@ __device__ __forceinline__ void rollout_body(
         // permutation it writes is read two launches later, by the next launch of THIS queue: in order, no flag needed.)
         static_assert(F::WPE == 1 && !F::kHelpers, "chained launches: one-wave envs (no barrier that a wave giving up could leave others at)");
         if (!chain_wait(chain, w.env)) {      // (wave-uniform) the env's state never came: void run, the host is told
-            chain_give_up(chain, w.lane);
+            chain_give_up(chain, w.lane, w.env);
             return;
         }
         load_record(chain.xchg + (size_t)w.env * kXchgBytes, w.lane, active, q, e);
@@ -957,7 +960,8 @@ __global__ __launch_bounds__(F::kBlock, 4) void k_rollout_chain_default_config(
 // one wave per env: the caller's state arrays -> the env's exchange record at generation `gen` (a chain starts) ...
 __global__ __launch_bounds__(256) void k_chain_import(Params p, char* __restrict__ xchg, int gen, unsigned* __restrict__ abort_word) {
     const int env = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (blockIdx.x == 0 && threadIdx.x == 0) store_dev_i32(abort_word, 0);
+    if (blockIdx.x == 0 && threadIdx.x < 8) abort_word[threadIdx.x] = 0u;      // (the abort word and its diagnostics; NOT the started-workgroups counter
+                                                                               // behind them: it only ever grows -- the other queue's gate may be reading it)
     if (env >= p.n_envs) return;
     const bool active = lane < p.n_ped;
     Ped q;

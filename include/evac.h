@@ -171,9 +171,12 @@ int evac_destroy(evac_handle_t h);
  * heaviest workgroup and its boundary and prologue run under the other half's steps (N = 60 x 4096 envs, 20 steps per launch:
  * +3.4-5 %).  One call, one slab [T][E][D+3], the same bits as parts = 1 (the Philox streams are keyed by the
  * global env id).  Stream contract of such a handle:
- *   - evac_rollout(h, ..., stream): both kernels start after everything enqueued on `stream` so far (an event recorded on
- *     `stream`), but `stream` does NOT wait for them -- consecutive evac_rollout calls must not meet at a common point, or the
- *     halves would run in lock-step again;
+ *   - evac_rollout(h, ..., stream): the kernels go to the handle's own streams, and `stream` does NOT wait for them --
+ *     consecutive evac_rollout calls must not meet at a common point, or the halves would run in lock-step again.  The own
+ *     streams are put behind what `stream` holds (an event recorded on it) at the FIRST evac_rollout after an evac_join or any
+ *     other call on the handle, and at every call that passes `actions` (new inputs); a run of RandomAgent rollout calls
+ *     without a join between them is ordered after the work `stream` held at its first call only (a wait per launch costs a
+ *     barrier packet, more than the form gains) -- so: join before `stream` reuses or refills anything those launches touch;
  *   - evac_join(h, stream): `stream` waits for everything the handle's own streams have been given so far.  Call it before
  *     anything on `stream` (or the host, after synchronising `stream`) consumes a slab, and before ending a stream capture;
  *   - every other call on the handle (evac_reset, evac_step*, evac_observe, evac_get_state, evac_set_state, evac_reschedule,

@@ -71,6 +71,8 @@ for name, n, E, wrap_kw, T, opts in (("C2 chained, 20-step launches", 60, 4096, 
                 torch.equal(o["episode_stats"].view(torch.int32)[done], r["episode_stats"].view(torch.int32)[done])
             bad += 0 if same else 1
         rounds += 1
+        if k % 200 == 199:
+            print(f"   ... {name}: {rounds * R * T} steps, launches that differ so far {bad}", flush=True)
         if k % 5 == 4:                            # something else than a plain rollout: the chain restarts behind it
             ra, rb = a.step(act), b.step(act)
             bad += 0 if all(torch.equal(x, y) for x, y in zip(ra[:4], rb[:4])) else 1
