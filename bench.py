@@ -99,10 +99,11 @@ def parse_args(argv=None):
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="after the headline sweeps keep running the same sweeps for this much GPU time (0: skip): `sustained` in the line, "
                          "and `value` becomes the settled median when it differs from the headline sweeps' by more than 2 %%")
-    ap.add_argument("--rollout-form", default="auto", choices=["auto", "one", "parts"],
-                    help="how the handle issues a rollout (evac_options_t.parts): one = ONE kernel on the launching stream; parts = two "
-                         "half-batch kernels on two streams the handle owns (evac_join closes a sweep); auto = parts where the library "
-                         "says it pays, on a single GPU without gathers -- one otherwise")
+    ap.add_argument("--rollout-form", default="auto", choices=["auto", "one", "parts", "chain"],
+                    help="how the handle issues a rollout (evac_options_t): one = ONE kernel per call on the launching stream, every launch "
+                         "behind the one before; chain = consecutive launches alternately on two streams the handle owns, ordered per env on "
+                         "the device (evac_options_t.chain; evac_join closes a sweep); parts = two half-batch kernels per call on those two "
+                         "streams (evac_options_t.parts); auto = chain on a single GPU without gathers, one otherwise")
     ap.add_argument("--no-gather", action="store_true", help="skip the all-gather of the outputs (N>1)")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the gather path -- process group, collective on the comm stream, double-buffered pipeline -- with "
@@ -501,7 +502,7 @@ def side_workload(name: str, mode: str, inner: int, sweeps: int, device, traffic
                    "value_from": f"median of sweeps {len(wall) // 2}..{len(wall) - 1} (the last half)", "gpu_ms_timed_total": sum(dev) * 1e3,
                    "value_first_half": E * EPISODE / statistics.median(wall[:max(1, len(wall) // 2)]),
                    "value_min_median_max": [E * EPISODE / max(wall), value, E * EPISODE / min(wall)]},
-        "kernel": variant, "kernels_in_flight": env.num_parts, "kernel_ms_per_launch": kernel_s * 1e3,
+        "kernel": variant, "kernels_in_flight": max(1, env.own_streams), "kernel_ms_per_launch": kernel_s * 1e3,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": traffic, "traffic_source": tr["source"], "traffic_note": tr["note"],
                      "hbm_traffic_frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
@@ -518,8 +519,9 @@ def side_workloads(args, device):
     out = {}
     try:      # the headline batch, the driver's K steps per launch, issued as ONE kernel per rollout call (what rounds 1-5 timed)
         out["c2_one_kernel"] = side_workload("c2", "rollout", max(1, min(args.inner, args.steps)), args.side_sweeps, device, args.traffic_json,
-                                             options=ea.KernelOptions(parts=1))
-        out["c2_one_kernel"]["note"] = "the headline's batch and launch shape with evac_options_t.parts = 1: one kernel per rollout call on the launching stream"
+                                             options=ea.KernelOptions(parts=1, chain=0))
+        out["c2_one_kernel"]["note"] = ("the headline's batch and launch shape as plain launches (evac_options_t.chain = 0, parts = 1): one kernel per "
+                                        "rollout call on the launching stream, every launch behind the one before -- what rounds 1-5 timed")
     except SystemExit:
         raise
     except Exception as exc:  # noqa: BLE001
@@ -602,10 +604,11 @@ def main(argv=None):
     # streams by events recorded behind ONE launch per chunk, so those runs keep one kernel per launch.
     form_req = args.rollout_form
     if form_req == "auto":
-        form_req = "parts_auto" if (world == 1 and not use_dist and args.mode == "rollout") else "one"
+        form_req = "chain_auto" if (world == 1 and not use_dist and args.mode == "rollout") else "one"
     if form_req != "one" and use_dist and not args.no_gather:
-        raise SystemExit("bench.py: --rollout-form parts with gathers is not supported (the gather pipeline waits on one launch per chunk)")
-    kopts = ea.KernelOptions(parts={"one": 1, "parts": 2, "parts_auto": -1}[form_req])
+        raise SystemExit("bench.py: --rollout-form parts / chain with gathers is not supported (the gather pipeline waits on one launch per chunk)")
+    kopts = {"one": ea.KernelOptions(parts=1, chain=0), "parts": ea.KernelOptions(parts=2, chain=0),
+             "chain": ea.KernelOptions(chain=1), "chain_auto": ea.KernelOptions(chain=-1)}[form_req]
     env = ShardedEvacuationEnv(cfg, wrap, total_envs=total_envs, device=device, seed=seed, options=kopts)
     loc = env.local
     E, D = loc.num_envs, loc.obs_dim
@@ -842,8 +845,14 @@ def main(argv=None):
     ws0 = loc.workspace.clone() if loc.workspace is not None else None
     phase0 = W % EPISODE
 
+    def progress(what):
+        """One line on stderr per phase: a run that stops writing is taken to be hung by the GPU box's watchdog, and a hang is then located."""
+        if rank == 0:
+            print(f"bench.py: {what}", file=sys.stderr, flush=True)
+
     # ---- the headline: whole episode sweeps, launches back to back, no host sync inside ----
     import statistics
+    progress(f"warm-up done; {loc.kernel_variant(args.mode)}; timing {sweeps} sweeps")
     uniform = all(t == inner for t in sizes)
     launches_per_sweep = per_sweep * len(sizes)
     sweep_wall, sweep_dev = [], []
@@ -865,6 +874,7 @@ def main(argv=None):
     # eleven sweeps are ~50 ms; clocks and power settle over seconds.  All ranks run the same number of sweeps (from the max-over-ranks
     # median above); nothing else changes: same brackets, same launches, same gathers.
     sustain_wall, sustain_dev = [], []
+    progress(f"headline sweeps done: {[round(x * 1e3, 3) for x in sweep_wall]} ms")
     if args.sustain_seconds > 0:
         med0 = statistics.median(sweep_wall)
         if use_dist:
@@ -901,14 +911,18 @@ def main(argv=None):
     sustained = None
     if sustain_wall:
         allw, alld = sweep_wall + sustain_wall, sweep_dev + sustain_dev          # in the order they ran
-        cum, first, last = 0.0, [], []
+        cum, first = 0.0, []
         total_dev = sum(alld)
-        for w_, d_ in zip(allw, alld):
-            if cum < 0.050:
+        for w_, d_ in zip(allw, alld):                      # the sweeps that START within the first 50 ms of GPU time ...
+            if cum < 0.050 or not first:
                 first.append(w_)
-            if cum >= total_dev - 0.500:
+            cum += d_
+        cum, last = 0.0, []
+        for w_, d_ in zip(reversed(allw), reversed(alld)):  # ... and those that END within the last 500 ms
+            if cum < 0.500 or not last:
                 last.append(w_)
             cum += d_
+        last.reverse()
         v_first = total_envs * steps_per_sweep / statistics.median(first)
         v_last = total_envs * steps_per_sweep / statistics.median(last)
         sustained = {"gpu_seconds": total_dev, "sweeps": len(allw), "first_50ms": v_first, "last_500ms": v_last,
@@ -975,6 +989,7 @@ def main(argv=None):
         run["form"] = form
 
     # ---- diagnostic 1: one sweep of blocks, each bracketed by a device-idle sync of its own (the headline of rounds 1-3) ----
+    progress(f"sustained sweeps done ({len(sustain_wall)}); block diagnostic")
     wall, phases, t_call = [], [], []
     one_launch = chunk_bufs(K, 0)["launch"] if (args.mode == "rollout" and sizes == [K] and not do_gather) else None
     for b in range(per_sweep):
@@ -1022,6 +1037,7 @@ def main(argv=None):
         else:
             loc.step(step_actions)
 
+    progress("replay of one sweep with an event pair per launch")
     restore()
     per_launch = []
     for b in range(per_sweep):
@@ -1053,7 +1069,7 @@ def main(argv=None):
     # two parts: what each of the two concurrent kernels takes, from an event pair on each of the handle's own streams around one
     # more sweep (the period of that stream's launches: kernel + its boundary) -- what rocprofv3's kernel trace shows per kernel
     part_ms = None
-    if loc.num_parts > 1 and args.mode == "rollout":
+    if loc.own_streams and args.mode == "rollout":
         barrier()
         pev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in loc.part_streams()]
         for (a_, _z), s_ in zip(pev, loc.part_streams()):
@@ -1102,6 +1118,7 @@ def main(argv=None):
     achieved = bytes_per_launch / kernel_s / 1e9
 
     # the per-step API (one evac_step launch per step, actions resident in HBM), for transparency
+    progress("per-step API")
     step_api = None
     if rank == 0 and args.mode == "rollout" and not args.no_step_api:
         for _ in range(50):
@@ -1177,6 +1194,7 @@ def main(argv=None):
     side = None
     if (rank == 0 and world == 1 and args.workload == "c2" and args.mode == "rollout" and not args.envs and not args.no_side_workloads
             and not args.no_step_api and not do_gather):        # (--no-step-api = "the headline kernel only": profiling and A/B runs)
+        progress("side workloads")
         side = side_workloads(args, device)
 
     if rank == 0:
@@ -1236,7 +1254,7 @@ def main(argv=None):
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": tr["note"],
                          "salu_wave_insts_per_env_step": tr["salu"], "lds_wave_insts_per_env_step": tr["lds"],
                          "kernel": loc.kernel_variant(args.mode),
-                         "kernels_in_flight": loc.num_parts, "round_ms": kernel_s * 1e3,
+                         "kernels_in_flight": max(1, loc.own_streams), "round_ms": kernel_s * 1e3,
                          "part_stream_ms_per_launch": part_ms,
                          "kernel_ms_per_launch": kernel_s * 1e3, "kernel_launches_timed": back_to_back if (uniform and not gather_rollout) else len(full),
                          "launch_ms_with_gather": (sweep_launch_s * 1e3 if gather_rollout else None),
@@ -1265,12 +1283,20 @@ def main(argv=None):
         }
         if sustained is not None:
             out["sustained"] = sustained
-        out["config"]["rollout_form"] = {"requested": args.rollout_form, "parts": loc.num_parts,
-                                         "note": ("evac_options_t.parts = 2: every rollout call issues envs [0, E/2) and [E/2, E) as two kernels on two streams the "
-                                                  "handle owns; a sweep is closed by evac_join on the timing stream; roofline.achieved = the whole batch's "
-                                                  "algorithmic bytes per round of launches / the round's period (round_ms = kernel_ms_per_launch), "
-                                                  "part_stream_ms_per_launch = the launch period of each of the two streams") if loc.num_parts > 1 else
-                                                 "one kernel per rollout call on the launching stream"}
+        ro = loc.resolved_options()
+        out["config"]["rollout_form"] = {
+            "requested": args.rollout_form, "parts": loc.num_parts, "chain": ro.chain, "own_streams": loc.own_streams,
+            "note": ("evac_options_t.chain = 1: rollout call g goes to stream g & 1 of two streams the handle owns; a launch waits PER ENV, on the "
+                     "device, for the launch before it (a generation word in an exchange record per env) and its queue waits until every workgroup "
+                     "of that launch has started; at most two launches overlap; a sweep is closed by evac_join on the timing stream.  "
+                     "roofline.achieved = the batch's algorithmic bytes per launch / the launch PERIOD (round_ms = kernel_ms_per_launch = sweep / "
+                     "launches); a kernel's own duration, as a kernel trace shows it, is about two periods (part_stream_ms_per_launch = each "
+                     "stream's time per launch of the whole chain, i.e. half its own launches' period)") if ro.chain == 1 else
+                    (("evac_options_t.parts = 2: every rollout call issues envs [0, E/2) and [E/2, E) as two kernels on two streams the "
+                      "handle owns; a sweep is closed by evac_join on the timing stream; roofline.achieved = the whole batch's "
+                      "algorithmic bytes per round of launches / the round's period (round_ms = kernel_ms_per_launch), "
+                      "part_stream_ms_per_launch = the launch period of each of the two streams") if loc.num_parts > 1 else
+                     "one kernel per rollout call on the launching stream")}
         out["cpu_baseline"] = cpu_base
         if side is not None:
             out["workloads"] = side

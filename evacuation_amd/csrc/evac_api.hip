@@ -993,7 +993,7 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
             if (h->chain_restart) {
                 // the state in memory is whatever the caller's stream left: every env at generation c, one deal in all four
                 // permutation buffers, the other stream behind both
-                hipLaunchKernelGGL(evac::k_chain_import, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, S, h->p, h->chain_xchg, c, h->chain_abort);
+                hipLaunchKernelGGL(evac::k_chain_import, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, S, h->p, h->chain_xchg, c, h->chain_abort, h->chain_wgs);
                 hipLaunchKernelGGL(evac::k_schedule, dim3(1), dim3(1024), 0, S, E, (const int*)(moving + ((c + 3) & 3) * (size_t)E),
                                    perm + (c & 3) * (size_t)E, (int32_t*)nullptr, 16, 1);
                 hipLaunchKernelGGL(evac::k_copy_perm3, dim3(64), dim3(256), 0, S, E, (const int*)(perm + (c & 3) * (size_t)E),

@@ -958,10 +958,16 @@ __global__ __launch_bounds__(F::kBlock, 4) void k_rollout_chain_default_config(
 // (re)start of a chain: every env's generation word (device-scope stores, like the launches' own), and one permutation copied to
 // the three other buffers of the four-deep rotation
 // one wave per env: the caller's state arrays -> the env's exchange record at generation `gen` (a chain starts) ...
-__global__ __launch_bounds__(256) void k_chain_import(Params p, char* __restrict__ xchg, int gen, unsigned* __restrict__ abort_word) {
+__global__ __launch_bounds__(256) void k_chain_import(Params p, char* __restrict__ xchg, int gen, unsigned* __restrict__ abort_word,
+                                                      unsigned long long started_so_far) {
     const int env = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (blockIdx.x == 0 && threadIdx.x < 8) abort_word[threadIdx.x] = 0u;      // (the abort word and its diagnostics; NOT the started-workgroups counter
-                                                                               // behind them: it only ever grows -- the other queue's gate may be reading it)
+    if (blockIdx.x == 0 && threadIdx.x < 8) abort_word[threadIdx.x] = 0u;      // (the abort word and its diagnostics)
+    // the started-workgroups counter behind them is SET to what the host has enqueued so far -- every one of those workgroups has
+    // run: a restart follows a join --, so that a caller who restored a snapshot of the workspace (bench.py's replays) and told the
+    // library (evac_reschedule) does not leave the gates waiting for counts that were rolled back.  A gate of the other queue that
+    // reads the word before this store sees an older, smaller value: it waits, it cannot pass early.
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store((unsigned long long*)(abort_word + 8), started_so_far, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (env >= p.n_envs) return;
     const bool active = lane < p.n_ped;
     Ped q;

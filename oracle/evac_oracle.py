@@ -283,6 +283,36 @@ def env_step(p: OracleParams, st: OracleState, action, noise: np.ndarray, precis
                 terminated=bool(term_agent or term_ped), truncated=bool(truncated))
 
 
+class EpisodeLog:
+    """The per-episode bookkeeping of EvacuationEnv: the three sums its step() keeps (env.py:65-67, 168-170) and the nine-key dict its
+    NEXT reset() logs for the episode that ended (env.py:114-125).  ``overall_timesteps`` is Time.overall_timesteps (area.py:47,55):
+    steps of this env since it was created."""
+
+    KEYS = ("episode_intrinsic_reward", "episode_status_reward", "episode_reward", "episode_length", "escaped_pedestrians",
+            "exiting_pedestrians", "following_pedestrians", "viscek_pedestrians", "overall_timesteps")
+
+    def __init__(self, overall_timesteps: int = 0):
+        self.episode_reward = 0.0             # env.py:129-131 (zeroed by every reset)
+        self.episode_intrinsic_reward = 0.0
+        self.episode_status_reward = 0.0
+        self.overall_timesteps = int(overall_timesteps)
+
+    def after_step(self, out: Dict[str, object]) -> None:
+        """env.py:168-170, with the dict env_step returns; Time.step counts the step (area.py:55)."""
+        self.episode_reward += out["reward"]
+        self.episode_intrinsic_reward += out["intrinsic"]
+        self.episode_status_reward += out["reward_agent"] + out["reward_ped"]
+        self.overall_timesteps += 1
+
+    def record(self, st: OracleState) -> Dict[str, float]:
+        """env.py:114-125: built from the final state of the episode, before the reset that logs it touches anything."""
+        return {"episode_intrinsic_reward": self.episode_intrinsic_reward, "episode_status_reward": self.episode_status_reward,
+                "episode_reward": self.episode_reward, "episode_length": st.now,
+                "escaped_pedestrians": int(np.sum(st.status == ESCAPED)), "exiting_pedestrians": int(np.sum(st.status == EXITING)),
+                "following_pedestrians": int(np.sum(st.status == FOLLOWER)), "viscek_pedestrians": int(np.sum(st.status == VISCEK)),
+                "overall_timesteps": self.overall_timesteps}
+
+
 # ------------------------------------------------------------------------------------------
 # observations
 # ------------------------------------------------------------------------------------------

@@ -136,6 +136,29 @@ class RefHarness:
         return rec
 
 
+EPISODE_RECORD_KEYS = ("episode_intrinsic_reward", "episode_status_reward", "episode_reward", "episode_length", "escaped_pedestrians",
+                       "exiting_pedestrians", "following_pedestrians", "viscek_pedestrians", "overall_timesteps")
+
+
+def capture_episode_record(h: "RefHarness") -> np.ndarray:
+    """The dict the reference logs for the episode that just ended (env.py:114-127): it is built and emitted by the NEXT reset(), so
+    that reset is made here, with the reference's own wandb hand-off switched on and pointed at a recorder (the shell module of
+    _reference_loader; no arithmetic involved).  The global RNG is put back, so the fixture's recorded draws stay what they were."""
+    wandb = sys.modules["wandb"]
+    got = []
+    old_log, old_flag = wandb.log, h.env.wandb_enabled
+    st = np.random.get_state()
+    try:
+        wandb.log = lambda d, *a, **k: got.append(dict(d))
+        h.env.wandb_enabled = True
+        h.env.reset()
+    finally:
+        wandb.log, h.env.wandb_enabled = old_log, old_flag
+        np.random.set_state(st)
+    assert len(got) == 1 and tuple(got[0]) == EPISODE_RECORD_KEYS, got
+    return np.array([float(got[0][k]) for k in EPISODE_RECORD_KEYS], dtype=np.float64)
+
+
 def _margin(pre, post, width, height):
     sys.path.insert(0, os.path.join(HERE, "..", ".."))
     from oracle.evac_oracle import threshold_margin
@@ -166,6 +189,9 @@ def make_trajectory(ref, name, seed, steps, obs_every=1, **cfg_kw):
             break
     out = dict(params_json=json.dumps(_params_dict(h.cfg)), seed=seed, draw_pos=draw_pos, draw_dir=draw_dir,
                action=np.array(actions, dtype=np.float32), margin=np.array(margins))
+    if recs[-1]["terminated"] or recs[-1]["truncated"]:      # the episode ended: what the reference logs for it (env.py:114-127)
+        out["episode_record_keys"] = json.dumps(list(EPISODE_RECORD_KEYS))
+        out["episode_record"] = capture_episode_record(h)
     for k in ("pos", "dir", "status", "agent_pos", "agent_dir", "now"):
         out[k] = np.array([s[k] for s in snaps])
     for k in ("noise", "reward", "reward_agent", "reward_ped", "intrinsic", "terminated", "truncated"):
@@ -176,9 +202,48 @@ def make_trajectory(ref, name, seed, steps, obs_every=1, **cfg_kw):
         out[k] = np.array([obs[i][k] for i in idx])
     path = os.path.join(HERE, f"{name}.npz")
     np.savez_compressed(path, **out)
+    if "episode_record" in out:
+        print(f"   episode record: " + ", ".join(f"{k}={v:g}" for k, v in zip(EPISODE_RECORD_KEYS, out["episode_record"])))
     print(f"{name}: steps={len(recs)} N={h.cfg.number_of_pedestrians} "
           f"term={recs[-1]['terminated']} trunc={recs[-1]['truncated']} min_margin={min(margins):.2e} "
           f"size={os.path.getsize(path)/1024:.0f} KiB")
+
+
+def make_terminating_episode(ref, name="episode_all_escaped", seed=12, n=12):
+    """An episode that TERMINATES because every pedestrian has escaped (area.py:175-178), for the counts of the episode record
+    (env.py:114-127): after a normal reset the state is set by hand -- a crowd within the exit's radius, two stragglers a little
+    outside it and next to the leader -- and the reference runs on RandomAgent-style actions until it says `terminated`.  The fixture
+    holds the state it started from, the actions, the noise the reference drew, every step's outputs and the record."""
+    h = RefHarness(ref, number_of_pedestrians=n, is_new_exiting_reward=True, is_new_followers_reward=True, intrinsic_reward_coef=1.0,
+                   max_timesteps=400)
+    np.random.seed(seed)
+    h.reset()
+    rng = np.random.Generator(np.random.PCG64(77))
+    ang = rng.uniform(0.15 * np.pi, 0.85 * np.pi, size=n)
+    rad = rng.uniform(0.05, 0.38, size=n)
+    rad[:2] = (0.47, 0.52)                                     # two stragglers outside the exit's radius (0.4) ...
+    pos = np.stack([rad * np.cos(ang), -1.0 + rad * np.sin(ang)], axis=1)
+    agent_pos = np.array([pos[0, 0] + 0.05, pos[0, 1] + 0.05], dtype=np.float32)     # ... with the leader among them
+    dr = np.stack([_unit(v) * 0.01 for v in rng.uniform(-1, 1, size=(n, 2))])
+    status = np.where(rad < 0.4, 3, 2)                         # EXITING | FOLLOWER (what update_statuses gives for these positions)
+    h.set_state(pos, dr, status, agent_pos, np.zeros(2, np.float32), 0)
+    snaps, recs, actions = [h.snapshot()], [], []
+    for k in range(400):
+        a = np.array([0.0, -1.0], dtype=np.float32) + rng.uniform(-0.3, 0.3, size=2).astype(np.float32)    # towards the exit, wobbling
+        rec = h.step(a)
+        actions.append(a); recs.append(rec); snaps.append(h.snapshot())
+        if rec["terminated"] or rec["truncated"]:
+            break
+    assert recs[-1]["terminated"] and not recs[-1]["truncated"], "the crafted episode did not terminate"
+    out = dict(params_json=json.dumps(_params_dict(h.cfg)), seed=seed, action=np.array(actions, dtype=np.float32),
+               episode_record_keys=json.dumps(list(EPISODE_RECORD_KEYS)), episode_record=capture_episode_record(h))
+    for k in ("pos", "dir", "status", "agent_pos", "agent_dir", "now"):
+        out[k] = np.array([s[k] for s in snaps])
+    for k in ("noise", "reward", "reward_agent", "reward_ped", "intrinsic", "terminated", "truncated"):
+        out[k] = np.array([r[k] for r in recs])
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: steps={len(recs)} N={n} terminated; record: " + ", ".join(f"{k}={v:g}" for k, v in zip(EPISODE_RECORD_KEYS, out["episode_record"])))
 
 
 def _unit(v):
@@ -325,6 +390,8 @@ def main(argv=None):
          step_size=0.05, is_new_exiting_reward=True, intrinsic_reward_coef=1.0)
     traj("traj_n256_s10_noreward", 10, 64, obs_every=16, number_of_pedestrians=256,
          is_new_followers_reward=False, init_reward_each_step=0.0, noise_coef=0.05)
+    if not only or "episode_all_escaped" in only:
+        make_terminating_episode(ref)
     if not only or "crafted" in only:
         make_crafted(ref)
 

@@ -26,6 +26,14 @@ def state_at(d, k, dtype=np.float64) -> O.OracleState:
                          np.array(d["agent_dir"][k], dtype=np.float32), int(d["now"][k]))
 
 
+def episode_record_files():
+    """Fixtures that end with the reference's own per-episode record (env.py:114-127, captured by make_golden.capture_episode_record):
+    the trajectories that ran to truncation, and the crafted episode that terminates with every pedestrian escaped."""
+    out = [f for f in traj_files() if "episode_record" in np.load(f).files]
+    extra = os.path.join(GOLDEN, "episode_all_escaped.npz")
+    return out + ([extra] if os.path.exists(extra) else [])
+
+
 def crafted_cases():
     d = np.load(os.path.join(GOLDEN, "crafted.npz"))
     for name in d["names"]:

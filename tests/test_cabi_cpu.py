@@ -197,12 +197,16 @@ def test_kernel_resource_budgets():
         # the default faces of the production families: one wave per env (4- and 16-wave workgroups), sub-wave, cell list, teams
         headline = ("k_step" in name or "k_rollout" in name) and "diag" not in name and \
                    ("Wave<1," in name or "_sub<" in name or "Cells<" in name or "Team<" in name)
-        if headline:
+        generic_chain = "k_rollout_chain<" in name     # chained launches of NON-default configurations (the benchmark's faces are the _default_config ones)
+        if headline and not generic_chain:
             assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (name, k)
+        if generic_chain:                              # ... may keep a few spilled registers (the hand-off's addresses live through the step loop)
+            assert k["private_segment_fixed_size"] <= 16, (name, k)
         if "Wave<4, 1024>" in name:        # the CU-wide form of the four-wave envs: a few spilled scalars at most
             assert k["private_segment_fixed_size"] <= 16, (name, k)
     assert sum("Cells<" in n and "k_rollout<" in n for n in names) == 8      # 4 sizes x 2 observation faces
     assert sum("Team<" in n and "k_rollout<" in n for n in names) == 8       # 4 team sizes x 2 observation faces
     for fam in ("Wave<1, 1024>", "Wave<4, 1024>"):                           # generic + default-configuration faces, 2 observation faces each
         assert sum(fam in n and "k_rollout<" in n for n in names) == 2 and sum(fam in n and "k_rollout_default_config<" in n for n in names) == 2
+    assert sum("k_rollout_chain<" in n for n in names) == 2 and sum("k_rollout_chain_default_config<" in n for n in names) == 2
     assert sum("k_rollout_default_config" in n for n in names) >= 30 and sum("k_step_default_config" in n for n in names) >= 20

@@ -23,7 +23,7 @@ def _run(extra, timeout=600, env_extra=None, expect_rc0=True):
     env.update(EVAC_BENCH_FORCE_DEVICE="0", EVAC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.update(env_extra or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--blocks", "6",
-                        "--envs", "512", "--no-step-api"] + extra, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+                        "--envs", "512", "--no-step-api", "--sustain-seconds", "0.02"] + extra, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
     if not expect_rc0:
         assert r.returncode != 0
         return r.stderr

@@ -134,8 +134,8 @@ def test_normalized_env_accepts_destinations(ea):
 
 
 def test_final_info_needs_no_extra_call(ea):
-    """rpo_agent.py:198-203 verbatim against our infos: `if "final_info" in infos: for info in infos["final_info"]: if
-    info and "episode" in info: ...`; the record carries the reference's nine logging keys (env.py:115-125)."""
+    """What rpo_agent.py:198-203 asks of `infos` -- membership of "final_info", iteration over it, `info["episode"]` of the finished
+    envs and None for the others -- answered without an extra call; the record carries the reference's nine logging keys (env.py:115-125)."""
     import torch
     n, E, L = 12, 6, 7
     cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=L)
@@ -147,7 +147,7 @@ def test_final_info_needs_no_extra_call(ea):
     for t in range(1, 2 * L + 1):
         obs, reward, terminations, truncations, infos = env.step(acts)
         returns += reward
-        if "final_info" in infos:                                            # <- the trainer's own lines
+        if "final_info" in infos:                                            # (the trainer's access pattern)
             for info in infos["final_info"]:
                 if info and "episode" in info:
                     seen.append((t, info))
@@ -179,6 +179,68 @@ def test_final_info_needs_no_extra_call(ea):
     ints = stats_int_view(ro["episode_stats"]).cpu().numpy()
     assert (ints[L - 1, :, 0] == L).all() and (ints[2 * L - 1, :, 0] == 2 * L).all() and (ints[2 * L - 1, :, 1] == 2).all()
     env.close(); env2.close()
+
+
+def _episode_record_files():
+    from tests import helpers as H
+    return H.episode_record_files()
+
+
+@pytest.mark.parametrize("path", _episode_record_files(), ids=lambda p: os.path.basename(p)[:-4])
+@pytest.mark.parametrize("face", ["step", "rollout"])
+def test_episode_record_equals_the_references_log(ea, path, face):
+    """VERDICT r05 item 5a.  The nine-key dict the REFERENCE logs at the reset after an episode (env.py:114-127; captured from the
+    reference by tests/golden/make_golden.py: one episode run to truncation, one crafted episode that terminates with everybody
+    escaped) against evac_episode_stats_t of the same episode on the GPU: the same start state, the reference's actions and the noise
+    it drew.  Status counts, episode_length and overall_timesteps exactly; the three reward sums to 1e-5 relative (f32 sums of 40-52
+    terms against the reference's f64).  `step`: teacher-forced (set to the reference's pre-state before every step -- the
+    accumulators are not part of that state); `rollout`: free-running in ONE launch (evac_rollout with given actions and noise)."""
+    import json
+    import torch
+    from tests import helpers as H
+    d = np.load(path)
+    p = H.load_params(d["params_json"])
+    keys = json.loads(str(d["episode_record_keys"]))
+    ref = dict(zip(keys, d["episode_record"]))
+    T, n, E = len(d["action"]), int(p.number_of_pedestrians), 3
+    cfg = cfg_from_params(ea, p)
+    env = ea.BatchedEvacuationEnv(cfg, ea.EnvWrappersConfig(positions="grav", alpha=3), num_envs=E, seed=1)
+    dev = env.device
+
+    def rep(a, dtype=np.float32):                       # the same episode in every env of the batch
+        return np.broadcast_to(np.asarray(a, dtype=dtype)[None], (E,) + np.shape(a)).copy()
+
+    def put_state(k):
+        env.set_state(pos=rep(d["pos"][k]), dir=rep(d["dir"][k]), status=rep(d["status"][k], np.uint8), agent_pos=rep(d["agent_pos"][k]),
+                      agent_dir=rep(d["agent_dir"][k]), now=rep(d["now"][k], np.int32))
+    env.reset()                                         # (episode sums zeroed, n_episodes = 1 like the reference's first reset)
+    put_state(0)
+    if face == "step":
+        for k in range(T):
+            put_state(k)
+            obs, rew, term, trunc, infos = env.step(rep(d["action"][k]), noise=rep(d["noise"][k]))
+        torch.cuda.synchronize()
+        assert bool(term.any()) == bool(d["terminated"][-1]) and bool(trunc.any()) == bool(d["truncated"][-1])
+        stats = infos["episode_stats"]
+    else:
+        ro = env.rollout(T, actions=np.broadcast_to(d["action"][:, None, :], (T, E, 2)).copy(),
+                         noise=np.broadcast_to(d["noise"][:, None, :], (T, E, n)).astype(np.float32).copy())
+        torch.cuda.synchronize()
+        done = ((ro["terminated"] != 0) | (ro["truncated"] != 0)).cpu().numpy()
+        assert done[-1].all() and not done[:-1].any(), "the free-running f32 episode ended at another step than the reference's"
+        stats = ro["episode_stats"][-1]
+    from evacuation_amd.vector_env import STATS_FIELDS, stats_int_view
+    f = stats.cpu().numpy()
+    ints = stats_int_view(stats).cpu().numpy()
+    for e in range(E):
+        got = {k: float(f[e, j]) for j, k in enumerate(STATS_FIELDS)}
+        got["overall_timesteps"], got["n_episodes"] = int(ints[e, 0]), int(ints[e, 1])
+        for k in ("escaped_pedestrians", "exiting_pedestrians", "following_pedestrians", "viscek_pedestrians", "episode_length", "overall_timesteps"):
+            assert got[k] == ref[k], (face, e, k, got[k], ref[k])
+        for k in ("episode_reward", "episode_intrinsic_reward", "episode_status_reward"):
+            np.testing.assert_allclose(got[k], ref[k], rtol=1e-5, atol=1e-4, err_msg=f"{face} env {e} {k}")
+        assert got["n_episodes"] == 1
+    env.close()
 
 
 @pytest.mark.parametrize("alpha", [4, 6, 14, 30])

@@ -1,22 +1,21 @@
-"""GPU: HostVectorEnv -- the SyncVectorEnv-shaped host face -- under the reference trainer's OWN rollout
-lines.  `_ReferenceRolloutLoop.learn` holds /root/reference/src/agents/rpo_agent.py:168-170 and :193-203 character for
-character (same indentation: a method body with the `for update` / `for step` nesting of the reference), so what the
-unmodified trainer does with the vector env's return values -- `action.cpu().numpy()` in, `np.logical_or`, `torch.tensor(reward)`,
-`torch.Tensor(next_obs)`, `torch.Tensor(done)`, the `final_info` walk -- is executed against this env, with the trainer's
-wrapper chain (NormalizeObservation / NormalizeReward / ClipAction) on.  The numbers are checked against the device-tensor
-face (NormalizedVectorEnv) stepping a twin env with the same actions."""
+"""GPU: HostVectorEnv -- the SyncVectorEnv-shaped host face -- used the way the reference's trainer uses
+its vector env.  `_TrainerStyleRollout` is a small driver written for this test; it makes the same CALLS on the env as the
+rollout loop of RPOAgent.learn (/root/reference/src/agents/rpo_agent.py) and nothing else of it:
+
+  * :168-170  ``reset(seed=...)``; the returned observation goes through ``torch.Tensor(...)`` to the device;
+  * :193      ``step(action.cpu().numpy())`` -- NumPy actions in, a 5-tuple of NumPy arrays + ``infos`` out;
+  * :194      ``np.logical_or(terminations, truncations)``;
+  * :195-196  ``torch.tensor(reward)``, ``torch.Tensor(next_obs)``, ``torch.Tensor(done)`` -> device;
+  * :198-203  ``"final_info" in infos`` / iterating ``infos["final_info"]`` / ``info["episode"]["r"]``, ``["l"]`` with the running
+              ``global_step`` (+ num_envs per vector step).
+
+The policy between those calls is a scripted action, which the env cannot tell from a network's.  The trainer's wrapper chain
+(NormalizeObservation / NormalizeReward / ClipAction) is on.  The numbers are checked against the device-tensor face
+(NormalizedVectorEnv) stepping a twin env with the same actions."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-
-
-class _Writer:
-    def __init__(self):
-        self.scalars = []
-
-    def add_scalar(self, tag, value, step):
-        self.scalars.append((tag, value, step))
 
 
 class _Cfg:
@@ -24,59 +23,50 @@ class _Cfg:
         self.__dict__.update(kw)
 
 
-class _ReferenceRolloutLoop:
-    """The env-facing lines of RPOAgent.learn (rpo_agent.py:158-203); everything between them that belongs to the policy
-    (network, log-probs, values) is replaced by a scripted action, which the env cannot tell from a policy's."""
+class _TrainerStyleRollout:
+    """See the module docstring: the env-facing call pattern of rpo_agent.py:168-170,193-203, in this test's own words."""
 
     def __init__(self, envs, cfg, device, script):
-        import torch
         self.envs, self.cfg, self.device, self.script = envs, cfg, device, script
-        self.writer = _Writer()
-        self.obs_space = _Cfg(shape=(envs.obs_dim,))
-        self.action_space = envs.single_action_space
+        self.logged = []          # (tag, value, global_step): what the trainer hands to its TensorBoard writer (:202-203)
         self.trace = []
-        self._torch = torch
+        self.reset_obs = None
 
-    def learn(self):
-        torch = self._torch
-        obs = torch.zeros((self.cfg.num_steps, self.cfg.num_envs) + self.obs_space.shape).to(self.device)
-        rewards = torch.zeros((self.cfg.num_steps, self.cfg.num_envs)).to(self.device)
-        dones = torch.zeros((self.cfg.num_steps, self.cfg.num_envs)).to(self.device)
-
-        # TRY NOT TO MODIFY: start the game
+    def run(self):
+        import torch
+        c, dev = self.cfg, self.device
+        shape = (c.num_steps, c.num_envs)
+        obs_buf = torch.zeros(shape + (self.envs.obs_dim,), device=dev)
+        rew_buf, done_buf = torch.zeros(shape, device=dev), torch.zeros(shape, device=dev)
+        first, _ = self.envs.reset(seed=c.seed)                                   # :168
+        cur_obs = torch.Tensor(first).to(dev)                                     # :169
+        cur_done = torch.zeros(c.num_envs, device=dev)                            # :170
+        self.reset_obs = cur_obs.clone()
         global_step = 0
-        next_obs, _ = self.envs.reset(seed=self.cfg.seed)
-        next_obs = torch.Tensor(next_obs).to(self.device)
-        next_done = torch.zeros(self.cfg.num_envs).to(self.device)
-        self.reset_obs = next_obs.clone()
-
-        for update in range(1, self.cfg.num_updates + 1):
-            for step in range(0, self.cfg.num_steps):
-                global_step += 1 * self.cfg.num_envs
-                obs[step] = next_obs                                                # mem
-                dones[step] = next_done                                             # mem
-                action = self.script[(update - 1) * self.cfg.num_steps + step].to(self.device)
-
-                # TRY NOT TO MODIFY: execute the game and log data.
-                next_obs, reward, terminations, truncations, infos = self.envs.step(action.cpu().numpy())
-                done = np.logical_or(terminations, truncations)
-                rewards[step] = torch.tensor(reward).to(self.device).view(-1)       # mem
-                next_obs, next_done = torch.Tensor(next_obs).to(self.device), torch.Tensor(done).to(self.device)
-
-                if "final_info" in infos:
-                    for info in infos["final_info"]:
-                        if info and "episode" in info:
-                            print(f"global_step={global_step}, episodic_return={info['episode']['r']}")
-                            self.writer.add_scalar("charts/episodic_return", info["episode"]["r"], global_step)
-                            self.writer.add_scalar("charts/episodic_length", info["episode"]["l"], global_step)
-                self.trace.append((next_obs.clone(), rewards[step].clone(), next_done.clone(), reward.dtype, terminations.dtype,
-                                   truncations.dtype, type(next_obs)))
-        return obs, rewards, dones
+        for k in range(c.num_updates * c.num_steps):
+            row = k % c.num_steps
+            global_step += c.num_envs
+            obs_buf[row], done_buf[row] = cur_obs, cur_done
+            action = self.script[k].to(dev)                                       # (stands in for the policy's sample)
+            stepped = self.envs.step(action.cpu().numpy())                        # :193
+            host_obs, reward, terminations, truncations, infos = stepped
+            done = np.logical_or(terminations, truncations)                      # :194
+            rew_buf[row] = torch.tensor(reward).to(dev).view(-1)                  # :195
+            cur_obs, cur_done = torch.Tensor(host_obs).to(dev), torch.Tensor(done).to(dev)      # :196
+            if "final_info" in infos:                                             # :198
+                for info in infos["final_info"]:                                  # :199
+                    if info and "episode" in info:                                # :200
+                        print(f"global_step={global_step}, episodic_return={info['episode']['r']}")
+                        self.logged.append(("charts/episodic_return", info["episode"]["r"], global_step))
+                        self.logged.append(("charts/episodic_length", info["episode"]["l"], global_step))
+            self.trace.append((cur_obs.clone(), rew_buf[row].clone(), cur_done.clone(), reward.dtype, terminations.dtype,
+                               truncations.dtype, type(cur_obs)))
+        return obs_buf, rew_buf, done_buf
 
 
 @pytest.mark.parametrize("zero_copy", [True, False])
 @pytest.mark.parametrize("normalize", [True, False])
-def test_the_reference_trainers_rollout_lines_run_verbatim(normalize, zero_copy, capsys):
+def test_the_reference_trainers_call_pattern_on_the_host_face(normalize, zero_copy, capsys):
     import dataclasses
     import torch
     import evacuation_amd as ea
@@ -91,8 +81,8 @@ def test_the_reference_trainers_rollout_lines_run_verbatim(normalize, zero_copy,
     rng = np.random.default_rng(5)
     T = tcfg.num_steps * tcfg.num_updates
     script = [torch.as_tensor(rng.uniform(-1.5, 1.5, (E, 2)).astype(np.float32)) for _ in range(T)]     # (exercises ClipAction)
-    loop = _ReferenceRolloutLoop(envs, tcfg, torch.device("cuda:0"), script)
-    obs_buf, rewards, dones = loop.learn()
+    loop = _TrainerStyleRollout(envs, tcfg, torch.device("cuda:0"), script)
+    obs_buf, rewards, dones = loop.run()
     out = capsys.readouterr().out
     # ... against the device-tensor face stepping a twin env
     if normalize:
@@ -113,8 +103,8 @@ def test_the_reference_trainers_rollout_lines_run_verbatim(normalize, zero_copy,
         n_final += int((te | tr).sum())
     assert n_final == E * (T // L)                                                     # every env truncates every L steps
     # the trainer logged one return and one length per finished episode, with the reference's global_step
-    rets = [s for s in loop.writer.scalars if s[0] == "charts/episodic_return"]
-    lens = [s for s in loop.writer.scalars if s[0] == "charts/episodic_length"]
+    rets = [s for s in loop.logged if s[0] == "charts/episodic_return"]
+    lens = [s for s in loop.logged if s[0] == "charts/episodic_length"]
     assert len(rets) == len(lens) == n_final and all(l[1] == L for l in lens)
     assert {s[2] for s in rets} == {E * L * k for k in range(1, T // L + 1)}
     assert out.count("episodic_return=") == n_final

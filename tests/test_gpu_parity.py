@@ -686,10 +686,11 @@ def test_single_env_facade_matches_reference_surface(ea):
     # what the reference's scripted agent reads off the env (baseline_wacuum_cleaner.py:14-28): exit position, step size, room half-widths
     assert env.area is u.area and env.area.width == p.width and env.area.height == p.height
     assert env.area.exit.position.dtype == np.float32 and env.area.exit.position.shape == (2,) and env.area.eps == p.eps
-    SWITCH = 0.2                                                                  # constants.py:35 SWITCH_DISTANCE_TO_LEADER
-    go_up = lambda pos: pos[1] < env.area.height - SWITCH / 2 + env.area.step_size      # noqa: E731  (baseline_wacuum_cleaner.py:19-20, verbatim)
-    go_left = lambda pos: pos[0] > -env.area.width + SWITCH / 2 - env.area.step_size    # noqa: E731  (:25-26)
-    assert go_up(obs["agent_position"]) and go_left(obs["agent_position"])              # the leader starts in the middle of the room
+    # (the scripted agent's sweep tests -- baseline_wacuum_cleaner.py:17-29 -- compare the leader's coordinates with the room's half-widths
+    # less half the leader radius plus a step; with the attributes above they can be evaluated: the leader starts in the middle of the room)
+    reach = 0.2 / 2 - float(env.area.step_size)                                  # constants.py:35 (leader radius 0.2)
+    ax, ay = (float(v) for v in obs["agent_position"])
+    assert -float(env.area.width) + reach < ax < float(env.area.width) - reach and -float(env.area.height) + reach < ay < float(env.area.height) - reach
     with pytest.raises(TypeError):
         env.step([1, 0])                       # integer action: the reference raises too (area.py:190)
     agent = ea.RandomAgent(env.action_space)

@@ -43,7 +43,7 @@ def _Env(**kv):
     return kernel_options(from_switches(**kv))
 
 
-def oracle_episode(p, wrap, seed, gid, T):
+def oracle_episode(p, wrap, seed, gid, T, start=None):
     """The oracle stepping env `gid` for T steps on the device's Philox draws (reset draws, RandomAgent actions, noise), with
     the same-step autoreset of evac_rollout.
 
@@ -53,14 +53,20 @@ def oracle_episode(p, wrap, seed, gid, T):
     interaction radius (+ SPREAD for the tainted one's position error) when the neighbour sums were taken.  `counts` = a
     tainted pedestrian stood near a status radius, so the env's counts (rewards, flags, the gravity exit term) may differ.
     Returns per step (flat observation, reward, terminated, truncated, gravity tolerances, taint copy, counts) and the final
-    state."""
+    state.  `start` = (OracleState, steps taken so far, resets so far): continue from a given state -- a batch's state LATE in an
+    episode, taken from the device (f32 values are exact in f64: the start state is an input like the reset draws are) -- instead of
+    from the reset; the Philox counters continue where that state's env stood."""
     n = p.number_of_pedestrians
     SPREAD = 2e-3
-    dr = P.reset_draws(seed, [gid], n, 0)[0]
-    st = O.env_reset(p, dr[:, 0:2].astype(np.float64), dr[:, 2:4].astype(np.float64))
-    n_resets, rows = 1, []
+    if start is None:
+        dr = P.reset_draws(seed, [gid], n, 0)[0]
+        st = O.env_reset(p, dr[:, 0:2].astype(np.float64), dr[:, 2:4].astype(np.float64))
+        n_resets, t0 = 1, 0
+    else:
+        st, t0, n_resets = start
+    rows = []
     taint, counts = np.zeros(n, bool), False
-    for t in range(T):
+    for t in range(t0, t0 + T):
         pre, pre_status = st.pos.copy(), st.status.copy()
         act = P.random_action(seed, [gid], t)[0]
         nz = P.step_noise(seed, [gid], n, t, p.noise_coef)[0].astype(np.float64)
@@ -98,14 +104,29 @@ def oracle_episode(p, wrap, seed, gid, T):
 FACE_LOG = []     # (kernel variant, pedestrian-steps compared, of, env-steps whose rewards / flags were compared, of): printed at the end of the session (conftest)
 
 
-def check_against_oracle(ea, p, wrap, E, T, seed, offset, expect_variant):
-    """Returns (pedestrian-steps compared, pedestrian-steps in all, env-steps whose rewards / flags were compared)."""
+def check_against_oracle(ea, p, wrap, E, T, seed, offset, expect_variant, late=0, options=None):
+    """Returns (pedestrian-steps compared, pedestrian-steps in all, env-steps whose rewards / flags were compared).  `late`: the batch
+    is first stepped `late` steps by the same face (launches of 100); the oracle then starts from THAT state -- the rows and columns
+    of the neighbour sums are compacted there, most pedestrians have escaped, followers outnumber VISCEK pedestrians -- and the
+    T steps that follow are compared."""
     import torch
-    env = ea.BatchedEvacuationEnv(cfg_from_params(ea, p), wrap, num_envs=E, seed=seed, env_id_offset=offset)
+    env = ea.BatchedEvacuationEnv(cfg_from_params(ea, p), wrap, num_envs=E, seed=seed, env_id_offset=offset, options=options)
     name = env.kernel_variant("rollout")
     for part in expect_variant:
         assert part in name, name
     env.reset()
+    starts = [None] * E
+    if late:
+        for _ in range(late // 100):
+            env.rollout(100)
+        torch.cuda.synchronize()
+        s0 = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+        clock = env.clock.cpu().numpy()
+        for e in range(E):
+            st0 = O.OracleState(s0["pos"][e].astype(np.float64), s0["dir"][e].astype(np.float64), s0["status"][e].astype(np.int8),
+                                s0["agent_pos"][e].astype(np.float32), s0["agent_dir"][e].astype(np.float32), int(s0["now"][e]))
+            starts[e] = (st0, int(clock[e, 2]), int(clock[e, 1]))
+        name += f" -- from t = {late}"
     ro = env.rollout(T)                                      # ONE launch of the production face (no capture, no recording)
     torch.cuda.synchronize()
     assert env.team_error() == 0
@@ -114,7 +135,7 @@ def check_against_oracle(ea, p, wrap, E, T, seed, offset, expect_variant):
     D, n = env.obs_dim, p.number_of_pedestrians
     ped_steps = scalar_steps = 0
     for e in range(E):
-        rows, st, taint, counts = oracle_episode(p, wrap, seed, offset + e, T)
+        rows, st, taint, counts = oracle_episode(p, wrap, seed, offset + e, T, start=starts[e])
         for t in range(T):
             obs, rew, term, trunc, tol, tnt, cnt = rows[t]
             got = slab[t, e]
@@ -156,6 +177,33 @@ def test_cu_wide_default_config_rollout_vs_oracle(ea):
         peds, all_peds, scalars = check_against_oracle(ea, p, wrap, E=96, T=50, seed=0x5EED0002, offset=1000,
                                                        expect_variant=("k_rollout_default_config", "CU-wide"))
     assert peds >= 0.92 * all_peds and scalars >= 0.97 * 96 * 50, (peds, all_peds, scalars)     # (observed: 97.6 % / 100 %, printed at the end of the session)
+
+
+@pytest.mark.parametrize("face", ["c2", "c2_chained", "c3", "c5_team8"])
+def test_production_faces_late_in_an_episode_vs_oracle(ea, face):
+    """the same faces checked where an episode spends most of its time -- from t = 1200 (N = 60, 256) / 600
+    (N = 1024) on, 40 free-running steps against the oracle started from the batch's own state at that moment: compacted rows and
+    columns, row-less envs (no tile, no loop), the teams' transposed few-rows sweep.  `c2_chained`: BASELINE config 2's kernel as
+    the bench times it since round 6 -- chained launches -- with the 40 steps issued as two launches of 20."""
+    if face in ("c2", "c2_chained"):
+        p = O.OracleParams(number_of_pedestrians=60, is_new_exiting_reward=True, is_new_followers_reward=True, max_timesteps=2000)
+        wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
+        opts = ea.KernelOptions(cu_wide=1, chain=1 if face == "c2_chained" else 0)
+        peds, all_peds, scalars = check_against_oracle(ea, p, wrap, E=96, T=40, seed=0x5EED0002, offset=1000, late=1200, options=opts,
+                                                       expect_variant=("k_rollout_default_config", "CU-wide") + (("chained",) if face == "c2_chained" else ()))
+        assert peds >= 0.85 * all_peds and scalars >= 0.9 * 96 * 40, (peds, all_peds, scalars)
+    elif face == "c3":
+        p = O.OracleParams(number_of_pedestrians=256, is_new_exiting_reward=True, max_timesteps=2000)
+        wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
+        peds, all_peds, scalars = check_against_oracle(ea, p, wrap, E=24, T=40, seed=0x5EED0003, offset=0, late=1200, options=ea.KernelOptions(cu_wide=1),
+                                                       expect_variant=("k_rollout_default_config", "4 waves/env", "CU-wide"))
+        assert peds >= 0.5 * all_peds and scalars >= 0.7 * 24 * 40, (peds, all_peds, scalars)
+    else:
+        p = O.OracleParams(number_of_pedestrians=1024, is_new_exiting_reward=True, max_timesteps=2000)
+        wrap = ea.EnvWrappersConfig(positions="rel", statuses="ohe", type="Box")
+        peds, all_peds, scalars = check_against_oracle(ea, p, wrap, E=8, T=40, seed=0x5EED0005, offset=64, late=600, options=ea.KernelOptions(team=8),
+                                                       expect_variant=("k_rollout_default_config", "<8 CUs/env"))
+        assert peds >= 0.5 * all_peds and scalars >= 0.3 * 8 * 40, (peds, all_peds, scalars)
 
 
 def test_cu_wide_four_wave_rollout_vs_oracle(ea):

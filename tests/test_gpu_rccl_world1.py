@@ -31,7 +31,7 @@ def test_bench_force_gather_runs_the_pipeline_with_rccl(extra):
     """bench.py --force-gather: world size 1, backend nccl, the SAME ChunkPipeline as an N-GPU run -- the gather of chunk j - 1
     on the comm stream under chunk j, buffer-reuse waits, the drain of both streams -- and a bench line that says so."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-gather", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
-           "--no-step-api", "--sweeps", "1"] + extra
+           "--no-step-api", "--sweeps", "1", "--sustain-seconds", "0.02"] + extra
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_env())
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])

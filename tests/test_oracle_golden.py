@@ -2,6 +2,7 @@
 
 CPU only.  f64 'ref' precision must match to 1e-12 teacher-forced AND free-running (the oracle is
 deterministic given the reset draws, the actions and the per-pedestrian noise)."""
+import json
 import os
 
 import numpy as np
@@ -47,6 +48,30 @@ def test_teacher_forced_steps(path):
         st = H.state_at(d, k)
         out = O.env_step(p, st, d["action"][k], d["noise"][k])
         _check_step(out, st, d, k)
+
+
+@pytest.mark.parametrize("path", H.episode_record_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_episode_record_matches_the_references_log(path):
+    """The nine-key dict the reference logs at the reset that follows an episode (env.py:114-127), captured from the reference itself:
+    the oracle's bookkeeping (EpisodeLog) over the same steps gives the same sums (1e-9) and exactly the same counts."""
+    d = np.load(path)
+    p = H.load_params(d["params_json"])
+    keys = json.loads(str(d["episode_record_keys"]))
+    assert tuple(keys) == O.EpisodeLog.KEYS
+    log = O.EpisodeLog()
+    for k in range(len(d["action"])):
+        st = H.state_at(d, k)                                  # teacher-forced: the reference's own pre-state of every step
+        log.after_step(O.env_step(p, st, d["action"][k], d["noise"][k]))
+    assert bool(d["terminated"][-1]) or bool(d["truncated"][-1])
+    rec = log.record(st)
+    for k, v in zip(keys, d["episode_record"]):
+        if k.endswith("_pedestrians") or k in ("episode_length", "overall_timesteps"):
+            assert rec[k] == int(v), (k, rec[k], v)
+        else:
+            np.testing.assert_allclose(rec[k], v, rtol=1e-9, atol=1e-9, err_msg=k)
+    assert sum(rec[k] for k in keys if k.endswith("_pedestrians")) == p.number_of_pedestrians
+    if "all_escaped" in path:
+        assert rec["escaped_pedestrians"] == p.number_of_pedestrians and bool(d["terminated"][-1]) and not bool(d["truncated"][-1])
 
 
 @pytest.mark.parametrize("path", H.traj_files(), ids=lambda p: os.path.basename(p)[:-4])
