@@ -96,6 +96,9 @@ def parse_args(argv=None):
                          "along with the default C2 line as `workloads`")
     ap.add_argument("--side-sweeps", type=int, default=20,
                     help="episode sweeps per side workload (rollout mode); their figure is the median of the LAST half (settled clocks)")
+    ap.add_argument("--side-only", default="", choices=["", "c2_one_kernel", "c3", "c5_shard", "big_step"],
+                    help="run ONLY this entry of `workloads` (exactly as the default line runs it) and print it as the JSON line: what "
+                         "tools/final_run.sh puts under rocprofv3, so that a kernel trace covers the launches that entry times and no others")
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="after the headline sweeps keep running the same sweeps for this much GPU time (0: skip): `sustained` in the line, "
                          "and `value` becomes the settled median when it differs from the headline sweeps' by more than 2 %%")
@@ -467,6 +470,8 @@ def side_workload(name: str, mode: str, inner: int, sweeps: int, device, traffic
         actions = torch.rand((E, 2), device=device) * 2 - 1
         go = env.step_launcher(actions, stream=stream)
         launches, warm, sweeps = EPISODE, 20, 1
+    ea0, ea1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ea0.record(stream)                                        # (every launch of this entry, warm-up included: what a kernel trace of the process averages)
     for _ in range(warm):
         go()
     torch.cuda.synchronize()
@@ -482,6 +487,10 @@ def side_workload(name: str, mode: str, inner: int, sweeps: int, device, traffic
         torch.cuda.synchronize()
         wall.append(time.perf_counter() - t0)
         dev.append(e0.elapsed_time(e1) * 1e-3)
+    env.join(stream)
+    ea1.record(stream)
+    torch.cuda.synchronize()
+    all_launches = warm + sweeps * launches
     if env.team_error():
         raise SystemExit(f"bench.py: evac_team_error is set in side workload {name}; results discarded")
     settled = slice(len(wall) // 2, None)                      # the last half of the sweeps
@@ -503,6 +512,12 @@ def side_workload(name: str, mode: str, inner: int, sweeps: int, device, traffic
                    "value_first_half": E * EPISODE / statistics.median(wall[:max(1, len(wall) // 2)]),
                    "value_min_median_max": [E * EPISODE / max(wall), value, E * EPISODE / min(wall)]},
         "kernel": variant, "kernels_in_flight": max(1, env.own_streams), "kernel_ms_per_launch": kernel_s * 1e3,
+        "profile_check": {"launches": all_launches, "sum_of_sweeps_ms_per_launch": sum(dev) * 1e3 / (sweeps * launches),
+                          "first_launch_to_last_ms_per_launch": ea0.elapsed_time(ea1) / all_launches,
+                          "note": "for a reader with the kernel trace of `bench.py --side-only <this entry>`: the trace's average duration of this kernel "
+                                  "over ALL its launches (warm-up and every sweep) is to be compared with sum_of_sweeps_ms_per_launch (the sweeps' own "
+                                  "HIP-event time over their launches; first_launch_to_last also holds the idle gaps between sweeps); "
+                                  "kernel_ms_per_launch -- what `value` and `roofline` use -- is the median of the LAST half of the sweeps"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": traffic, "traffic_source": tr["source"], "traffic_note": tr["note"],
                      "hbm_traffic_frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
@@ -511,6 +526,12 @@ def side_workload(name: str, mode: str, inner: int, sweeps: int, device, traffic
                      "valu_pipe_frac": (tr["valu"] * 64.0 * E * inner / kernel_s / VALU_PIPE_PEAK) if tr["valu"] else None,
                      "equivalent_bandwidth": mode == "rollout"},
     }
+
+
+def side_options(ea, mode):
+    """The options of a side workload's handle: as the headline's on one GPU -- chained rollout launches wherever the library offers them
+    (the CU-wide kernels of one- and four-wave envs: C3; the teams of C5 and the per-step runs are plain handles)."""
+    return ea.KernelOptions(chain=-1) if mode == "rollout" else None
 
 
 def side_workloads(args, device):
@@ -528,7 +549,7 @@ def side_workloads(args, device):
         out["c2_one_kernel"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     for key, name, mode, inner in SIDE_WORKLOADS:
         try:
-            out[key] = side_workload(name, mode, inner, args.side_sweeps, device, args.traffic_json)
+            out[key] = side_workload(name, mode, inner, args.side_sweeps, device, args.traffic_json, options=side_options(ea, mode))
         except SystemExit:
             raise
         except Exception as exc:  # noqa: BLE001
@@ -539,6 +560,21 @@ def side_workloads(args, device):
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
+    if args.side_only:                                         # one entry of `workloads`, exactly as the default line runs it
+        import torch
+        import evacuation_amd as ea
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X; evacuation_amd has no CPU path")
+        device = torch.device("cuda:0")
+        torch.cuda.set_device(device)
+        if args.side_only == "c2_one_kernel":
+            entry = side_workload("c2", "rollout", max(1, min(args.inner, args.steps)), args.side_sweeps, device, args.traffic_json,
+                                  options=ea.KernelOptions(parts=1, chain=0))
+        else:
+            key, name, mode, inner = next(w for w in SIDE_WORKLOADS if w[0] == args.side_only)
+            entry = side_workload(name, mode, inner, args.side_sweeps, device, args.traffic_json, options=side_options(ea, mode))
+        print(json.dumps({"side_only": args.side_only, **entry}), flush=True)
+        return 0
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args, argv))
     rank = int(os.environ.get("RANK", "0"))
@@ -870,6 +906,7 @@ def main(argv=None):
         sweep_dev.append(e0.elapsed_time(e1) * 1e-3)
     pipe.flush()
     barrier()
+    sweep_wall_this_rank = list(sweep_wall)                    # (before the max over ranks below: gather_report.per_rank[r].headline)
     # ---- steady state: the SAME sweeps again until --sustain-seconds of GPU time have passed.  The headline's
     # eleven sweeps are ~50 ms; clocks and power settle over seconds.  All ranks run the same number of sweeps (from the max-over-ranks
     # median above); nothing else changes: same brackets, same launches, same gathers.
@@ -1086,7 +1123,11 @@ def main(argv=None):
     gather_info = None
     if gather_rollout:
         vers, envv = comm_environment()
-        mine = {"rank": rank, "device": dev_index}
+        #  this rank's OWN clock over the headline sweeps next to the job's max-over-ranks figure: one slow rank shows
+        mine = {"rank": rank, "device": dev_index,
+                "headline": {"sweep_wall_ms_this_rank": [x * 1e3 for x in sweep_wall_this_rank],
+                             "value_if_every_rank_were_this_one": total_envs * steps_per_sweep / statistics.median(sweep_wall_this_rank),
+                             "env_steps_per_s_of_this_rank": E * steps_per_sweep / statistics.median(sweep_wall_this_rank)}}
         for f_, rec in gather_runs.items():
             rep = gather_report(f_, world, inner * E * (D + 3 if f_ == "slab" else D) * 4, alone_ms.get(f_, []), rec["chunks"], kernel_s * 1e3,
                                 env=envv if f_ == form else None, versions=vers if f_ == form else None)
@@ -1255,6 +1296,16 @@ def main(argv=None):
                          "salu_wave_insts_per_env_step": tr["salu"], "lds_wave_insts_per_env_step": tr["lds"],
                          "kernel": loc.kernel_variant(args.mode),
                          "kernels_in_flight": max(1, loc.own_streams), "round_ms": kernel_s * 1e3,
+                         "profile_check": {
+                             "sweeps_all": len(sweep_dev) + len(sustain_dev),
+                             "mean_period_ms_all_sweeps": (sum(sweep_dev) + sum(sustain_dev)) * 1e3 / max(1, (len(sweep_dev) + len(sustain_dev)) * launches_per_sweep),
+                             "expected_kernel_trace_avg_duration_ms": max(1, loc.own_streams) * (sum(sweep_dev) + sum(sustain_dev)) * 1e3
+                                                                      / max(1, (len(sweep_dev) + len(sustain_dev)) * launches_per_sweep),
+                             "note": "for a reader with the kernel trace of this command: a CHAINED launch is enqueued behind its queue's previous launch and "
+                                     "ends two launch periods later (its queue carries every second launch), so the trace's average DURATION of the "
+                                     "rollout kernel is kernels_in_flight x the launch period, and the period itself is the trace's start-to-start "
+                                     "distance of consecutive launches (tools/chain_trace.sh prints both); mean_period_ms_all_sweeps is over "
+                                     "every timed sweep (headline + sustained), round_ms the settled median `value` uses"},
                          "part_stream_ms_per_launch": part_ms,
                          "kernel_ms_per_launch": kernel_s * 1e3, "kernel_launches_timed": back_to_back if (uniform and not gather_rollout) else len(full),
                          "launch_ms_with_gather": (sweep_launch_s * 1e3 if gather_rollout else None),

@@ -55,6 +55,7 @@ SIGNATURES = {
     "evac_create_ex": (C.c_int, [C.POINTER(EvacConfig), C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(EvacOptions), C.POINTER(_P)]),
     "evac_get_options": (C.c_int, [_P, C.POINTER(EvacOptions)]),
     "evac_join": (C.c_int, [_P, _P]),
+    "evac_order_next_rollout": (C.c_int, [_P]),
     "evac_num_parts": (C.c_int32, [_P]),
     "evac_own_streams": (C.c_int32, [_P]),
     "evac_part_stream": (_P, [_P, C.c_int32]),

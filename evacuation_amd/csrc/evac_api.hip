@@ -525,6 +525,8 @@ void destroy_parts(evac_handle* h) {
     }
     if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
     if (h->chain_ev) (void)hipEventDestroy(h->chain_ev);
+    if (h->chain_xchg) (void)hipFree(h->chain_xchg);
+    h->chain_xchg = nullptr;
     h->fork_ev = h->chain_ev = nullptr;
     h->chain = false;
     h->n_parts = 1;
@@ -542,7 +544,8 @@ int join_parts(evac_handle* h, hipStream_t stream) {
     h->parts_pending = false;
     h->forked = false;
     if (h->chain && h->chain_dirty && h->chain_xchg) {     // the chain's launches kept the state in the exchange records: back to the caller's arrays
-        hipLaunchKernelGGL(evac::k_chain_export, dim3((unsigned)((h->p.n_envs + 3) / 4)), dim3(256), 0, stream, h->p, (const char*)h->chain_xchg);
+        const int wpe = h->cu_wide4 ? 4 : 1;
+        hipLaunchKernelGGL(evac::k_chain_export, dim3((unsigned)((h->p.n_envs * wpe + 3) / 4)), dim3(256), 0, stream, h->p, (const char*)h->chain_xchg, wpe);
         h->chain_dirty = false;
         if (hipGetLastError() != hipSuccess) return fail(h, EVAC_ERR_HIP, "evac_join: export of the chain's state failed");
     }
@@ -575,7 +578,9 @@ int evac_create_ex(const evac_config_t* cfg, int32_t num_envs, int32_t device, u
     const int chain_opt = option_value("EVAC_CHAIN", o.chain);
     int can_wait_value = 0;
     if (hipDeviceGetAttribute(&can_wait_value, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess) { (void)hipGetLastError(); can_wait_value = 0; }
-    if (chain_opt != 0 && can_wait_value && h->cu_wide && num_envs % 16 == 0 && num_envs >= 32) {
+    const bool chain_one_wave = h->cu_wide && num_envs % 16 == 0 && num_envs >= 32;
+    const bool chain_four_waves = h->cu_wide4 && num_envs % 4 == 0 && num_envs >= 8;     // (the CU-wide form of four-wave envs: a barrier per env in LDS)
+    if (chain_opt != 0 && can_wait_value && (chain_one_wave || chain_four_waves)) {
         bool ok = make_part_streams(h);
         {
             DeviceGuard g(device);
@@ -593,11 +598,24 @@ int evac_create_ex(const evac_config_t* cfg, int32_t num_envs, int32_t device, u
             } else {
                 (void)hipGetLastError();
             }
+            // The exchange records (evac_common.h) live in UNCACHED device memory, the second thing a chained handle allocates
+            // itself.  In ordinary hipMalloc memory -- the caller's workspace -- a record line can sit in the L2 of an XCD that once
+            // touched it with a plain access (the workspace's zero fill, the import), and another XCD's write-through store does not
+            // refresh that copy: an import written with `sc1` stores over the zero-filled workspace read back as zeros in ~1.5 of a
+            // record's 12 lines (tools/chain_debug.py, round 6).  A plain-store import cured that case, but the same can happen to the
+            // import's own lines once a batch that fills the chip lets workgroups land on whatever XCD has room.  Memory that no L2
+            // ever holds removes the question: 1.5 KB per env and launch at memory speed is nothing next to 20 steps.
+            void* xchg = nullptr;
+            const size_t xbytes = (size_t)num_envs * (size_t)evac::xchg_bytes(h->cu_wide4 ? 256 : 64);
+            if (ok && hipExtMallocWithFlags(&xchg, xbytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); xchg = nullptr; ok = false; }
+            if (ok && (hipMemset(xchg, 0, xbytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) { (void)hipGetLastError(); ok = false; }   // (hipMemset does not wait)
+            h->chain_xchg = (char*)xchg;
         }
         if (ok) {
             h->chain = true;
             h->opt.chain = 1;
             h->variant[3] = h->variant[1] + ", chained launches on 2 streams";
+            (void)chain_one_wave;
             return EVAC_OK;
         }
         destroy_parts(h);                              // (no second queue: plain launches)
@@ -637,6 +655,11 @@ int evac_get_options(evac_handle_t h, evac_options_t* out) {
 int evac_join(evac_handle_t h, void* stream) {
     if (!h) return EVAC_ERR_INVALID_ARGUMENT;
     return join_parts(h, (hipStream_t)stream);
+}
+int evac_order_next_rollout(evac_handle_t h) {
+    if (!h) return EVAC_ERR_INVALID_ARGUMENT;
+    h->forked = false;
+    return EVAC_OK;
 }
 int32_t evac_num_parts(evac_handle_t h) { return h ? h->n_parts : -1; }
 int32_t evac_own_streams(evac_handle_t h) { return h ? ((h->n_parts > 1 || h->chain) && h->part_stream[0] ? 2 : 0) : -1; }
@@ -692,7 +715,7 @@ int evac_bind_state(evac_handle_t h, float* ped, uint8_t* status, float* agent, 
 
 namespace {
 struct WorkspaceLayout {
-    size_t sched, stats, team_rec, team_tile, team_xchg_end, chain_sched, chain_xchg, chain_abort, total;
+    size_t sched, stats, team_rec, team_tile, team_xchg_end, chain_sched, chain_abort, total;
 };
 WorkspaceLayout workspace_layout(const evac_handle* h) {
     const size_t E = (size_t)h->p.n_envs;
@@ -701,10 +724,9 @@ WorkspaceLayout workspace_layout(const evac_handle* h) {
     size_t o = 0;
     w.sched = o; o = up(o + 4 * E * sizeof(int32_t));          // moving[2][E] | perm[2][E]
     w.stats = o; o = up(o + 64);
-    if (h->chain) {                                            // moving[4][E] | perm[4][E] | the exchange records | the abort word
-        w.chain_sched = o; o = up(o + 8 * E * sizeof(int32_t));
-        w.chain_xchg = o; o = up(o + E * (size_t)evac::kXchgBytes);
-        w.chain_abort = o; o = up(o + 128);
+    if (h->chain) {                                            // moving[4][E] | perm[4][E] | the abort word + started-workgroups counter
+        w.chain_sched = o; o = up(o + 8 * E * sizeof(int32_t));    // (the exchange records are NOT here: they need memory the L2s do not cache,
+        w.chain_abort = o; o = up(o + 128);                        //  which the library allocates itself: evac_create_ex)
     }
     if (h->team_k) {
         w.team_rec = o; o = up(o + evac::kTeamSets * E * 32 * 16);          // (two slot sets: evac_team.h, exchange)
@@ -757,7 +779,6 @@ int evac_bind_workspace(evac_handle_t h, void* workspace, int64_t bytes) {
     h->chain_bound = false;
     if (h->chain) {
         h->chain_sched = (int32_t*)(base + w.chain_sched);
-        h->chain_xchg = base + w.chain_xchg;
         h->chain_abort = (unsigned*)(base + w.chain_abort);
         h->chain_dirty = false;
         h->chain_wgs = 0;                             // (the workspace comes zero-filled: include/evac.h)
@@ -785,7 +806,7 @@ void deal_now(evac_handle_t h, hipStream_t s, bool both) {
     const int g = h->sched_gen;
     hipLaunchKernelGGL(evac::k_schedule, dim3(1), dim3(1024), 0, s, E, (const int*)(h->sched + ((g + 1) & 1) * E),
                        h->sched + (2 + (g & 1)) * E, both ? h->sched + (2 + ((g + 1) & 1)) * E : (int32_t*)nullptr,
-                       h->cu_wide4 ? 4 : 16, h->cu_wide4 ? 4 : 1);
+                       h->cu_wide4 ? 4 : 16, h->cu_wide4 ? 4 : 1, 0);
 }
 }  // namespace
 
@@ -968,6 +989,8 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
             // CHAINED: launch g on stream g & 1, ordered per env on the device (include/evac.h).  Both streams start behind what the
             // caller's stream holds -- once per join (below): a barrier packet per launch costs more than the chain gains.
             using FW = evac::Wave<1, 1024>;
+            using FW4 = evac::Wave<4, 1024>;
+            const int wpe = h->cu_wide4 ? 4 : 1, per_wg = h->cu_wide4 ? 4 : 16;
             const int E = h->p.n_envs, c = h->chain_gen;
             hipStream_t S = h->part_stream[c & 1], O = h->part_stream[(c + 1) & 1];
             // THE INVARIANT OF THE CHAIN: launch g + 1 must not start being dispatched before every workgroup of launch g has a CU.
@@ -993,11 +1016,20 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
             if (h->chain_restart) {
                 // the state in memory is whatever the caller's stream left: every env at generation c, one deal in all four
                 // permutation buffers, the other stream behind both
-                hipLaunchKernelGGL(evac::k_chain_import, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, S, h->p, h->chain_xchg, c, h->chain_abort, h->chain_wgs);
+                hipLaunchKernelGGL(evac::k_chain_import, dim3((unsigned)((E * wpe + 3) / 4)), dim3(256), 0, S, h->p, h->chain_xchg, c, h->chain_abort, h->chain_wgs, wpe);
                 hipLaunchKernelGGL(evac::k_schedule, dim3(1), dim3(1024), 0, S, E, (const int*)(moving + ((c + 3) & 3) * (size_t)E),
-                                   perm + (c & 3) * (size_t)E, (int32_t*)nullptr, 16, 1);
+                                   perm + (c & 3) * (size_t)E, (int32_t*)nullptr, per_wg, wpe == 4 ? 4 : 1, option_value("EVAC_CHAIN_DEAL", 0));
                 hipLaunchKernelGGL(evac::k_copy_perm3, dim3(64), dim3(256), 0, S, E, (const int*)(perm + (c & 3) * (size_t)E),
                                    perm + ((c + 1) & 3) * (size_t)E, perm + ((c + 2) & 3) * (size_t)E, perm + ((c + 3) & 3) * (size_t)E);
+                // ... and the OTHER queue behind all of this.  Its gate alone does not order it: until the import has set the counter the
+                // word holds whatever the workspace's memory held -- the caller's zero fill may not have run yet on this queue's
+                // timeline, a recycled allocation carries the count of the handle that used it before -- and a gate that passes on such a
+                // value starts launch c + 1 before the deal above exists: it then reads a permutation of ANOTHER batch (seen: a 64-env
+                // handle in memory a 512-env handle had used took env indices up to 511 -- tests/test_gpu_parity.py, whole file only).
+                if (hipEventRecord(h->chain_ev, S) != hipSuccess || hipStreamWaitEvent(O, h->chain_ev, 0) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return fail(h, EVAC_ERR_HIP, "evac_rollout: restart of the chain failed");
+                }
                 h->chain_start = c;
                 h->chain_restart = false;
             }
@@ -1011,12 +1043,22 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
                 (void)hipGetLastError();
                 return fail(h, EVAC_ERR_HIP, "evac_rollout: hipStreamWaitValue64 (the chain's dispatch gate) failed");
             }
-            evac::ChainArgs ca{h->chain_xchg, c, h->chain_abort, h->team_flag_dev, started};
+            static const int deal_mode = option_value("EVAC_CHAIN_DEAL", 0);                    // (diagnostic: A/B runs of one binary)
+            evac::ChainArgs ca{h->chain_xchg, c, h->chain_abort, h->team_flag_dev, deal_mode, started};
             evac::Params pp = h->p;
-            if (h->team_fault && c == h->chain_start + 1) pp.n_envs = E - 16;        // fault injection: the last workgroup of ONE launch is never run
+            if (h->team_fault && c == h->chain_start + 1) pp.n_envs = E - per_wg;    // fault injection: the last workgroup of ONE launch is never run
 #define EVAC_CHAIN_ARGS pp, (int)n_steps, (const float2*)actions, slab_out, final_stats, (const int*)(perm + (c & 3) * (size_t)E), (int*)(moving + (c & 3) * (size_t)E), (const int*)deal_loads, (int*)deal_perm, ca
-            const dim3 grid((unsigned)(E / FW::kEnvsPerBlock));
-            if (h->default_cfg && h->p.obs_pos == EVAC_POS_GRAV)
+            const dim3 grid((unsigned)(E / per_wg));
+            if (h->cu_wide4) {
+                if (h->default_cfg && h->p.obs_pos == EVAC_POS_GRAV)
+                    hipLaunchKernelGGL((evac::k_rollout_chain_default_config<FW4, true>), grid, dim3(FW4::kBlock), 0, S, EVAC_CHAIN_ARGS);
+                else if (h->default_cfg)
+                    hipLaunchKernelGGL((evac::k_rollout_chain_default_config<FW4, false>), grid, dim3(FW4::kBlock), 0, S, EVAC_CHAIN_ARGS);
+                else if (h->p.obs_pos == EVAC_POS_GRAV)
+                    hipLaunchKernelGGL((evac::k_rollout_chain<FW4, true>), grid, dim3(FW4::kBlock), 0, S, EVAC_CHAIN_ARGS);
+                else
+                    hipLaunchKernelGGL((evac::k_rollout_chain<FW4, false>), grid, dim3(FW4::kBlock), 0, S, EVAC_CHAIN_ARGS);
+            } else if (h->default_cfg && h->p.obs_pos == EVAC_POS_GRAV)
                 hipLaunchKernelGGL((evac::k_rollout_chain_default_config<FW, true>), grid, dim3(FW::kBlock), 0, S, EVAC_CHAIN_ARGS);
             else if (h->default_cfg)
                 hipLaunchKernelGGL((evac::k_rollout_chain_default_config<FW, false>), grid, dim3(FW::kBlock), 0, S, EVAC_CHAIN_ARGS);

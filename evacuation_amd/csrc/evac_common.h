@@ -734,7 +734,10 @@ __device__ __forceinline__ void store_env(const Params& p, int env, int i, bool 
 // Launch g waits for generation g, and publishes g + 1 behind its record stores.  k_chain_import fills the records from the
 // caller's arrays when a chain (re)starts; k_chain_export writes them back when the caller's stream joins (evac_join).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void store_dev(void* ptr, f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
+// (the trailing s_nop: a store of more than 64 bits reads its data registers for a cycle or two after it issues, and the compiler, which
+// does not know that this asm is a store, may let the next vector instruction overwrite them -- cdna_hip_programming.md 5.7; seen here as
+// records that came back wrong whenever a build's register allocation happened to reuse the data registers at once)
+__device__ __forceinline__ void store_dev(void* ptr, f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory"); }
 __device__ __forceinline__ void store_dev_i32(void* ptr, int v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
 __device__ __forceinline__ void load_dev(f4& v, const void* ptr) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory"); }
 __device__ __forceinline__ void load_dev_i32(int& v, const void* ptr) { asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory"); }
@@ -744,19 +747,27 @@ __device__ __forceinline__ int load_dev_i32_now(const void* ptr) {      // (issu
     asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(ptr) : "memory");
     return v;
 }
-constexpr int kXchgBytes = 1536, kXchgStatus = 1024, kXchgEnv = 1280, kXchgGen = 1408;
+// (T = lanes per env: 64 for one-wave envs -- the layout above --, 256 for four-wave envs: 16 T bytes of pedestrians, 4 T of statuses,
+// one line of env words, one line for the generation)
+template <int T>
+struct Xchg {
+    static constexpr int kStatus = 16 * T, kEnv = 20 * T, kGen = 20 * T + 128, kBytes = 20 * T + 256;
+};
+constexpr int xchg_bytes(int lanes_per_env) { return 20 * lanes_per_env + 256; }
 struct ChainArgs {
     char* xchg;          // [E] exchange records (kXchgBytes each, 128-byte aligned)
     int gen;             // this launch: waits for generation `gen`, publishes `gen + 1`
     unsigned* abort;     // device word (workspace, a line of its own): a wait of some launch timed out -- every later wait gives up at once
     unsigned* err;       // the handle's host-mapped error word (as the teams')
+    int deal_mode;       // diagnostic (EVAC_CHAIN_DEAL): how workgroup 0 deals the launch after next (schedule_slot); 0 in the product
     unsigned long long* started;   // workgroups of the chain's launches that have started (since the chain's last restart): what the
                                    // NEXT launch's queue waits for before it dispatches (evac_api.hip, "the invariant of the chain")
 };
 constexpr int kChainMaxPolls = 1 << 19;     // bounded wait: ~0.3 s of polls with the back-off below; a launch that gives up voids the run
 // Wait until the env's record holds generation `gen`.  Wave-uniform (all lanes poll the same word).  false: timed out.
+template <int T>
 __device__ __forceinline__ bool chain_wait(const ChainArgs& ch, int env) {
-    const char* addr = ch.xchg + (size_t)env * kXchgBytes + kXchgGen;
+    const char* addr = ch.xchg + (size_t)env * Xchg<T>::kBytes + Xchg<T>::kGen;
     int pause = 0;
     for (int polls = 0; polls < kChainMaxPolls; ++polls) {
         const int v = __builtin_amdgcn_readfirstlane(load_dev_i32_now(addr));
@@ -781,13 +792,14 @@ __device__ __forceinline__ void chain_give_up(const ChainArgs& ch, int lane, int
         __hip_atomic_store(ch.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-// the env's record -> registers (every lane loads; the per-env words come from lanes 0..2 of the env-word line)
-__device__ __forceinline__ void load_record(const char* rec, int lane, bool active, Ped& q, Env& e) {
+// the env's record -> registers (every lane loads its pedestrian `idx`; the per-env words come from lanes 0..2 of the env-word line)
+template <int T>
+__device__ __forceinline__ void load_record(const char* rec, int idx, int lane, bool active, Ped& q, Env& e) {
     f4 v, w;
     int st;
-    load_dev(v, rec + lane * 16);
-    load_dev_i32(st, rec + kXchgStatus + lane * 4);
-    load_dev(w, rec + kXchgEnv + (lane & 7) * 16);
+    load_dev(v, rec + idx * 16);
+    load_dev_i32(st, rec + Xchg<T>::kStatus + idx * 4);
+    load_dev(w, rec + Xchg<T>::kEnv + (lane & 7) * 16);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(v), "+v"(w), "+v"(st)::"memory");
     const float wx = w.x, wy = w.y, wz = w.z, ww = w.w;
     e.ax = readlane_const<0>(wx); e.ay = readlane_const<0>(wy); e.adx = readlane_const<0>(wz); e.ady = readlane_const<0>(ww);
@@ -797,15 +809,17 @@ __device__ __forceinline__ void load_record(const char* rec, int lane, bool acti
     q.x = active ? v.x : 0.0f; q.y = active ? v.y : 0.0f; q.dx = active ? v.z : 0.0f; q.dy = active ? v.w : 0.0f;
     q.st = active ? st : 0;
 }
-// registers -> the env's record: three store instructions, every line written whole by one of them (all 64 lanes store)
-__device__ __forceinline__ void store_record(char* rec, int lane, bool active, const Ped& q, const Env& e) {
-    store_dev(rec + lane * 16, active ? f4{q.x, q.y, q.dx, q.dy} : f4{0.0f, 0.0f, 0.0f, 0.0f});
-    store_dev_i32(rec + kXchgStatus + lane * 4, active ? q.st : 0);
-    if (lane < 8) {
+// registers -> the env's record: three store instructions, every line written whole by one of them (all 64 lanes of a wave store:
+// 8 lines of pedestrians, 2 of statuses; `words`: this wave also writes the line of env words -- the env's first wave)
+template <int T>
+__device__ __forceinline__ void store_record(char* rec, int idx, int lane, bool words, bool active, const Ped& q, const Env& e) {
+    store_dev(rec + idx * 16, active ? f4{q.x, q.y, q.dx, q.dy} : f4{0.0f, 0.0f, 0.0f, 0.0f});
+    store_dev_i32(rec + Xchg<T>::kStatus + idx * 4, active ? q.st : 0);
+    if (words && lane < 8) {
         const f4 a = f4{e.ax, e.ay, e.adx, e.ady};
         const f4 c = f4{__builtin_bit_cast(float, e.now), __builtin_bit_cast(float, e.n_resets), __builtin_bit_cast(float, (int)e.total), 0.0f};
         const f4 k = f4{e.acc_ret, e.acc_intr, e.acc_stat, 0.0f};
-        store_dev(rec + kXchgEnv + lane * 16, lane == 0 ? a : (lane == 1 ? c : (lane == 2 ? k : f4{0.0f, 0.0f, 0.0f, 0.0f})));
+        store_dev(rec + Xchg<T>::kEnv + lane * 16, lane == 0 ? a : (lane == 1 ? c : (lane == 2 ? k : f4{0.0f, 0.0f, 0.0f, 0.0f})));
     }
 }
 

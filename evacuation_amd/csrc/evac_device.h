@@ -325,7 +325,12 @@ __device__ __forceinline__ int simd_wave_slot() {   // slot of this wave among t
 __device__ __forceinline__ int schedule_bin(int load, int unit) { return min(max(load / unit, 0), kWave); }
 // rank by load (ascending) -> slot.  Workgroup 0 takes the per_wg LIGHTEST envs of the batch (it deals the next launch's envs
 // before it starts stepping -- rollout_body -- and must still be done before the others); the rest is dealt in snake order.
-__device__ __forceinline__ int schedule_slot(int r, int n_envs, int per_wg) {
+// (mode: a run-time switch of the CHAINED launches' deal, for A/B runs of ONE binary -- this kernel's speed depends on its register
+// allocation more than on most source changes, so compile-time variants cannot be compared: 1 = envs of similar load share a
+// workgroup, lightest workgroups first; 2 = heaviest first; 0 = the snake deal below)
+__device__ __forceinline__ int schedule_slot(int r, int n_envs, int per_wg, int mode = 0) {
+    if (mode == 1) return r;
+    if (mode == 2) return n_envs - 1 - r;
     const int e16 = n_envs & ~(per_wg - 1);  // the last, partial workgroup: as ranked
     if (r < per_wg || r >= e16) return r;
     r -= per_wg;
@@ -339,7 +344,7 @@ __device__ __forceinline__ int schedule_slot(int r, int n_envs, int per_wg) {
 // The counting sort by ONE workgroup of 1024 threads (hist: kWave + 2 ints of LDS; all 16 waves call it together): as a launch
 // of its own (k_schedule) and at the start of workgroup 0 of a rollout launch (rollout_body).
 __device__ __forceinline__ void schedule_envs_by_workgroup(int* hist, int tid, int n_envs, const int* __restrict__ loads,
-                                                           int* __restrict__ perm, int per_wg, int unit) {
+                                                           int* __restrict__ perm, int per_wg, int unit, int mode = 0) {
     constexpr int kPer = 4;                  // envs per thread and pass: their loads are fetched back to back (one memory latency, not four)
     if (tid < kWave + 2) hist[tid] = 0;
     __syncthreads();
@@ -376,7 +381,7 @@ __device__ __forceinline__ void schedule_envs_by_workgroup(int* hist, int tid, i
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
             const int e = base + k * 1024 + tid;
-            if (e < n_envs) perm[schedule_slot(r[k], n_envs, per_wg)] = e;
+            if (e < n_envs) perm[schedule_slot(r[k], n_envs, per_wg, mode)] = e;
         }
     }
 }
@@ -611,18 +616,35 @@ __device__ __forceinline__ void rollout_body(
         if (deal_perm && blockIdx.x == 0) {    // (workgroup-uniform; the host passes deal_perm only for batches of >= one full workgroup)
             const int lightest = deal_loads[perm[0]];
             if (4 * lightest <= 3 * p.n_ped)
-                schedule_envs_by_workgroup(sm.deal_hist, (int)threadIdx.x, p.n_envs, deal_loads, deal_perm, F::kEnvsPerBlock, F::WPE == 1 ? 1 : 4);
+                schedule_envs_by_workgroup(sm.deal_hist, (int)threadIdx.x, p.n_envs, deal_loads, deal_perm, F::kEnvsPerBlock, F::WPE == 1 ? 1 : 4,
+                                           CHAIN ? chain.deal_mode : 0);
         }
     }
     if constexpr (CHAIN) {
         // (a chained launch deals -- above -- BEFORE it waits: the sort of workgroup 0 runs under the hand-off of its envs.  The
         // permutation it writes is read two launches later, by the next launch of THIS queue: in order, no flag needed.)
-        static_assert(F::WPE == 1 && !F::kHelpers, "chained launches: one-wave envs (no barrier that a wave giving up could leave others at)");
-        if (!chain_wait(chain, w.env)) {      // (wave-uniform) the env's state never came: void run, the host is told
-            chain_give_up(chain, w.lane, w.env);
-            return;
+        static_assert(F::kPace && !F::kHelpers, "chained launches: the CU-wide families (one-wave envs, and four-wave envs with a barrier per env)");
+        constexpr int T = F::kThreadsPerEnv;
+        if constexpr (F::WPE == 1) {
+            if (!chain_wait<T>(chain, w.env)) {      // (wave-uniform) the env's state never came: void run, the host is told
+                chain_give_up(chain, w.lane, w.env);
+                return;
+            }
+            load_record<T>(chain.xchg + (size_t)w.env * Xchg<T>::kBytes, w.lane, w.lane, active, q, e);
+        } else {
+            // several waves per env: its first wave waits, the others meet it at the env's barrier and take ITS verdict -- one
+            // poller per env, and all waves of the env leave together should the wait give up
+            if (w.wave_in_env == 0) {
+                const bool ok = chain_wait<T>(chain, w.env);
+                if (w.lane == 0) sm.chain_ok[w.slot] = ok ? 1 : 0;
+            }
+            F::sync(w);
+            if (sm.chain_ok[w.slot] == 0) {
+                if (w.wave_in_env == 0) chain_give_up(chain, w.lane, w.env);
+                return;
+            }
+            load_record<T>(chain.xchg + (size_t)w.env * Xchg<T>::kBytes, w.i, w.lane, active, q, e);
         }
-        load_record(chain.xchg + (size_t)w.env * kXchgBytes, w.lane, active, q, e);
     }
     const uint32_t gid = p.env_id_offset + (uint32_t)w.env;
     const size_t E = (size_t)p.slab_envs;
@@ -877,10 +899,18 @@ __device__ __forceinline__ void rollout_body(
         if (F::aborted(w)) return;      // a team that lost a member: void results, the env keeps its pre-launch state
     }
     if constexpr (CHAIN) {
-        char* rec = chain.xchg + (size_t)w.env * kXchgBytes;
-        store_record(rec, w.lane, active, q, e);
-        wait_vmem();                                       // every lane's record stores are acknowledged ...
-        if (w.lane == 0) store_dev_i32(rec + kXchgGen, chain.gen + 1);      // ... before the next launch's wave may load them
+        constexpr int T = F::kThreadsPerEnv;
+        char* rec = chain.xchg + (size_t)w.env * Xchg<T>::kBytes;
+        if constexpr (F::WPE == 1) {
+            store_record<T>(rec, w.lane, w.lane, true, active, q, e);
+            wait_vmem();                                       // every lane's record stores are acknowledged ...
+            if (w.lane == 0) store_dev_i32(rec + Xchg<T>::kGen, chain.gen + 1);      // ... before the next launch's wave may load them
+        } else {
+            store_record<T>(rec, w.i, w.lane, w.wave_in_env == 0, active, q, e);
+            wait_vmem();
+            F::sync(w);                                        // ... of EVERY wave of the env
+            if (w.wave_in_env == 0 && w.lane == 0) store_dev_i32(rec + Xchg<T>::kGen, chain.gen + 1);
+        }
     } else {
         store_env(p, w.env, w.i, active, w.owner, q, e);
     }
@@ -959,8 +989,9 @@ __global__ __launch_bounds__(F::kBlock, 4) void k_rollout_chain_default_config(
 // the three other buffers of the four-deep rotation
 // one wave per env: the caller's state arrays -> the env's exchange record at generation `gen` (a chain starts) ...
 __global__ __launch_bounds__(256) void k_chain_import(Params p, char* __restrict__ xchg, int gen, unsigned* __restrict__ abort_word,
-                                                      unsigned long long started_so_far) {
-    const int env = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+                                                      unsigned long long started_so_far, int wpe) {
+    // (one wave per 64 pedestrians of an env: wave `part` of env `env`; T = 64 wpe lanes per env)
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), env = wv / wpe, part = wv - env * wpe, lane = threadIdx.x & 63, T = 64 * wpe;
     if (blockIdx.x == 0 && threadIdx.x < 8) abort_word[threadIdx.x] = 0u;      // (the abort word and its diagnostics)
     // the started-workgroups counter behind them is SET to what the host has enqueued so far -- every one of those workgroups has
     // run: a restart follows a join --, so that a caller who restored a snapshot of the workspace (bench.py's replays) and told the
@@ -969,19 +1000,21 @@ __global__ __launch_bounds__(256) void k_chain_import(Params p, char* __restrict
     if (blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_store((unsigned long long*)(abort_word + 8), started_so_far, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (env >= p.n_envs) return;
-    const bool active = lane < p.n_ped;
+    const int idx = part * 64 + lane;
+    const bool active = idx < p.n_ped;
     Ped q;
     Env e;
-    load_env(p, env, lane, active, q, e);
-    char* rec = xchg + (size_t)env * kXchgBytes;
+    load_env(p, env, idx, active, q, e);
+    char* rec = xchg + (size_t)env * xchg_bytes(T);
+    const int kXchgStatus = 16 * T, kXchgEnv = 20 * T, kXchgGen = 20 * T + 128;
     // PLAIN stores, made visible by the kernel boundary like any kernel's output.  (`sc1` stores here were wrong: the workspace comes
     // zero-filled by plain stores, and in the first launch after an import ~1.5 of a record's 12 lines read back as zeros -- a copy a
     // plain store left in some XCD's L2 is not refreshed by another XCD's write-through store; tools/chain_debug.py.  Inside the chain
     // a record's reader is its next writer and its `sc1` store drops the line, so no such copy exists: 10^6 chained steps against the
     // plain kernels, with restarts and joins in between, bit for bit -- tools/soak_variants.py.)
-    *(f4*)(rec + lane * 16) = active ? f4{q.x, q.y, q.dx, q.dy} : f4{0.0f, 0.0f, 0.0f, 0.0f};
-    *(int*)(rec + kXchgStatus + lane * 4) = active ? q.st : 0;
-    if (lane == 0) {
+    *(f4*)(rec + idx * 16) = active ? f4{q.x, q.y, q.dx, q.dy} : f4{0.0f, 0.0f, 0.0f, 0.0f};
+    *(int*)(rec + kXchgStatus + idx * 4) = active ? q.st : 0;
+    if (idx == 0) {
         *(f4*)(rec + kXchgEnv) = f4{e.ax, e.ay, e.adx, e.ady};
         *(f4*)(rec + kXchgEnv + 16) = f4{__builtin_bit_cast(float, e.now), __builtin_bit_cast(float, e.n_resets), __builtin_bit_cast(float, (int)e.total), 0.0f};
         *(f4*)(rec + kXchgEnv + 32) = f4{e.acc_ret, e.acc_intr, e.acc_stat, 0.0f};
@@ -989,14 +1022,16 @@ __global__ __launch_bounds__(256) void k_chain_import(Params p, char* __restrict
     }
 }
 // ... and back (the caller's stream joins: its arrays are the state again)
-__global__ __launch_bounds__(256) void k_chain_export(Params p, const char* __restrict__ xchg) {
-    const int env = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+__global__ __launch_bounds__(256) void k_chain_export(Params p, const char* __restrict__ xchg, int wpe) {
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), env = wv / wpe, part = wv - env * wpe, lane = threadIdx.x & 63;
     if (env >= p.n_envs) return;
-    const bool active = lane < p.n_ped;
+    const int idx = part * 64 + lane;
+    const bool active = idx < p.n_ped;
     Ped q;
     Env e;
-    load_record(xchg + (size_t)env * kXchgBytes, lane, active, q, e);
-    store_env(p, env, lane, active, lane == 0, q, e);
+    if (wpe == 1) load_record<64>(xchg + (size_t)env * Xchg<64>::kBytes, idx, lane, active, q, e);
+    else load_record<256>(xchg + (size_t)env * Xchg<256>::kBytes, idx, lane, active, q, e);
+    store_env(p, env, idx, active, idx == 0, q, e);
 }
 __global__ void k_copy_perm3(int n_envs, const int* __restrict__ src, int* __restrict__ a, int* __restrict__ b, int* __restrict__ c) {
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_envs; e += gridDim.x * blockDim.x) {
@@ -1009,9 +1044,9 @@ __global__ void k_copy_perm3(int n_envs, const int* __restrict__ src, int* __res
 // (perm_other: the second permutation buffer of the schedule, brought to the same deal -- a rollout launch that skips its own
 // deal leaves whatever that buffer holds to the launch after it)
 __global__ __launch_bounds__(1024) void k_schedule(int n_envs, const int* __restrict__ moving, int* __restrict__ perm, int* __restrict__ perm_other,
-                                                   int per_wg, int unit) {
+                                                   int per_wg, int unit, int mode = 0) {
     __shared__ int hist[kWave + 2];
-    schedule_envs_by_workgroup(hist, (int)threadIdx.x, n_envs, moving, perm, per_wg, unit);
+    schedule_envs_by_workgroup(hist, (int)threadIdx.x, n_envs, moving, perm, per_wg, unit, mode);
     if (perm_other) {
         __syncthreads();                     // (this workgroup's own global stores are visible to it after the barrier)
         for (int e = threadIdx.x; e < n_envs; e += 1024) perm_other[e] = perm[e];

@@ -71,6 +71,7 @@ struct Wave {
         alignas(16) int progress[kPace ? 16 : 4];                  // kPace: step counter of every wave, [SIMD][wave of the SIMD]
         int pace_sink[kPace ? 16 : 1][kPace ? kWave : 1];           // kPace: where lanes 1..63 of a wave store when lane 0 publishes the counter
         int deal_hist[kPace ? kWave + 2 : 1];                      // kPace: histogram of workgroup 0's sort of the next launch's envs (rollout_body)
+        int chain_ok[kEnvsPerBlock];                               // chained launches of multi-wave envs: did the env's first wave see its generation?
     };
 
     struct Ctx {

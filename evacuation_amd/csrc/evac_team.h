@@ -62,6 +62,15 @@ __device__ __forceinline__ void lds_add(int* ptr, int v) { (void)__hip_atomic_fe
 // are gone.  (An 8-byte half is the unit the tags protect: positions and float sums have no spare bits, so they travel next to a
 // tagged word; global accesses of a lane are not torn below that on this hardware -- and tools/soak_variants.py compares every
 // launch of 10^6 steps with the one-workgroup kernels bit for bit.)
+// THE INVARIANT this rests on (nothing enforces it at run time): a slot of set (round & 1) that a reader polls in round r
+// must not still hold a tag equal to r mod 31 from an EARLIER round, i.e. every slot is rewritten at least once in any 62 consecutive
+// rounds of its set's parity.  Today: stage_next publishes a tile entry from every ped lane on every step, reduce_publish a record
+// from every ped wave on every step; the only rounds without a tile are the first step of a launch and the step after an autoreset
+// (the host refills the area with tag 31 before a launch), so a slot is at most 4 rounds old when it is polled.  A future path that
+// could skip publishing for 62 rounds (records-only or tile-only rounds in a row) must widen the tag or reset the slot -- a stale
+// slot would validate as fresh without any error.  And the 8-byte half must stay the store granule (16-byte sc1 stores are observed
+// untorn below 8 bytes on gfx950; not an architectural guarantee): both are what tools/soak_variants.py watches over.
+static_assert((1 << 5) - 1 == 31, "tags are taken mod 31: five bits, the all-ones pattern reserved for the host's 0xff fill");
 constexpr int kTeamSets = 2;
 constexpr int kTagBits = 5, kTagMod = 31;
 constexpr int kEntryTagShift = 24;                          // heading words: 24-bit field | tag << 24 | flags (bits 29, 30)

@@ -254,9 +254,20 @@ def peer_store_probe(device, group=None, rows: int = 256, row_words: int = 9, ta
 
     err, peers, handles, g = None, None, None, None
     try:
+        from torch.multiprocessing.reductions import reduce_tensor
         slab = torch.zeros((rows, row_words), dtype=torch.float32, device=device)
         gathered = torch.zeros((world, rows, take), dtype=torch.float32, device=device)
-        handles = _exchange_handles(gathered, group)
+        #  the export itself can fail on ONE rank (hipIpcGetMemHandle): it is made outside the collective and a failure
+        # travels as None, as in PeerStoreGather.try_build -- nobody is left waiting in all_gather_object
+        mine = None
+        try:
+            mine = reduce_tensor(gathered)
+        except Exception as exc:  # noqa: BLE001
+            err = f"{type(exc).__name__}: {exc}"
+        handles = [None] * world
+        dist.all_gather_object(handles, mine, group=group)
+        if not agree(err):
+            return info
         try:
             peers = _open_handles(handles, gathered, group)
         except Exception as exc:  # noqa: BLE001
@@ -276,6 +287,11 @@ def peer_store_probe(device, group=None, rows: int = 256, row_words: int = 9, ta
         info["stage"] = "store"
         try:
             g = PeerStoreGather(slab, take, gathered, group=group, _mapped=(peers, handles))
+        except Exception as exc:  # noqa: BLE001
+            err = f"{type(exc).__name__}: {exc}"
+        if not agree(err):                      # (a rank whose constructor raised must not meet the others inside self_test's barrier)
+            return info
+        try:
             t0 = time.perf_counter()
             g.self_test()
             info["store_ms"] = (time.perf_counter() - t0) * 1e3

@@ -99,12 +99,31 @@ class HostVectorEnv:
     # a small pool, and an array goes out again only when NOBODY holds it any more (its reference count is back to the pool's own:
     # views, ``torch.from_numpy`` tensors and slices all hold the base array); otherwise a new one takes its slot.
     _POOL = 4
+    _FREE_REFCOUNT = None      # what sys.getrefcount says of a pooled array nobody else holds: measured once, not assumed
+
+    @classmethod
+    def _free_refcount(cls) -> int:
+        """The reference count `_fresh` sees for an array that only the pool holds -- the pool's slot, the local name and
+        getrefcount's own argument on CPython 3.10, but an interpreter that borrows stack references counts differently: measured with
+        the very access pattern `_fresh` uses.  -1: no usable reference counts (not CPython): every array is then made fresh."""
+        if cls._FREE_REFCOUNT is None:
+            if not hasattr(sys, "getrefcount"):
+                cls._FREE_REFCOUNT = -1
+            else:
+                pool = [np.empty(1, dtype=np.float32)]
+                a = pool[0]
+                free = sys.getrefcount(a)
+                held = a                                   # one more holder must be visible, or the count tells nothing
+                cls._FREE_REFCOUNT = free if sys.getrefcount(a) == free + 1 else -1
+                del held
+        return cls._FREE_REFCOUNT
 
     def _fresh(self, kind: int, shape, dtype):
         pool = self._pools[kind]
         i = self._pool_next[kind] = (self._pool_next[kind] + 1) % self._POOL
         a = pool[i]
-        if a is None or sys.getrefcount(a) != 3:          # (3 = the pool's slot + the local name + getrefcount's argument)
+        free = self._free_refcount()
+        if a is None or free < 0 or sys.getrefcount(a) > free:      # (somebody still holds it -- or the counts cannot be trusted: a new one)
             a = pool[i] = np.empty(shape, dtype=dtype)
         return a
 

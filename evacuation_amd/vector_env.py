@@ -270,6 +270,11 @@ class BatchedEvacuationEnv:
             st = self._stream() if stream is None else C.c_void_p(stream.cuda_stream)
             _lib.check(self.lib.evac_join(self._h, st), self._h)
 
+    def order_next_rollout(self) -> None:
+        """The next ``rollout_launcher`` launch follows what the launching stream holds at that moment (``evac_order_next_rollout``)."""
+        if self.own_streams:
+            self.lib.evac_order_next_rollout(self._h)
+
     def part_streams(self):
         """The handle's own streams (``options.parts = 2``) as ``torch.cuda.ExternalStream`` objects, for timing events; else ``[]``."""
         return [torch.cuda.ExternalStream(int(self.lib.evac_part_stream(self._h, k)), device=self.device) for k in range(self.own_streams)]
@@ -479,8 +484,9 @@ class BatchedEvacuationEnv:
         """A zero-argument callable that enqueues ``rollout(n_steps, out=out)`` (RandomAgent actions) with all ctypes
         arguments prepared once: for loops that launch the same shape many times.  On the stream that is current at
         each call, or always on ``stream`` (a torch stream) if one is given -- which saves the lookup, ~1.5 us per call.
-        With ``options.parts = 2`` the two half-batch kernels go to the handle's own streams behind what the launching stream holds,
-        and NOTHING waits for them until ``join()``.
+        With ``options.parts = 2`` / ``options.chain = 1`` the kernels go to the handle's own streams, which are put behind what the
+        launching stream holds ONCE per ``join()`` (at the first launch after it), and NOTHING waits for them until ``join()``: keep
+        ``out`` alive and untouched on your stream until then (``order_next_rollout()`` if you did touch it).
         The call only ENQUEUES: for rooms of more than 512 pedestrians (team kernels) poll ``team_error(sync=False)`` after waiting
         for the launch and before consuming its slab -- a launch that lost a team member still returns success here."""
         T, E, D = int(n_steps), self.num_envs, self.obs_dim
@@ -540,6 +546,10 @@ class BatchedEvacuationEnv:
             out["positions"], out["statuses"] = traj[:, :, :self.n_ped, 0:2], traj[:, :, :self.n_ped, 2]
             out["agent_positions"] = traj[:, :, self.n_ped, 0:2]
         nz = self._as_device(noise, (T, E, self.n_ped), torch.float32, "noise")
+        if self.own_streams:
+            # (the outputs may be fresh from torch's stream-ordered allocator -- memory that kernels still queued on the current stream
+            # may be using -- and `episode_stats` is zero-filled on the current stream: the handle's own streams must follow all that)
+            self.lib.evac_order_next_rollout(self._h)
         _lib.check(self.lib.evac_rollout(self._h, T, _ptr(act), _ptr(out.get("actions")), _ptr(slab),
                                          _ptr(out.get("episode_stats")), k_cap, _ptr(traj), _ptr(nz), self._stream()), self._h)
         self.join()                   # (two parts: the returned tensors are ordered behind the launch on the current stream, as ever)

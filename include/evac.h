@@ -199,6 +199,11 @@ int evac_destroy(evac_handle_t h);
  * evac_team_clear_error(), and the handle issues plain launches from then on.
  * evac_own_streams: 0, or 2 for handles with parts = 2 or chain = 1 (the kernels in flight per rollout round). */
 int evac_join(evac_handle_t h, void* stream);
+/* The NEXT evac_rollout call puts the handle's own streams behind what its `stream` holds at that moment, as the first call after a
+ * join does: for a caller who, between two rollout calls and without a join, gave `stream` work the coming launches must follow -- a
+ * freshly allocated or refilled output buffer (a stream-ordered allocator hands out memory that kernels still queued on `stream`
+ * may be using), new workspace contents.  The Python host's rollout(), which allocates its outputs, calls it every time. */
+int evac_order_next_rollout(evac_handle_t h);
 int32_t evac_num_parts(evac_handle_t h);
 int32_t evac_own_streams(evac_handle_t h);
 void* evac_part_stream(evac_handle_t h, int32_t part);

@@ -44,6 +44,10 @@ def test_two_ranks_on_one_gpu(extra):
     form = rep["timed_form"]
     assert form == {"slab": "slab", "direct": "direct", "peer": "peer", "auto": "peer"}.get(extra[1] if extra[:1] == ["--gather"] else "", "obs") == d["config"]["gather"]
     for x in rep["per_rank"]:
+        #  every rank's own clock over the headline sweeps: a slow rank shows; the job's value is the slowest rank's
+        # (`value` itself may be the settled median of the sustained sweeps: only the headline sweeps' own figures are compared)
+        assert x["headline"]["env_steps_per_s_of_this_rank"] > 0 and len(x["headline"]["sweep_wall_ms_this_rank"]) == d["config"]["sweeps"]["timed"]
+        assert x["headline"]["value_if_every_rank_were_this_one"] >= 0.999 * d["config"]["sweeps"]["value_min_median_max"][0]
         assert x[form]["world"] == 2 and x[form]["gather_ms_alone"] > 0 and x[form]["bytes_received_per_chunk"] == x[form]["bytes_per_link_per_chunk"] > 0
     if "split" not in extra and form in ("obs", "peer"):
         assert rep["alternative_form"] == ("peer" if form == "obs" else "obs") and rep["alternative_value"] > 0

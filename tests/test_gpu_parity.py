@@ -546,6 +546,8 @@ def test_two_parts_on_the_handles_own_streams_equal_one_kernel(ea, n, E, wrap_kw
     (60, 512, dict(positions="grav", alpha=3), 7),                            # CU-wide forced on a small batch, odd launch length
     (33, 64, dict(positions="rel", statuses="ohe", type="Box"), 10),          # generic observation, four workgroups
     (64, 160, dict(positions="abs", statuses="cat", type="Dict"), 5),         # the env fills its wave; generic kernels (not the default configuration)
+    (256, 1024, dict(positions="grav", alpha=3), 20),                         # BASELINE config 3: four waves per env, four envs per CU-wide workgroup
+    (200, 52, dict(positions="rel", statuses="ohe", type="Box"), 6),          # four-wave envs that do not fill their lanes, 13 workgroups, Box observation
 ])
 def test_chained_launches_equal_plain_launches(ea, n, E, wrap_kw, T):
     """evac_options_t.chain = 1: consecutive rollout launches on two queues, ordered per env by generation

@@ -2,7 +2,8 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import evacuation_amd as ea
-E, T, n = int(sys.argv[1]) if len(sys.argv) > 1 else 512, 7, 60
+E, n = int(sys.argv[1]) if len(sys.argv) > 1 else 512, 60
+T = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 sync_each = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=45, is_new_exiting_reward=True, is_new_followers_reward=True)
 wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)

@@ -22,7 +22,10 @@ def kernel_variant(key, envs):
     n_ped, _, wrap_kw, _ = bench.WORKLOADS[workload]
     cfg = ea.EnvConfig(number_of_pedestrians=n_ped, is_new_exiting_reward=True, is_new_followers_reward=True,
                        intrinsic_reward_coef=0.0, max_timesteps=bench.EPISODE)
-    env = ea.BatchedEvacuationEnv(cfg, ea.EnvWrappersConfig(**wrap_kw), num_envs=int(envs))
+    # (the options bench.py's headline takes on one GPU: chained launches where the library offers them -- the C2 rollout; the side
+    # workloads and the per-step runs are plain handles)
+    opts = ea.KernelOptions(chain=-1) if mode == "rollout" else None
+    env = ea.BatchedEvacuationEnv(cfg, ea.EnvWrappersConfig(**wrap_kw), num_envs=int(envs), options=opts)
     env.reset()
     if mode == "rollout":
         env.rollout(2)                      # (the team kernels' residency check runs at the first rollout)

@@ -61,6 +61,17 @@ if "e" in which:
     timed("e) one handle, CHAINED launches           ", [env.rollout_launcher(T, out)], [env.join], 4096)
     print("   team/chain error word:", env.team_error(), env.kernel_variant())
     env.close()
+if "f" in which or "g" in which:          # BASELINE config 3 (N = 256 x 1024 envs, four waves per env): plain and chained
+    cfg3 = ea.EnvConfig(number_of_pedestrians=256, is_new_exiting_reward=True, is_new_followers_reward=True, max_timesteps=2000)
+    for tag, opt in (("f) C3 one handle, one kernel per launch  ", dict(chain=0)), ("g) C3 one handle, CHAINED launches       ", dict(chain=1))):
+        if tag[0] not in which:
+            continue
+        env = ea.BatchedEvacuationEnv(cfg3, wrap, num_envs=1024, seed=0x5EED0003, options=ea.KernelOptions(**opt))
+        env.reset()
+        out = {"slab": torch.empty((T, 1024, env.obs_dim + 3), device=dev), "episode_stats": torch.zeros((T, 1024, env.stats_words), device=dev)}
+        timed(tag, [env.rollout_launcher(T, out)], [env.join], 1024, sweeps=8, warm=min(WARM, 60))
+        print("   error word:", env.team_error(), env.kernel_variant())
+        env.close()
 if "c" in which:
     s1 = torch.cuda.current_stream(); s2 = side_stream(dev, beside=s1)
     (ea_, oa), (eb, ob) = make(4096, 1, parts=1), make(4096, 2, parts=1)
