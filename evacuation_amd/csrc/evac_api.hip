@@ -10,6 +10,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "evac_device.h"
 #include "evac_subwave.h"
@@ -106,6 +107,7 @@ struct evac_handle {
     int chain_start;          // the launch at which the chain (re)started: deals begin two launches later
     bool chain_restart;       // the state was written by something else than the chain's last launch: fill the generation words first
     int32_t* chain_sched;     // moving[4][E] | perm[4][E]
+    size_t chain_xchg_bytes;  // (what the pool handed out: given back with it)
     char* chain_xchg;         // [E] exchange records (evac_common.h): the state between the chain's launches
     unsigned* chain_abort;    // device word: a wait timed out
     bool chain_dirty;         // the records are ahead of the caller's state arrays (k_chain_export at the next join)
@@ -272,6 +274,76 @@ int option_value(const char* env_name, int option) {
     return option;
 }
 
+// ---- What a handle allocates from the device ITSELF -- its two streams, the chain's uncached exchange records, the host-mapped error
+// word -- is taken from pools that live as long as the process and goes back to them when the handle is destroyed; nothing of it is
+// ever given back to HIP.  Creating and freeing these per handle re-used device addresses (and hardware queues) at a high rate under
+// whatever else the process runs, and on some MI355X boxes a process that did so read stale memory through OTHER allocations for a
+// while afterwards (tests/test_gpu_parity.py's chained cases, in their first iterations only, serialised launches included:
+// DESIGN.md "the pools").  A process that creates a thousand handles now makes one pair of streams.
+struct PooledPair { int device; hipStream_t s[2]; };
+struct PooledBuf { int device; size_t bytes; void* p; };
+struct PooledWord { int device; void* host; void* dev; };
+std::mutex g_pool_mu;
+std::vector<PooledPair> g_pool_pairs;
+std::vector<PooledBuf> g_pool_bufs;
+std::vector<PooledWord> g_pool_words;
+bool pools_on() { static const bool on = option_value("EVAC_DIAG_NO_POOLS", 0) == 0; return on; }
+
+// 64 bytes of host memory the device can write (the error word of the team kernels and of the chain), zeroed
+bool take_error_word(int device, void** host, void** dev) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool_words.size(); ++i)
+            if (g_pool_words[i].device == device) {
+                *host = g_pool_words[i].host; *dev = g_pool_words[i].dev;
+                g_pool_words.erase(g_pool_words.begin() + (long)i);
+                std::memset(*host, 0, 64);
+                return true;
+            }
+    }
+    *host = *dev = nullptr;
+    if (hipHostMalloc(host, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(dev, *host, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (*host) (void)hipHostFree(*host);
+        *host = *dev = nullptr;
+        return false;
+    }
+    std::memset(*host, 0, 64);
+    return true;
+}
+void give_error_word(int device, void* host, void* dev) {
+    if (!host) return;
+    if (!pools_on()) { (void)hipHostFree(host); return; }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_words.push_back(PooledWord{device, host, dev});
+}
+// uncached device memory of at least `bytes` (the caller fills it)
+void* take_uncached(int device, size_t bytes, size_t* got) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        size_t best = g_pool_bufs.size();
+        for (size_t i = 0; i < g_pool_bufs.size(); ++i)
+            if (g_pool_bufs[i].device == device && g_pool_bufs[i].bytes >= bytes && g_pool_bufs[i].bytes <= 2 * bytes + (1u << 16) &&
+                (best == g_pool_bufs.size() || g_pool_bufs[i].bytes < g_pool_bufs[best].bytes)) best = i;
+        if (best < g_pool_bufs.size()) {
+            void* p = g_pool_bufs[best].p;
+            *got = g_pool_bufs[best].bytes;
+            g_pool_bufs.erase(g_pool_bufs.begin() + (long)best);
+            return p;
+        }
+    }
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    *got = bytes;
+    return p;
+}
+void give_uncached(int device, void* p, size_t bytes) {
+    if (!p) return;
+    if (!pools_on()) { (void)hipFree(p); return; }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_bufs.push_back(PooledBuf{device, bytes, p});
+}
+
 int create_impl(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint64_t seed, uint64_t env_id_offset,
                 const evac_options_t& o, evac_handle_t* out) {
     if (!out) { g_create_error = "out is NULL"; return EVAC_ERR_INVALID_ARGUMENT; }
@@ -304,6 +376,7 @@ int create_impl(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
     h->chain_restart = true;
     h->chain_sched = nullptr;
     h->chain_xchg = nullptr;
+    h->chain_xchg_bytes = 0;
     h->chain_abort = nullptr;
     h->chain_dirty = false;
     h->chain_wgs = 0;
@@ -417,12 +490,9 @@ int create_impl(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
             DeviceGuard g(device);
             void* host = nullptr;
             void* dev = nullptr;
-            if (hipHostMalloc(&host, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dev, host, 0) != hipSuccess) {
-                (void)hipGetLastError();
-                if (host) (void)hipHostFree(host);
+            if (!take_error_word(device, &host, &dev)) {
                 h->team_k = 0;                       // no error word, no teams
             } else {
-                std::memset(host, 0, 64);
                 h->team_flag_host = (volatile unsigned*)host;
                 h->team_flag_dev = (unsigned*)dev;
                 int coop = 0;
@@ -486,6 +556,23 @@ float spin_pair_ms(hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent_t e1, h
 bool make_part_streams(evac_handle* h) {
     DeviceGuard g(h->device);
     hipEvent_t e0 = nullptr, e1 = nullptr, eb = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool_pairs.size(); ++i)
+            if (g_pool_pairs[i].device == h->device) {        // a pair an earlier handle found to overlap, idle since that handle was destroyed
+                h->part_stream[0] = g_pool_pairs[i].s[0];
+                h->part_stream[1] = g_pool_pairs[i].s[1];
+                g_pool_pairs.erase(g_pool_pairs.begin() + (long)i);
+                break;
+            }
+    }
+    if (h->part_stream[0]) {
+        bool ok = true;
+        for (int k = 0; ok && k < 2; ++k) ok = hipEventCreateWithFlags(&h->part_done[k], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        return ok;
+    }
     bool ok = hipStreamCreateWithFlags(&h->part_stream[0], hipStreamNonBlocking) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
               hipEventCreate(&e1) == hipSuccess && hipEventCreate(&eb) == hipSuccess;
     if (ok) {
@@ -514,18 +601,25 @@ bool make_part_streams(evac_handle* h) {
 }
 void destroy_parts(evac_handle* h) {
     DeviceGuard g(h->device);
+    for (int k = 0; k < 2; ++k)
+        if (h->part_stream[k]) (void)hipStreamSynchronize(h->part_stream[k]);
+    if (h->part_stream[0] && h->part_stream[1] && pools_on()) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_pool_pairs.push_back(PooledPair{h->device, {h->part_stream[0], h->part_stream[1]}});
+        h->part_stream[0] = h->part_stream[1] = nullptr;
+    }
     for (int k = 0; k < 2; ++k) {
-        if (h->part_stream[k]) { (void)hipStreamSynchronize(h->part_stream[k]); (void)hipStreamDestroy(h->part_stream[k]); }
+        if (h->part_stream[k]) (void)hipStreamDestroy(h->part_stream[k]);
         if (h->part_done[k]) (void)hipEventDestroy(h->part_done[k]);
         if (h->part[k]) {
-            if (h->part[k]->team_flag_host) (void)hipHostFree((void*)h->part[k]->team_flag_host);
+            give_error_word(h->device, (void*)h->part[k]->team_flag_host, (void*)h->part[k]->team_flag_dev);
             delete h->part[k];
         }
         h->part_stream[k] = nullptr; h->part_done[k] = nullptr; h->part[k] = nullptr;
     }
     if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
     if (h->chain_ev) (void)hipEventDestroy(h->chain_ev);
-    if (h->chain_xchg) (void)hipFree(h->chain_xchg);
+    give_uncached(h->device, h->chain_xchg, h->chain_xchg_bytes);
     h->chain_xchg = nullptr;
     h->fork_ev = h->chain_ev = nullptr;
     h->chain = false;
@@ -587,12 +681,13 @@ int evac_create_ex(const evac_config_t* cfg, int32_t num_envs, int32_t device, u
             void* host = nullptr;
             void* dev = nullptr;
             ok = ok && hipEventCreateWithFlags(&h->chain_ev, hipEventDisableTiming) == hipSuccess;
-            if (ok && (hipHostMalloc(&host, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dev, host, 0) != hipSuccess)) {
-                if (host) (void)hipHostFree(host);
+            if (ok && h->team_flag_host) {          // (a handle has one error word: the teams' serves the chain too)
+                host = (void*)h->team_flag_host;
+                dev = (void*)h->team_flag_dev;
+            } else if (ok && !take_error_word(device, &host, &dev)) {
                 ok = false;
             }
             if (ok) {
-                std::memset(host, 0, 64);
                 h->team_flag_host = (volatile unsigned*)host;
                 h->team_flag_dev = (unsigned*)dev;
             } else {
@@ -607,7 +702,10 @@ int evac_create_ex(const evac_config_t* cfg, int32_t num_envs, int32_t device, u
             // ever holds removes the question: 1.5 KB per env and launch at memory speed is nothing next to 20 steps.
             void* xchg = nullptr;
             const size_t xbytes = (size_t)num_envs * (size_t)evac::xchg_bytes(h->cu_wide4 ? 256 : 64);
-            if (ok && hipExtMallocWithFlags(&xchg, xbytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); xchg = nullptr; ok = false; }
+            if (ok) {
+                xchg = take_uncached(device, xbytes, &h->chain_xchg_bytes);
+                ok = xchg != nullptr;
+            }
             if (ok && (hipMemset(xchg, 0, xbytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) { (void)hipGetLastError(); ok = false; }   // (hipMemset does not wait)
             h->chain_xchg = (char*)xchg;
         }
@@ -677,7 +775,7 @@ int evac_destroy(evac_handle_t h) {
     if (h && (h->n_parts > 1 || h->part_stream[0] || h->chain)) destroy_parts(h);
     if (h && h->team_flag_host) {
         DeviceGuard g(h->device);
-        (void)hipHostFree((void*)h->team_flag_host);
+        give_error_word(h->device, (void*)h->team_flag_host, (void*)h->team_flag_dev);
     }
     delete h;
     return EVAC_OK;

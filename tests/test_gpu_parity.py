@@ -541,6 +541,53 @@ def test_two_parts_on_the_handles_own_streams_equal_one_kernel(ea, n, E, wrap_kw
     one.close(); two.close()
 
 
+def _where_slabs_differ(outs, refs, replay=None):
+    """The failure message of the chained-launch comparison: which launches, steps, envs and slab columns differ -- and, given a
+    replay of the same launches by a third handle (one launch at a time), which of the two sides left it."""
+    import torch
+    lines = []
+    if replay is not None:
+        R = len(outs)
+        last = replay[-R:]
+        for name, side in (("chained", outs), ("plain", refs)):
+            off = [j for j, (a, b) in enumerate(zip(side, last)) if not torch.equal(a["slab"], b["slab"])]
+            lines.append(f"{name} side differs from a serial replay in launches {off}")
+            for j in off[:2]:          # ... at which granularity, and with what in them?
+                a, b = side[j]["slab"].flatten(), last[j]["slab"].flatten()
+                ne = (a != b).nonzero().flatten()
+                addr = a.data_ptr() + 4 * ne
+                line = torch.unique(addr // 128)
+                in_wrong_lines = torch.isin((a.data_ptr() + 4 * torch.arange(a.numel(), device=a.device)) // 128, line)
+                could = int((in_wrong_lines & (b != 0)).sum())          # floats of the wrong lines that would show if the line were zero
+                zeros = int((a[ne] == 0).sum())
+                import time
+                time.sleep(0.3); torch.cuda.synchronize()
+                healed = bool(torch.equal(side[j]["slab"], last[j]["slab"]))
+                lines.append(f"  {name} launch {j}: {ne.numel()} wrong floats in {line.numel()} lines of 128 B ({zeros} of them read 0.0; a zeroed line would show {could}); "
+                             f"tensor at {a.data_ptr():#x} ({a.numel() * 4} B); first wrong lines at +{[(int(x) * 128 - a.data_ptr()) for x in line[:6].tolist()]}; "
+                             f"a few wrong values {[float(x) for x in a[ne][:6].tolist()]} for {[float(x) for x in b[ne][:6].tolist()]}; equal after 0.3 s: {healed}")
+            for j in off[:4]:          # where do the wrong rows come from?  the same (step, env) row of which launch of the whole run
+                bad = (side[j]["slab"] != last[j]["slab"]).any(dim=2)
+                t, e = torch.nonzero(bad, as_tuple=True)
+                src = {}
+                for tt, ee in list(zip(t.tolist(), e.tolist()))[:40]:
+                    row = side[j]["slab"][tt, ee]
+                    hit = [k for k in range(len(replay)) if torch.equal(replay[k]["slab"][tt, ee], row)]
+                    hit2 = [(k, t2) for k in range(len(replay)) for t2 in range(replay[k]["slab"].shape[0]) if t2 != tt and torch.equal(replay[k]["slab"][t2, ee], row)][:2] if not hit else []
+                    key = str(hit) if hit else ("other step " + str(hit2) if hit2 else ("zeros" if not bool(row.any()) else "nowhere"))
+                    src[key] = src.get(key, 0) + 1
+                lines.append(f"  {name} launch {j} (run launch {len(replay) - R + j}): {int(bad.sum())} wrong rows; the same row of run launch -> {src}")
+    for j, (o, r) in enumerate(zip(outs, refs)):
+        ne = o["slab"] != r["slab"]
+        ne |= torch.isnan(o["slab"]) != torch.isnan(r["slab"])
+        if not bool(ne.any()):
+            continue
+        t, e, c = (x.unique().tolist() for x in torch.nonzero(ne, as_tuple=True))
+        lines.append(f"launch {j}: {int(ne.sum())} values; steps {t[:12]}{'...' if len(t) > 12 else ''}; {len(e)} envs {e[:24]}{'...' if len(e) > 24 else ''}; "
+                     f"{len(c)} columns {c[:8]}..{c[-1]}")
+    return " | ".join(lines) if lines else "(equal apart from NaN payloads)"
+
+
 @pytest.mark.parametrize("n,E,wrap_kw,T", [
     (60, 4096, dict(positions="grav", alpha=3), 20),                          # BASELINE config 2 with the driver's launch length
     (60, 512, dict(positions="grav", alpha=3), 7),                            # CU-wide forced on a small batch, odd launch length
@@ -574,7 +621,13 @@ def test_chained_launches_equal_plain_launches(ea, n, E, wrap_kw, T):
         assert ch.team_error(sync=False) == 0
     # (the reference rollouts above reuse no buffer: compare the LAST repetition launch by launch)
     for j, (o, r) in enumerate(zip(outs, refs)):
-        assert torch.equal(o["slab"], r["slab"]), f"launch {j}"
+        if not torch.equal(o["slab"], r["slab"]):
+            third = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=11)            # which side is wrong?  the same launches, one at a time
+            third.reset()
+            replay = []
+            for _ in range(3 * R):
+                replay.append(third.rollout(T)); torch.cuda.synchronize()
+            raise AssertionError(f"launch {j}: " + _where_slabs_differ(outs, refs, replay))
         done = (r["terminated"] != 0) | (r["truncated"] != 0)
         assert torch.equal(o["episode_stats"][done], r["episode_stats"][done]), f"launch {j}: episode records"
     sa, sb = one.get_state(), ch.get_state()             # (joins by itself)
