@@ -116,7 +116,8 @@ def test_host_env_reissues_an_output_array_only_when_nobody_holds_it():
     page faults): the pool logic alone, on the CPU."""
     import types
     from evacuation_amd.host_env import HostVectorEnv
-    stub = types.SimpleNamespace(_POOL=HostVectorEnv._POOL, _pools=[[None] * HostVectorEnv._POOL for _ in range(4)], _pool_next=[0, 0, 0, 0])
+    stub = types.SimpleNamespace(_POOL=HostVectorEnv._POOL, _pools=[[None] * HostVectorEnv._POOL for _ in range(4)], _pool_next=[0, 0, 0, 0],
+                                 _free_refcount=HostVectorEnv._free_refcount)
     fresh = lambda kind=0: HostVectorEnv._fresh(stub, kind, (8,), np.float32)  # noqa: E731
     assert len({id(fresh()) for _ in range(40)}) <= HostVectorEnv._POOL          # dropped at once: the pool's arrays go round
     kept = []
