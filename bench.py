@@ -208,7 +208,7 @@ def load_traffic(path: str, key: str, kernel_variant: str, sources_sha16: str):
     """The counter-measured figures of `key` ("c2:rollout", ...) from profiles/traffic.json -- or None fields with a note when
     the entry was measured on other kernels than the ones loaded now (another kernel variant, or kernel sources that have
     changed since): stale counters must not ride along with a fresh timing."""
-    out = {"hbm_bytes_per_env_step": None, "valu": None, "salu": None, "lds": None, "source": None, "note": None}
+    out = {"hbm_bytes_per_env_step": None, "valu": None, "salu": None, "lds": None, "source": None, "note": None, "chain_record_bytes_per_env_launch": 0}
     try:
         with open(path) as f:
             ent = json.load(f).get(key)
@@ -226,6 +226,14 @@ def load_traffic(path: str, key: str, kernel_variant: str, sources_sha16: str):
     out.update(hbm_bytes_per_env_step=ent["hbm_bytes_per_env_step"], valu=ent.get("valu_wave_insts_per_env_step"),
                salu=ent.get("salu_wave_insts_per_env_step"), lds=ent.get("lds_wave_insts_per_env_step"),
                source=f'{ent.get("source")} ({ent.get("envs")} envs x {ent.get("steps_per_launch")} steps per launch)')
+    if ent.get("counted_variant") and ent["counted_variant"] != kernel_variant:
+        # the counters serialise dispatches, and chained launches wait for each other: the kernel was counted in its plain launches
+        # (same step loop) and the exchange record a chained launch reads and writes per env is added as its algorithmic size
+        out["chain_record_bytes_per_env_launch"] = int(ent.get("chain_record_bytes_per_env_launch") or 0)
+        out["note"] = (f"counters collected on {ent['counted_variant']!r} (--rollout-form one: under --pmc every dispatch runs alone, chained launches "
+                       f"would wait for each other); the chained form adds its exchange record, {out['chain_record_bytes_per_env_launch']} B per env "
+                       f"and launch read + written in uncached memory, to `traffic`")
+        out["source"] += "; + exchange records"
     return out
 
 
@@ -501,7 +509,7 @@ def side_workload(name: str, mode: str, inner: int, sweeps: int, device, traffic
     bytes_per_env_step = env.algorithmic_bytes_per_env_step
     bytes_per_launch = bytes_per_env_step * E * inner
     achieved = bytes_per_launch / kernel_s / 1e9
-    traffic = tr["hbm_bytes_per_env_step"] * E * inner if tr["hbm_bytes_per_env_step"] is not None else None
+    traffic = (tr["hbm_bytes_per_env_step"] * E * inner + tr["chain_record_bytes_per_env_launch"] * E) if tr["hbm_bytes_per_env_step"] is not None else None
     value = E / (sweep_s / EPISODE)
     env.close()
     return {
@@ -1240,7 +1248,8 @@ def main(argv=None):
 
     if rank == 0:
         tr = load_traffic(args.traffic_json, f"{args.workload}:{args.mode}", loc.kernel_variant(args.mode), csrc_sha16())
-        traffic = tr["hbm_bytes_per_env_step"] * E * inner if tr["hbm_bytes_per_env_step"] is not None else None   # per env-step, scaled to one launch
+        traffic = (tr["hbm_bytes_per_env_step"] * E * inner + tr["chain_record_bytes_per_env_launch"] * E
+                   if tr["hbm_bytes_per_env_step"] is not None else None)                 # per env-step, scaled to one launch
         traffic_src, valu_insts = tr["source"], tr["valu"]
         step_s = sweep_s / steps_per_sweep                         # the episode-average cost of one step of the whole batch
         value = total_envs / step_s

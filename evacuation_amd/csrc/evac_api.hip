@@ -103,6 +103,7 @@ struct evac_handle {
     // launch of its stream: everything a launch reads was written by a launch its queue has completed.
     bool chain;               // (requested and possible; used only with the workspace bound)
     bool chain_bound;
+    bool chain_small;         // the chain's launches are the 256-thread workgroups of one-wave envs (four envs each: no deal, no pace keeping)
     int chain_gen;            // rollout launches of the chain so far = the generation the next launch waits for
     int chain_start;          // the launch at which the chain (re)started: deals begin two launches later
     bool chain_restart;       // the state was written by something else than the chain's last launch: fill the generation words first
@@ -371,7 +372,7 @@ int create_impl(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
     h->part_done[0] = h->part_done[1] = h->fork_ev = nullptr;
     h->parts_pending = false;
     h->forked = false;
-    h->chain = h->chain_bound = false;
+    h->chain = h->chain_bound = h->chain_small = false;
     h->chain_gen = h->chain_start = 1;          // (never 0: a zero-filled workspace must not look like a published generation)
     h->chain_restart = true;
     h->chain_sched = nullptr;
@@ -674,7 +675,11 @@ int evac_create_ex(const evac_config_t* cfg, int32_t num_envs, int32_t device, u
     if (hipDeviceGetAttribute(&can_wait_value, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess) { (void)hipGetLastError(); can_wait_value = 0; }
     const bool chain_one_wave = h->cu_wide && num_envs % 16 == 0 && num_envs >= 32;
     const bool chain_four_waves = h->cu_wide4 && num_envs % 4 == 0 && num_envs >= 8;     // (the CU-wide form of four-wave envs: a barrier per env in LDS)
-    if (chain_opt != 0 && can_wait_value && (chain_one_wave || chain_four_waves)) {
+    // ... and the 256-thread workgroups of one-wave envs (four envs each), on request only (chain = 1 with cu_wide = 0)
+    const bool chain_small = chain_opt == 1 && !h->cu_wide && !h->cu_wide4 && h->sub_lanes == 0 && !h->cells && !h->team_k &&
+                             waves_per_env(h->p.n_ped) == 1 && num_envs % 4 == 0 && num_envs >= 8;
+    h->chain_small = chain_small;
+    if (chain_opt != 0 && can_wait_value && (chain_one_wave || chain_four_waves || chain_small)) {
         bool ok = make_part_streams(h);
         {
             DeviceGuard g(device);
@@ -1088,7 +1093,8 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
             // caller's stream holds -- once per join (below): a barrier packet per launch costs more than the chain gains.
             using FW = evac::Wave<1, 1024>;
             using FW4 = evac::Wave<4, 1024>;
-            const int wpe = h->cu_wide4 ? 4 : 1, per_wg = h->cu_wide4 ? 4 : 16;
+            using FS = evac::Wave<1, 256>;
+            const int wpe = h->cu_wide4 ? 4 : 1, per_wg = (h->cu_wide4 || h->chain_small) ? 4 : 16;
             const int E = h->p.n_envs, c = h->chain_gen;
             hipStream_t S = h->part_stream[c & 1], O = h->part_stream[(c + 1) & 1];
             // THE INVARIANT OF THE CHAIN: launch g + 1 must not start being dispatched before every workgroup of launch g has a CU.
@@ -1115,10 +1121,12 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
                 // the state in memory is whatever the caller's stream left: every env at generation c, one deal in all four
                 // permutation buffers, the other stream behind both
                 hipLaunchKernelGGL(evac::k_chain_import, dim3((unsigned)((E * wpe + 3) / 4)), dim3(256), 0, S, h->p, h->chain_xchg, c, h->chain_abort, h->chain_wgs, wpe);
-                hipLaunchKernelGGL(evac::k_schedule, dim3(1), dim3(1024), 0, S, E, (const int*)(moving + ((c + 3) & 3) * (size_t)E),
-                                   perm + (c & 3) * (size_t)E, (int32_t*)nullptr, per_wg, wpe == 4 ? 4 : 1, option_value("EVAC_CHAIN_DEAL", 0));
-                hipLaunchKernelGGL(evac::k_copy_perm3, dim3(64), dim3(256), 0, S, E, (const int*)(perm + (c & 3) * (size_t)E),
-                                   perm + ((c + 1) & 3) * (size_t)E, perm + ((c + 2) & 3) * (size_t)E, perm + ((c + 3) & 3) * (size_t)E);
+                if (!h->chain_small) {
+                    hipLaunchKernelGGL(evac::k_schedule, dim3(1), dim3(1024), 0, S, E, (const int*)(moving + ((c + 3) & 3) * (size_t)E),
+                                       perm + (c & 3) * (size_t)E, (int32_t*)nullptr, per_wg, wpe == 4 ? 4 : 1, option_value("EVAC_CHAIN_DEAL", 0));
+                    hipLaunchKernelGGL(evac::k_copy_perm3, dim3(64), dim3(256), 0, S, E, (const int*)(perm + (c & 3) * (size_t)E),
+                                       perm + ((c + 1) & 3) * (size_t)E, perm + ((c + 2) & 3) * (size_t)E, perm + ((c + 3) & 3) * (size_t)E);
+                }
                 // ... and the OTHER queue behind all of this.  Its gate alone does not order it: until the import has set the counter the
                 // word holds whatever the workspace's memory held -- the caller's zero fill may not have run yet on this queue's
                 // timeline, a recycled allocation carries the count of the handle that used it before -- and a gate that passes on such a
@@ -1131,7 +1139,7 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
                 h->chain_start = c;
                 h->chain_restart = false;
             }
-            const bool deals = c - h->chain_start >= 2;          // (the loads of launch c - 2, the last launch of this stream)
+            const bool deals = !h->chain_small && c - h->chain_start >= 2;          // (the loads of launch c - 2, the last launch of this stream)
             const int32_t* deal_loads = deals ? moving + ((c + 2) & 3) * (size_t)E : nullptr;
             int32_t* deal_perm = deals ? perm + ((c + 2) & 3) * (size_t)E : nullptr;
             unsigned long long* started = (unsigned long long*)(h->chain_abort + 8);      // (the same line as the abort word: bytes 32..39)
@@ -1145,9 +1153,20 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
             evac::ChainArgs ca{h->chain_xchg, c, h->chain_abort, h->team_flag_dev, deal_mode, started};
             evac::Params pp = h->p;
             if (h->team_fault && c == h->chain_start + 1) pp.n_envs = E - per_wg;    // fault injection: the last workgroup of ONE launch is never run
-#define EVAC_CHAIN_ARGS pp, (int)n_steps, (const float2*)actions, slab_out, final_stats, (const int*)(perm + (c & 3) * (size_t)E), (int*)(moving + (c & 3) * (size_t)E), (const int*)deal_loads, (int*)deal_perm, ca
+#define EVAC_CHAIN_ARGS pp, (int)n_steps, (const float2*)actions, slab_out, final_stats, (const int*)(h->chain_small ? nullptr : perm + (c & 3) * (size_t)E), (int*)(h->chain_small ? nullptr : moving + (c & 3) * (size_t)E), (const int*)deal_loads, (int*)deal_perm, ca
             const dim3 grid((unsigned)(E / per_wg));
-            if (h->cu_wide4) {
+            if (h->chain_small) {
+                // four one-wave envs per 256-thread workgroup, env = slot: the dispatcher places a workgroup of the next launch wherever
+                // four waves have retired, so the chain needs no deal and no pace keeping to keep the CUs full
+                if (h->default_cfg && h->p.obs_pos == EVAC_POS_GRAV)
+                    hipLaunchKernelGGL((evac::k_rollout_chain_default_config<FS, true>), grid, dim3(FS::kBlock), 0, S, EVAC_CHAIN_ARGS);
+                else if (h->default_cfg)
+                    hipLaunchKernelGGL((evac::k_rollout_chain_default_config<FS, false>), grid, dim3(FS::kBlock), 0, S, EVAC_CHAIN_ARGS);
+                else if (h->p.obs_pos == EVAC_POS_GRAV)
+                    hipLaunchKernelGGL((evac::k_rollout_chain<FS, true>), grid, dim3(FS::kBlock), 0, S, EVAC_CHAIN_ARGS);
+                else
+                    hipLaunchKernelGGL((evac::k_rollout_chain<FS, false>), grid, dim3(FS::kBlock), 0, S, EVAC_CHAIN_ARGS);
+            } else if (h->cu_wide4) {
                 if (h->default_cfg && h->p.obs_pos == EVAC_POS_GRAV)
                     hipLaunchKernelGGL((evac::k_rollout_chain_default_config<FW4, true>), grid, dim3(FW4::kBlock), 0, S, EVAC_CHAIN_ARGS);
                 else if (h->default_cfg)

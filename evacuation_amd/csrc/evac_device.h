@@ -623,7 +623,7 @@ __device__ __forceinline__ void rollout_body(
     if constexpr (CHAIN) {
         // (a chained launch deals -- above -- BEFORE it waits: the sort of workgroup 0 runs under the hand-off of its envs.  The
         // permutation it writes is read two launches later, by the next launch of THIS queue: in order, no flag needed.)
-        static_assert(F::kPace && !F::kHelpers, "chained launches: the CU-wide families (one-wave envs, and four-wave envs with a barrier per env)");
+        static_assert(!F::kHelpers && (F::kPace || F::WPE == 1), "chained launches: one-wave envs (any workgroup size), and four-wave envs in CU-wide workgroups (a barrier per env)");
         constexpr int T = F::kThreadsPerEnv;
         if constexpr (F::WPE == 1) {
             if (!chain_wait<T>(chain, w.env)) {      // (wave-uniform) the env's state never came: void run, the host is told

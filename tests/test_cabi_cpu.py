@@ -208,5 +208,6 @@ def test_kernel_resource_budgets():
     assert sum("Team<" in n and "k_rollout<" in n for n in names) == 8       # 4 team sizes x 2 observation faces
     for fam in ("Wave<1, 1024>", "Wave<4, 1024>"):                           # generic + default-configuration faces, 2 observation faces each
         assert sum(fam in n and "k_rollout<" in n for n in names) == 2 and sum(fam in n and "k_rollout_default_config<" in n for n in names) == 2
-    assert sum("k_rollout_chain<" in n for n in names) == 4 and sum("k_rollout_chain_default_config<" in n for n in names) == 4      # one- and four-wave envs
+    # chained launches: one-wave envs in 256-thread and in CU-wide workgroups, four-wave envs in CU-wide workgroups; 2 observation faces each
+    assert sum("k_rollout_chain<" in n for n in names) == 6 and sum("k_rollout_chain_default_config<" in n for n in names) == 6
     assert sum("k_rollout_default_config" in n for n in names) >= 30 and sum("k_step_default_config" in n for n in names) >= 20

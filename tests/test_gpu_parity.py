@@ -588,24 +588,27 @@ def _where_slabs_differ(outs, refs, replay=None):
     return " | ".join(lines) if lines else "(equal apart from NaN payloads)"
 
 
-@pytest.mark.parametrize("n,E,wrap_kw,T", [
-    (60, 4096, dict(positions="grav", alpha=3), 20),                          # BASELINE config 2 with the driver's launch length
-    (60, 512, dict(positions="grav", alpha=3), 7),                            # CU-wide forced on a small batch, odd launch length
-    (33, 64, dict(positions="rel", statuses="ohe", type="Box"), 10),          # generic observation, four workgroups
-    (64, 160, dict(positions="abs", statuses="cat", type="Dict"), 5),         # the env fills its wave; generic kernels (not the default configuration)
-    (256, 1024, dict(positions="grav", alpha=3), 20),                         # BASELINE config 3: four waves per env, four envs per CU-wide workgroup
-    (200, 52, dict(positions="rel", statuses="ohe", type="Box"), 6),          # four-wave envs that do not fill their lanes, 13 workgroups, Box observation
+@pytest.mark.parametrize("n,E,wrap_kw,T,wide", [
+    (60, 4096, dict(positions="grav", alpha=3), 20, 1),                       # BASELINE config 2 with the driver's launch length
+    (60, 512, dict(positions="grav", alpha=3), 7, 1),                         # CU-wide forced on a small batch, odd launch length
+    (33, 64, dict(positions="rel", statuses="ohe", type="Box"), 10, 1),       # generic observation, four workgroups
+    (64, 160, dict(positions="abs", statuses="cat", type="Dict"), 5, 1),      # the env fills its wave; generic kernels (not the default configuration)
+    (256, 1024, dict(positions="grav", alpha=3), 20, 1),                      # BASELINE config 3: four waves per env, four envs per CU-wide workgroup
+    (200, 52, dict(positions="rel", statuses="ohe", type="Box"), 6, 1),       # four-wave envs that do not fill their lanes, 13 workgroups, Box observation
+    (60, 4096, dict(positions="grav", alpha=3), 20, 0),                       # BASELINE config 2 in 256-thread workgroups (four envs each, no deal)
+    (33, 36, dict(positions="rel", statuses="ohe", type="Box"), 9, 0),        # ... a small batch of them, generic observation
 ])
-def test_chained_launches_equal_plain_launches(ea, n, E, wrap_kw, T):
+def test_chained_launches_equal_plain_launches(ea, n, E, wrap_kw, T, wide):
     """evac_options_t.chain = 1: consecutive rollout launches on two queues, ordered per env by generation
     words on the device.  Slabs, episode records and the final state of many back-to-back launches -- autoresets among them --
     equal the plain handle's bit for bit; calls that are not plain rollouts join and restart the chain behind them."""
     import torch
     cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=45, is_new_exiting_reward=True, is_new_followers_reward=True)
     wrap = ea.EnvWrappersConfig(**wrap_kw)
-    one = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=11, options=ea.KernelOptions(cu_wide=1))
-    ch = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=11, options=ea.KernelOptions(cu_wide=1, chain=1))
+    one = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=11, options=ea.KernelOptions(cu_wide=wide))
+    ch = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=11, options=ea.KernelOptions(cu_wide=wide, chain=1))
     assert ch.own_streams == 2 and ch.num_parts == 1 and ch.resolved_options().chain == 1 and "chained" in ch.kernel_variant()
+    assert ("CU-wide" in ch.kernel_variant()) == bool(wide)
     assert one.own_streams == 0
     one.reset(); ch.reset()
     D = one.obs_dim

@@ -31,7 +31,7 @@ ROOT=$(pwd)
 say "kernel trace of the driver's command"
 D=gpurun_out/${TAG}_c2_driver; mkdir -p $D
 echo "bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-step-api" > $D/command.txt
-(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$D/stats -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-step-api > $ROOT/$D/stats.log 2>&1)
+(cd /tmp && TMPDIR=/tmp timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$D/stats -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-step-api > $ROOT/$D/stats.log 2>&1)
 python tools/chain_timeline.py $D/stats > $D/timeline.txt 2>&1
 tail -1 $D/stats.log > $D/bench_line.json
 # 2. every entry of `workloads` on its own: the trace covers the launches that entry times and no others
@@ -39,19 +39,20 @@ for s in c2_one_kernel c3 c5_shard big_step; do
   say "kernel trace of --side-only $s"
   D=gpurun_out/${TAG}_side_$s; mkdir -p $D
   echo "bench.py --side-only $s --steps 20" > $D/command.txt
-  (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$D/stats -- python3 $ROOT/bench.py --side-only $s --steps 20 > $ROOT/$D/stats.log 2>&1)
+  (cd /tmp && TMPDIR=/tmp timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$D/stats -- python3 $ROOT/bench.py --side-only $s --steps 20 > $ROOT/$D/stats.log 2>&1)
   tail -1 $D/stats.log > $D/bench_line.json
   python tools/summarize_pmc.py $D > $D/summary.txt 2>&1
 done
 # 3. counters (separate --pmc passes; short runs: every dispatch is serialised under the counters)
-say "pmc c2 driver";  bash tools/profile_pmc.sh ${TAG}_c2_driver_pmc --gpus 1 --steps 20 --warmup 5 --sweeps 2 --sustain-seconds 0 > /dev/null 2>&1
+# (rollouts are counted in their PLAIN launches -- --rollout-form one: rocprofv3 --pmc runs every dispatch alone and a chained launch would wait
+# for its predecessor for ever; tools/make_traffic_json.py records that and adds the chain's exchange records)
 say "pmc c2 plain";   bash tools/profile_pmc.sh ${TAG}_c2_plain_pmc --gpus 1 --steps 20 --warmup 5 --sweeps 2 --sustain-seconds 0 --rollout-form one > /dev/null 2>&1
-say "pmc c3";         bash tools/profile_pmc.sh ${TAG}_c3 --workload c3 --steps 400 --warmup 100 --sweeps 1 --sustain-seconds 0 > /dev/null 2>&1
-say "pmc c5";         bash tools/profile_pmc.sh ${TAG}_c5 --workload c5 --steps 400 --warmup 100 --sweeps 1 --sustain-seconds 0 > /dev/null 2>&1
+say "pmc c3";         bash tools/profile_pmc.sh ${TAG}_c3 --workload c3 --steps 400 --warmup 100 --sweeps 1 --sustain-seconds 0 --rollout-form one > /dev/null 2>&1
+say "pmc c5";         bash tools/profile_pmc.sh ${TAG}_c5 --workload c5 --steps 400 --warmup 100 --sweeps 1 --sustain-seconds 0 --rollout-form one > /dev/null 2>&1
 say "pmc c2 step";    bash tools/profile_pmc.sh ${TAG}_c2_step --mode step --steps 200 --warmup 50 --sweeps 1 --sustain-seconds 0 > /dev/null 2>&1
 say "pmc big step";   bash tools/profile_pmc.sh ${TAG}_big_step --workload big --mode step --steps 100 --warmup 20 --sweeps 1 --blocks 3 --sustain-seconds 0 > /dev/null 2>&1
 say "traffic.json"
-python tools/make_traffic_json.py gpurun_out/${TAG}_c2_driver_pmc c2:rollout 4096 20 gpurun_out/${TAG}_c3 c3:rollout 1024 100 gpurun_out/${TAG}_c5 c5:rollout 32 100 gpurun_out/${TAG}_c2_step c2:step 4096 1 gpurun_out/${TAG}_big_step big:step 524288 1 > gpurun_out/$TAG/traffic_update.txt 2>&1
+python tools/make_traffic_json.py gpurun_out/${TAG}_c2_plain_pmc c2:rollout 4096 20 gpurun_out/${TAG}_c3 c3:rollout 1024 100 gpurun_out/${TAG}_c5 c5:rollout 32 100 gpurun_out/${TAG}_c2_step c2:step 4096 1 gpurun_out/${TAG}_big_step big:step 524288 1 > gpurun_out/$TAG/traffic_update.txt 2>&1
 cp profiles/traffic.json gpurun_out/$TAG/traffic.json
 # (gpurun merges at most 64 MiB back: the raw per-dispatch counter and trace tables go, the summaries and the stats tables stay)
 find gpurun_out/${TAG}_* -name "*counter_collection.csv" -delete

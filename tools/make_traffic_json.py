@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
-def kernel_variant(key, envs):
+def kernel_variant(key, envs, chain=-1):
     """The variant string bench.py will see for this workload (needs the GPU: the team / CU-wide choice depends on the device)."""
     import evacuation_amd as ea
     workload, mode = key.split(":")
@@ -24,7 +24,7 @@ def kernel_variant(key, envs):
                        intrinsic_reward_coef=0.0, max_timesteps=bench.EPISODE)
     # (the options bench.py's headline takes on one GPU: chained launches where the library offers them -- the C2 rollout; the side
     # workloads and the per-step runs are plain handles)
-    opts = ea.KernelOptions(chain=-1) if mode == "rollout" else None
+    opts = ea.KernelOptions(chain=chain) if mode == "rollout" else None
     env = ea.BatchedEvacuationEnv(cfg, ea.EnvWrappersConfig(**wrap_kw), num_envs=int(envs), options=opts)
     env.reset()
     if mode == "rollout":
@@ -57,5 +57,13 @@ for d, key, envs, inner in zip(args[0::4], args[1::4], args[2::4], args[3::4]):
                  "salu_wave_insts_per_env_step": (sum(vals["SQ_INSTS_SALU"]) / len(vals["SQ_INSTS_SALU"]) / (int(envs) * int(inner))) if vals["SQ_INSTS_SALU"] else None,
                  "lds_wave_insts_per_env_step": (sum(vals["SQ_INSTS_LDS"]) / len(vals["SQ_INSTS_LDS"]) / (int(envs) * int(inner))) if vals["SQ_INSTS_LDS"] else None,
                  "source": os.path.relpath(d, ROOT), "kernel_variant": kernel_variant(key, envs), "csrc_sha16": bench.csrc_sha16()}
+    # rollouts are counted in their PLAIN launches (tools/final_run.sh passes --rollout-form one to the counter passes: rocprofv3 --pmc
+    # runs every dispatch alone, and a chained launch waits for its predecessor); where bench.py's headline chains its launches the
+    # entry says so and carries the exchange record's size (evac_common.h Xchg<T>: 20 T + 256 bytes, read once and written once)
+    plain = kernel_variant(key, envs, chain=0) if key.endswith(":rollout") else data[key]["kernel_variant"]
+    if plain != data[key]["kernel_variant"]:
+        lanes = 256 if "4 waves/env" in plain else 64
+        data[key]["counted_variant"] = plain
+        data[key]["chain_record_bytes_per_env_launch"] = 2 * (20 * lanes + 256)
     print(key, data[key])
 json.dump(data, open(out_path, "w"), indent=1, sort_keys=True)

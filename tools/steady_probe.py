@@ -82,3 +82,43 @@ if "d" in which:
     env, out = make(65536, 3, parts=1)
     timed("d) 65 536 envs, one handle                ", [env.rollout_launcher(T, out)], [env.join], 65536, sweeps=5, warm=min(WARM, 250))
     env.close()
+# the 256-thread workgroups (cu_wide = 0: four one-wave envs per workgroup, no pace keeping, no deal): alone, in throughput mode
+if "j" in which:
+    env, out = make(4096, 0x5EED0001, parts=1, cu_wide=0)
+    timed("j) 256-thread workgroups, one kernel/launch", [env.rollout_launcher(T, out)], [env.join], 4096)
+    print("  ", env.kernel_variant())
+    env.close()
+if "h" in which:
+    s1 = torch.cuda.current_stream(); s2 = side_stream(dev, beside=s1)
+    (ea_, oa), (eb, ob) = make(4096, 1, parts=1, cu_wide=0), make(4096, 2, parts=1, cu_wide=0)
+    la, lb = ea_.rollout_launcher(T, oa, stream=s1), eb.rollout_launcher(T, ob, stream=s2)
+    timed("h) 256-thread WGs: TWO batches, two streams", [la, lb], [lambda: s1.wait_stream(s2)], 8192)
+    ea_.close(); eb.close()
+if "i" in which:
+    env, out = make(65536, 3, parts=1, cu_wide=0)
+    timed("i) 256-thread WGs: 65 536 envs, one handle ", [env.rollout_launcher(T, out)], [env.join], 65536, sweeps=5, warm=min(WARM, 250))
+    env.close()
+if "k" in which:
+    env, out = make(4096, 0x5EED0001, chain=1, cu_wide=0)
+    timed("k) 256-thread workgroups, CHAINED launches ", [env.rollout_launcher(T, out)], [env.join], 4096)
+    print("   team/chain error word:", env.team_error(), env.kernel_variant())
+    env.close()
+# BASELINE config 3 in throughput mode: what keeping every CU busy is worth for the four-wave kernels
+if "l" in which or "m" in which:
+    cfg3 = ea.EnvConfig(number_of_pedestrians=256, is_new_exiting_reward=True, is_new_followers_reward=True, max_timesteps=2000)
+
+    def make3(E, seed, **opt):
+        env = ea.BatchedEvacuationEnv(cfg3, wrap, num_envs=E, seed=seed, options=ea.KernelOptions(**opt))
+        env.reset()
+        return env, {"slab": torch.empty((T, E, env.obs_dim + 3), device=dev), "episode_stats": torch.zeros((T, E, env.stats_words), device=dev)}
+    if "l" in which:
+        s1 = torch.cuda.current_stream(); s2 = side_stream(dev, beside=s1)
+        (ea_, oa), (eb, ob) = make3(1024, 1, chain=0), make3(1024, 2, chain=0)
+        la, lb = ea_.rollout_launcher(T, oa, stream=s1), eb.rollout_launcher(T, ob, stream=s2)
+        timed("l) C3: TWO batches of 1024 on two streams ", [la, lb], [lambda: s1.wait_stream(s2)], 2048, sweeps=8, warm=min(WARM, 60))
+        ea_.close(); eb.close()
+    if "m" in which:
+        env, out = make3(8192, 3, chain=0)
+        timed("m) C3: 8192 envs, one handle              ", [env.rollout_launcher(T, out)], [env.join], 8192, sweeps=4, warm=min(WARM, 40))
+        print("  ", env.kernel_variant())
+        env.close()
