@@ -19,8 +19,9 @@ for x in r:
     q[x["Queue_Id"]] = q.get(x["Queue_Id"], 0) + 1
 print(f"kernel: {name[:150]}")
 print(f"launches: {len(r)}; per hardware queue: {q}")
-# consecutive launches closer than 1 ms belong to one back-to-back run (a sweep); the gaps between sweeps are left out
-ss = [S[i + 1] - S[i] for i in range(len(r) - 1) if S[i + 1] - S[i] < 1000.0]
+# consecutive launches closer than 2.5 median distances belong to one back-to-back run (a sweep); the gaps between sweeps are left out
+all_ss = [S[i + 1] - S[i] for i in range(len(r) - 1)]
+ss = [x for x in all_ss if x < 2.5 * st.median(all_ss)]
 du = [E[i] - S[i] for i in range(len(r))]
 ov = sum(1 for i in range(len(r) - 1) if S[i + 1] < E[i])
 print(f"start-to-start of consecutive launches inside a sweep [us]: mean {st.mean(ss):.2f}, median {st.median(ss):.2f}, p10 {sorted(ss)[len(ss) // 10]:.2f}, p90 {sorted(ss)[-len(ss) // 10]:.2f}  (n = {len(ss)})")

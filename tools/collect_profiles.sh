@@ -21,6 +21,7 @@ for s in c2_one_kernel c3 c5_shard big_step; do
   [ -d $d ] || continue
   cp $d/stats/*/*_kernel_stats.csv profiles/${T}_side_${s}_kernel_stats.csv
   tail -1 $d/bench_line.json > profiles/${T}_side_${s}_traced_line.json
+  [ -f $d/timeline.txt ] && { cat $d/command.txt; echo; cat $d/timeline.txt; } > profiles/${T}_side_${s}_timeline.txt
 done
 # counter passes
 for k in c2_plain_pmc c2_step c3 c5 big_step; do

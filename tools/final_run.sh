@@ -33,15 +33,16 @@ D=gpurun_out/${TAG}_c2_driver; mkdir -p $D
 echo "bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-step-api" > $D/command.txt
 (cd /tmp && TMPDIR=/tmp timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$D/stats -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-step-api > $ROOT/$D/stats.log 2>&1)
 python tools/chain_timeline.py $D/stats > $D/timeline.txt 2>&1
-tail -1 $D/stats.log > $D/bench_line.json
+grep '^{"' $D/stats.log | tail -1 > $D/bench_line.json   # (rocprofv3 prints its own lines after the program's)
 # 2. every entry of `workloads` on its own: the trace covers the launches that entry times and no others
 for s in c2_one_kernel c3 c5_shard big_step; do
   say "kernel trace of --side-only $s"
   D=gpurun_out/${TAG}_side_$s; mkdir -p $D
   echo "bench.py --side-only $s --steps 20" > $D/command.txt
   (cd /tmp && TMPDIR=/tmp timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$D/stats -- python3 $ROOT/bench.py --side-only $s --steps 20 > $ROOT/$D/stats.log 2>&1)
-  tail -1 $D/stats.log > $D/bench_line.json
+  grep '^{"' $D/stats.log | tail -1 > $D/bench_line.json   # (rocprofv3 prints its own lines after the program's)
   python tools/summarize_pmc.py $D > $D/summary.txt 2>&1
+  python tools/chain_timeline.py $D/stats > $D/timeline.txt 2>&1      # (start-to-start = the launch period, also where the entry chains its launches)
 done
 # 3. counters (separate --pmc passes; short runs: every dispatch is serialised under the counters)
 # (rollouts are counted in their PLAIN launches -- --rollout-form one: rocprofv3 --pmc runs every dispatch alone and a chained launch would wait
