@@ -1104,7 +1104,8 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
             // g + 1 together and the second launch of a sweep timed out once in ~2000 sweeps; another kernel holding CUs while the
             // chain runs does the same; short of a deadlock the interleaved start left the pipeline in a 15-40 % slower rhythm for
             // the whole sweep).  So every workgroup of a chained launch counts itself in `started` when it gets its CU, and the QUEUE
-            // of launch g + 1 waits -- hipStreamWaitValue64: a packet, no CU held -- until the counter says that all workgroups of
+            // of launch g + 1 waits -- hipStreamWaitValue64: the runtime's one-wave wait kernel (__amd_rocclr_streamOpsWait in a kernel
+            // trace), one wave slot held, no workgroup of ours -- until the counter says that all workgroups of
             // launches <= g have started (+0.5 us per launch: tools/microbench/waitvalue.hip).  With it every wait inside a kernel is
             // for a workgroup that is resident or done, by induction down to the oldest launch in flight, which waits for nothing.
             const bool fork = h->chain_restart || !h->forked || actions != nullptr;      // (once per join, and with every new input: see the parts' fork above)
