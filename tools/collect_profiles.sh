@@ -11,7 +11,7 @@ done
 # the driver's command under the kernel trace: per-kernel stats, the timeline of its (chained) launches, the line the traced run printed
 d=gpurun_out/${T}_c2_driver
 if [ -d $d ]; then
-  cp $d/stats/*/*_kernel_stats.csv profiles/${T}_c2_driver_kernel_stats.csv
+  cp "$(ls -t $d/stats/*/*_kernel_stats.csv | head -1)" profiles/${T}_c2_driver_kernel_stats.csv      # (the newest: a re-run leaves the older process's tables beside it)
   { cat $d/command.txt; echo; cat $d/timeline.txt; } > profiles/${T}_c2_driver_timeline.txt
   tail -1 $d/bench_line.json > profiles/${T}_c2_driver_traced_line.json
 fi
@@ -19,7 +19,7 @@ fi
 for s in c2_one_kernel c3 c5_shard big_step; do
   d=gpurun_out/${T}_side_$s
   [ -d $d ] || continue
-  cp $d/stats/*/*_kernel_stats.csv profiles/${T}_side_${s}_kernel_stats.csv
+  cp "$(ls -t $d/stats/*/*_kernel_stats.csv | head -1)" profiles/${T}_side_${s}_kernel_stats.csv
   tail -1 $d/bench_line.json > profiles/${T}_side_${s}_traced_line.json
   [ -f $d/timeline.txt ] && { cat $d/command.txt; echo; cat $d/timeline.txt; } > profiles/${T}_side_${s}_timeline.txt
 done
@@ -27,7 +27,7 @@ done
 for k in c2_plain_pmc c2_step c3 c5 big_step; do
   d=gpurun_out/${T}_$k
   [ -d $d ] || continue
-  cp $d/stats/*/*_kernel_stats.csv profiles/${T}_${k}_kernel_stats.csv
+  cp "$(ls -t $d/stats/*/*_kernel_stats.csv | head -1)" profiles/${T}_${k}_kernel_stats.csv
   { cat $d/command.txt; echo; cat $d/summary.txt; } > profiles/${T}_${k}_pmc_summary.txt
 done
 for f in steady_probe subwave policy_example progress traffic_update; do [ -f $G/$f.txt ] && grep -v amdgpu.ids $G/$f.txt > profiles/${T}_$f.txt; done
