@@ -102,7 +102,7 @@ def parse_args(argv=None):
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="after the headline sweeps keep running the same sweeps for this much GPU time (0: skip): `sustained` in the line, "
                          "and `value` becomes the settled median when it differs from the headline sweeps' by more than 2 %%")
-    ap.add_argument("--rollout-form", default="auto", choices=["auto", "one", "parts", "chain"],
+    ap.add_argument("--rollout-form", default="auto", choices=["auto", "one", "parts", "chain", "persist"],
                     help="how the handle issues a rollout (evac_options_t): one = ONE kernel per call on the launching stream, every launch "
                          "behind the one before; chain = consecutive launches alternately on two streams the handle owns, ordered per env on "
                          "the device (evac_options_t.chain; evac_join closes a sweep); parts = two half-batch kernels per call on those two "
@@ -230,10 +230,14 @@ def load_traffic(path: str, key: str, kernel_variant: str, sources_sha16: str):
         # the counters serialise dispatches, and chained launches wait for each other: the kernel was counted in its plain launches
         # (same step loop) and the exchange record a chained launch reads and writes per env is added as its algorithmic size
         out["chain_record_bytes_per_env_launch"] = int(ent.get("chain_record_bytes_per_env_launch") or 0)
-        out["note"] = (f"counters collected on {ent['counted_variant']!r} (--rollout-form one: under --pmc every dispatch runs alone, chained launches "
-                       f"would wait for each other); the chained form adds its exchange record, {out['chain_record_bytes_per_env_launch']} B per env "
-                       f"and launch read + written in uncached memory, to `traffic`")
-        out["source"] += "; + exchange records"
+        if out["chain_record_bytes_per_env_launch"]:
+            out["note"] = (f"counters collected on {ent['counted_variant']!r} (--rollout-form one: under --pmc every dispatch runs alone, chained launches "
+                           f"would wait for each other); the chained form adds its exchange record, {out['chain_record_bytes_per_env_launch']} B per env "
+                           f"and launch read + written in uncached memory, to `traffic`")
+            out["source"] += "; + exchange records"
+        else:
+            out["note"] = (f"counters collected on {ent['counted_variant']!r} (--rollout-form one: the same step loop, one launch per call); the persistent "
+                           f"kernel keeps the state in registers from call to call, so its HBM traffic per call is at most this")
     return out
 
 
@@ -482,6 +486,7 @@ def side_workload(name: str, mode: str, inner: int, sweeps: int, device, traffic
     ea0.record(stream)                                        # (every launch of this entry, warm-up included: what a kernel trace of the process averages)
     for _ in range(warm):
         go()
+    env.join(stream)                                          # (a persistent kernel ends at a join only: never wait for the device with one resident)
     torch.cuda.synchronize()
     wall, dev = [], []
     for _ in range(sweeps):
@@ -519,7 +524,7 @@ def side_workload(name: str, mode: str, inner: int, sweeps: int, device, traffic
                    "value_from": f"median of sweeps {len(wall) // 2}..{len(wall) - 1} (the last half)", "gpu_ms_timed_total": sum(dev) * 1e3,
                    "value_first_half": E * EPISODE / statistics.median(wall[:max(1, len(wall) // 2)]),
                    "value_min_median_max": [E * EPISODE / max(wall), value, E * EPISODE / min(wall)]},
-        "kernel": variant, "kernels_in_flight": max(1, env.own_streams), "kernel_ms_per_launch": kernel_s * 1e3,
+        "kernel": variant, "kernels_in_flight": 1 if "persistent" in variant else max(1, env.own_streams), "kernel_ms_per_launch": kernel_s * 1e3,
         "profile_check": {"launches": all_launches, "sum_of_sweeps_ms_per_launch": sum(dev) * 1e3 / (sweeps * launches),
                           "first_launch_to_last_ms_per_launch": ea0.elapsed_time(ea1) / all_launches,
                           "note": "for a reader with the kernel trace of `bench.py --side-only <this entry>`: the trace's average duration of this kernel "
@@ -539,7 +544,7 @@ def side_workload(name: str, mode: str, inner: int, sweeps: int, device, traffic
 def side_options(ea, mode):
     """The options of a side workload's handle: as the headline's on one GPU -- chained rollout launches wherever the library offers them
     (the CU-wide kernels of one- and four-wave envs: C3; the teams of C5 and the per-step runs are plain handles)."""
-    return ea.KernelOptions(chain=-1) if mode == "rollout" else None
+    return ea.KernelOptions(chain=2) if mode == "rollout" else None
 
 
 def side_workloads(args, device):
@@ -648,11 +653,12 @@ def main(argv=None):
     # streams by events recorded behind ONE launch per chunk, so those runs keep one kernel per launch.
     form_req = args.rollout_form
     if form_req == "auto":
-        form_req = "chain_auto" if (world == 1 and not use_dist and args.mode == "rollout") else "one"
+        form_req = "persist" if (world == 1 and not use_dist and args.mode == "rollout") else "one"
     if form_req != "one" and use_dist and not args.no_gather:
         raise SystemExit("bench.py: --rollout-form parts / chain with gathers is not supported (the gather pipeline waits on one launch per chunk)")
     kopts = {"one": ea.KernelOptions(parts=1, chain=0), "parts": ea.KernelOptions(parts=2, chain=0),
-             "chain": ea.KernelOptions(chain=1), "chain_auto": ea.KernelOptions(chain=-1)}[form_req]
+             "chain": ea.KernelOptions(chain=1), "chain_auto": ea.KernelOptions(chain=-1),
+             "persist": ea.KernelOptions(chain=2)}[form_req]          # (the library falls back to chained, then plain launches where it cannot: config.rollout_form says what ran)
     env = ShardedEvacuationEnv(cfg, wrap, total_envs=total_envs, device=device, seed=seed, options=kopts)
     loc = env.local
     E, D = loc.num_envs, loc.obs_dim
@@ -799,6 +805,8 @@ def main(argv=None):
     def drain_compute():
         """Everything issued to the device so far is done.  (hipDeviceSynchronize spins here; a hipStreamQuery loop costs the
         same wait plus ~2.5 us on the NEXT launch call -- the query leaves a marker behind: tools/block_overhead.py.)"""
+        if loc.own_streams:
+            loc.join()                                        # (no-op when the sweep has joined already; see barrier())
         torch.cuda.synchronize()
 
     def drain_gather():
@@ -811,6 +819,8 @@ def main(argv=None):
         """Opens a timed region (and, being the next one's opening, closes the previous one outside its timed region)."""
         if use_dist:
             dist.barrier()
+        if loc.own_streams:                                   # (a persistent kernel ends at a join only: a device-wide wait with it resident would wait for its time-out)
+            loc.join()
         torch.cuda.synchronize()
 
     # Every (chunk size, parity) buffer set is created HERE, on all ranks in the same order: the peer-mapped gathers rendezvous
@@ -1246,6 +1256,8 @@ def main(argv=None):
         progress("side workloads")
         side = side_workloads(args, device)
 
+    persistent = "persistent" in loc.kernel_variant(args.mode)
+    in_flight = 1 if persistent else max(1, loc.own_streams)
     if rank == 0:
         tr = load_traffic(args.traffic_json, f"{args.workload}:{args.mode}", loc.kernel_variant(args.mode), csrc_sha16())
         traffic = (tr["hbm_bytes_per_env_step"] * E * inner + tr["chain_record_bytes_per_env_launch"] * E
@@ -1304,13 +1316,17 @@ def main(argv=None):
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": tr["note"],
                          "salu_wave_insts_per_env_step": tr["salu"], "lds_wave_insts_per_env_step": tr["lds"],
                          "kernel": loc.kernel_variant(args.mode),
-                         "kernels_in_flight": max(1, loc.own_streams), "round_ms": kernel_s * 1e3,
+                         "kernels_in_flight": in_flight, "round_ms": kernel_s * 1e3,
                          "profile_check": {
                              "sweeps_all": len(sweep_dev) + len(sustain_dev),
                              "mean_period_ms_all_sweeps": (sum(sweep_dev) + sum(sustain_dev)) * 1e3 / max(1, (len(sweep_dev) + len(sustain_dev)) * launches_per_sweep),
-                             "expected_kernel_trace_avg_duration_ms": max(1, loc.own_streams) * (sum(sweep_dev) + sum(sustain_dev)) * 1e3
+                             "expected_kernel_trace_avg_duration_ms": (launches_per_sweep if persistent else max(1, loc.own_streams)) * (sum(sweep_dev) + sum(sustain_dev)) * 1e3
                                                                       / max(1, (len(sweep_dev) + len(sustain_dev)) * launches_per_sweep),
-                             "note": "for a reader with the kernel trace of this command: a CHAINED launch is enqueued behind its queue's previous launch and "
+                             "note": ("for a reader with the kernel trace of this command: ONE PERSISTENT rollout kernel per sweep carries all its "
+                                      f"{launches_per_sweep} calls, so the trace's average DURATION of the rollout kernel is the sweep (expected_kernel_trace_avg_duration_ms) and "
+                                      "the call period is that over the calls of a sweep; mean_period_ms_all_sweeps is over every timed sweep (headline + "
+                                      "sustained), round_ms the settled median `value` uses") if persistent else
+                                     "for a reader with the kernel trace of this command: a CHAINED launch is enqueued behind its queue's previous launch and "
                                      "ends two launch periods later (its queue carries every second launch), so the trace's average DURATION of the "
                                      "rollout kernel is kernels_in_flight x the launch period, and the period itself is the trace's start-to-start "
                                      "distance of consecutive launches (tools/chain_trace.sh prints both); mean_period_ms_all_sweeps is over "
@@ -1346,7 +1362,14 @@ def main(argv=None):
         ro = loc.resolved_options()
         out["config"]["rollout_form"] = {
             "requested": args.rollout_form, "parts": loc.num_parts, "chain": ro.chain, "own_streams": loc.own_streams,
-            "note": ("evac_options_t.chain = 1: rollout call g goes to stream g & 1 of two streams the handle owns; a launch waits PER ENV, on the "
+            "note": ("evac_options_t.chain = 2: ONE PERSISTENT KERNEL per join -- the first rollout call after a join starts the rollout kernel on a stream the handle "
+                     "owns, and every call (that one included) is a 64-byte COMMAND (steps, slab, episode records) the host writes into a ring in device "
+                     "memory; the resident kernel runs the call's steps, writes its slab and takes the next command with the state still in registers: no "
+                     "launch boundary, no prologue, no hand-off between calls; evac_join -- here: the end of every sweep -- posts STOP, the waves store their "
+                     "state and the kernel ends.  Every call still runs exactly its K steps into its own slab.  roofline.achieved = the batch's algorithmic "
+                     "bytes per call / the call PERIOD (round_ms = kernel_ms_per_launch = sweep / calls, kernel start and STOP included); a kernel trace shows "
+                     "one kernel per sweep whose duration is the sweep") if ro.chain == 2 else
+                    ("evac_options_t.chain = 1: rollout call g goes to stream g & 1 of two streams the handle owns; a launch waits PER ENV, on the "
                      "device, for the launch before it (a generation word in an exchange record per env) and its queue waits until every workgroup "
                      "of that launch has started; at most two launches overlap; a sweep is closed by evac_join on the timing stream.  "
                      "roofline.achieved = the batch's algorithmic bytes per launch / the launch PERIOD (round_ms = kernel_ms_per_launch = sweep / "

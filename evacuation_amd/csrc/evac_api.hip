@@ -103,6 +103,10 @@ struct evac_handle {
     // launch of its stream: everything a launch reads was written by a launch its queue has completed.
     bool chain;               // (requested and possible; used only with the workspace bound)
     bool chain_bound;
+    bool persist;             // evac_options_t.chain = 2: one persistent rollout kernel per join, every evac_rollout call a command of its ring
+    bool persist_running;     // the kernel is resident (on part_stream[0]) and reads commands
+    int persist_seq;          // the next command's index (its sequence number is index + 1; never reset)
+    int persist_first;        // the first command of the kernel that is running
     bool chain_small;         // the chain's launches are the 256-thread workgroups of one-wave envs (four envs each: no deal, no pace keeping)
     int chain_gen;            // rollout launches of the chain so far = the generation the next launch waits for
     int chain_start;          // the launch at which the chain (re)started: deals begin two launches later
@@ -126,6 +130,13 @@ int fail(evac_handle_t h, int code, const std::string& msg) {
 // A team rollout of this handle lost a member (evac_team.h): the outputs of that launch are void.  Sticky until
 // evac_team_clear_error; the handle runs the one-workgroup-per-env kernels from then on.
 int team_aborted(evac_handle_t h, const char* what) {
+    if (h->team_flag_host && *h->team_flag_host != 0u && h->persist) {
+        h->persist = false;
+        return fail(h, EVAC_ERR_TEAM_ABORTED,
+                    std::string(what) + ": the persistent rollout kernel waited in vain for its next command (more than ~2 s between two "
+                    "evac_rollout calls without an evac_join -- or the host waited for the device instead of joining) and gave up; the outputs since are void -- call evac_team_clear_error(), then reset or "
+                    "restore the batch; the handle issues plain launches from now on");
+    }
     if (h->team_flag_host && *h->team_flag_host != 0u && h->chain) {
         h->chain = false;
         return fail(h, EVAC_ERR_TEAM_ABORTED,
@@ -373,6 +384,8 @@ int create_impl(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
     h->parts_pending = false;
     h->forked = false;
     h->chain = h->chain_bound = h->chain_small = false;
+    h->persist = h->persist_running = false;
+    h->persist_seq = h->persist_first = 0;
     h->chain_gen = h->chain_start = 1;          // (never 0: a zero-filled workspace must not look like a published generation)
     h->chain_restart = true;
     h->chain_sched = nullptr;
@@ -600,8 +613,24 @@ bool make_part_streams(evac_handle* h) {
     if (!ok) (void)hipGetLastError();
     return ok;
 }
+// a command for the resident kernel: the payload, a store fence, then the sequence number in the same 64-byte segment (through the BAR)
+void post_command(evac_handle* h, int n_steps, const void* slab, const void* stats, const void* actions) {
+    volatile evac::PersistCmd* c = (volatile evac::PersistCmd*)(h->chain_xchg + (size_t)(h->persist_seq & (evac::kPersistRing - 1)) * 64);
+    c->slab = (unsigned long long)(uintptr_t)slab;
+    c->stats = (unsigned long long)(uintptr_t)stats;
+    c->actions = (unsigned long long)(uintptr_t)actions;
+    c->n_steps = n_steps;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    c->seq = (unsigned)h->persist_seq + 1u;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    h->persist_seq += 1;
+}
 void destroy_parts(evac_handle* h) {
     DeviceGuard g(h->device);
+    if (h->persist && h->persist_running) {            // (a handle destroyed without a join: the resident kernel is told to end)
+        post_command(h, 0, nullptr, nullptr, nullptr);
+        h->persist_running = false;
+    }
     for (int k = 0; k < 2; ++k)
         if (h->part_stream[k]) (void)hipStreamSynchronize(h->part_stream[k]);
     if (h->part_stream[0] && h->part_stream[1] && pools_on()) {
@@ -624,6 +653,7 @@ void destroy_parts(evac_handle* h) {
     h->chain_xchg = nullptr;
     h->fork_ev = h->chain_ev = nullptr;
     h->chain = false;
+    h->persist = false;
     h->n_parts = 1;
     h->parts_pending = false;
 }
@@ -631,6 +661,10 @@ void destroy_parts(evac_handle* h) {
 int join_parts(evac_handle* h, hipStream_t stream) {
     if (!h->part_stream[0] || !h->parts_pending) return EVAC_OK;
     DeviceGuard g(h->device);
+    if (h->persist && h->persist_running) {            // STOP: the waves store their state and the kernel ends
+        post_command(h, 0, nullptr, nullptr, nullptr);
+        h->persist_running = false;
+    }
     for (int k = 0; k < 2; ++k)
         if (hipEventRecord(h->part_done[k], h->part_stream[k]) != hipSuccess || hipStreamWaitEvent(stream, h->part_done[k], 0) != hipSuccess) {
             (void)hipGetLastError();
@@ -664,7 +698,7 @@ int evac_create_ex(const evac_config_t* cfg, int32_t num_envs, int32_t device, u
         if (f[k] < -1 || f[k] > 16) { g_create_error = "evac_options_t: every field must be -1 (automatic) or a small non-negative value"; if (out) *out = nullptr; return EVAC_ERR_INVALID_ARGUMENT; }
     if (!options) o.chain = 0;
     if (o.parts == 0 || o.parts > 2) { g_create_error = "evac_options_t.parts must be -1, 1 or 2"; if (out) *out = nullptr; return EVAC_ERR_INVALID_ARGUMENT; }
-    if (o.chain > 1) { g_create_error = "evac_options_t.chain must be -1, 0 or 1"; if (out) *out = nullptr; return EVAC_ERR_INVALID_ARGUMENT; }
+    if (o.chain > 2) { g_create_error = "evac_options_t.chain must be -1, 0, 1 or 2"; if (out) *out = nullptr; return EVAC_ERR_INVALID_ARGUMENT; }
     const int rc = create_impl(cfg, num_envs, device, seed, env_id_offset, o, out);
     if (rc != EVAC_OK) return rc;
     evac_handle* h = *out;
@@ -679,6 +713,41 @@ int evac_create_ex(const evac_config_t* cfg, int32_t num_envs, int32_t device, u
     const bool chain_small = chain_opt == 1 && !h->cu_wide && !h->cu_wide4 && h->sub_lanes == 0 && !h->cells && !h->team_k &&
                              waves_per_env(h->p.n_ped) == 1 && num_envs % 4 == 0 && num_envs >= 8;
     h->chain_small = chain_small;
+    // chain = 2: ONE PERSISTENT KERNEL PER JOIN (evac_common.h, PersistCmd).  The CU-wide kernels only (every workgroup resident at once: the grid
+    // must fit the device), and only where the host can write device memory directly (large BAR): the command ring lives in uncached device
+    // memory, written by the CPU -- no stream operation of ours could run while the resident kernel holds every CU.
+    if (chain_opt == 2) {
+        int large_bar = 0;
+        if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess) { (void)hipGetLastError(); large_bar = 0; }
+        const int per_wg = h->cu_wide4 ? 4 : 16;
+        const bool fits = (h->cu_wide || h->cu_wide4) && num_envs % per_wg == 0 && num_envs / per_wg <= h->cus;
+        bool ok = large_bar != 0 && fits && make_part_streams(h);
+        if (ok) {
+            DeviceGuard g(device);
+            void* host = (void*)h->team_flag_host;
+            void* dev = (void*)h->team_flag_dev;
+            if (!host && !take_error_word(device, &host, &dev)) ok = false;
+            if (ok) { h->team_flag_host = (volatile unsigned*)host; h->team_flag_dev = (unsigned*)dev; }
+            void* ring = nullptr;
+            const size_t rbytes = (size_t)evac::kPersistRing * 64 + 128;          // the ring, then a line with the abort word
+            if (ok) { ring = take_uncached(device, rbytes, &h->chain_xchg_bytes); ok = ring != nullptr; }
+            if (ok && (hipMemset(ring, 0, rbytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) { (void)hipGetLastError(); ok = false; }
+            h->chain_xchg = (char*)ring;
+            if (ok) {
+                h->chain_abort = (unsigned*)((char*)ring + (size_t)evac::kPersistRing * 64);
+                void* err_dev = (void*)h->team_flag_dev;                                     // words 4, 5 of the line: where the kernel raises the error word
+                ok = hipMemcpy((char*)h->chain_abort + 16, &err_dev, sizeof(err_dev), hipMemcpyHostToDevice) == hipSuccess;
+                if (!ok) (void)hipGetLastError();
+            }
+        }
+        if (ok) {
+            h->persist = true;
+            h->opt.chain = 2;
+            h->variant[3] = h->variant[1] + ", one persistent kernel per join";
+            return EVAC_OK;
+        }
+        if (h->part_stream[0]) destroy_parts(h);       // (not possible here: chained launches if they are, else plain ones)
+    }
     if (chain_opt != 0 && can_wait_value && (chain_one_wave || chain_four_waves || chain_small)) {
         bool ok = make_part_streams(h);
         {
@@ -765,13 +834,13 @@ int evac_order_next_rollout(evac_handle_t h) {
     return EVAC_OK;
 }
 int32_t evac_num_parts(evac_handle_t h) { return h ? h->n_parts : -1; }
-int32_t evac_own_streams(evac_handle_t h) { return h ? ((h->n_parts > 1 || h->chain) && h->part_stream[0] ? 2 : 0) : -1; }
+int32_t evac_own_streams(evac_handle_t h) { return h ? ((h->n_parts > 1 || h->chain || h->persist) && h->part_stream[0] ? 2 : 0) : -1; }
 void* evac_part_stream(evac_handle_t h, int32_t part) { return (h && evac_own_streams(h) == 2 && part >= 0 && part < 2) ? (void*)h->part_stream[part] : nullptr; }
 
 const char* evac_kernel_variant(evac_handle_t h, int32_t rollout) {
     if (!h) return "";
     if (!rollout) return h->variant[0].c_str();
-    if (h->n_parts > 1 || (h->chain && h->chain_bound)) return h->variant[3].c_str();
+    if (h->n_parts > 1 || (h->chain && h->chain_bound) || h->persist) return h->variant[3].c_str();
     // the path evac_rollout takes right now: teams only with their exchange areas bound and a grid that fits the device
     return h->variant[(h->team_k && h->team_bound && h->team_fit != 0) ? 2 : 1].c_str();
 }
@@ -853,7 +922,7 @@ int evac_bind_workspace(evac_handle_t h, void* workspace, int64_t bytes) {
     h->sched = nullptr;
     h->sched_gen = -1;
     h->team_bound = false;
-    if (h->chain && (h->parts_pending || h->chain_dirty)) {      // (the chain's launches in flight still use the old workspace, and the state lives in it)
+    if ((h->chain && (h->parts_pending || h->chain_dirty)) || (h->persist && h->parts_pending)) {      // (launches in flight still use the old workspace; the chain's state lives in it)
         DeviceGuard g(h->device);
         (void)join_parts(h, nullptr);
         (void)hipDeviceSynchronize();
@@ -926,6 +995,8 @@ int evac_reschedule(evac_handle_t h, void* stream) {
         return EVAC_OK;
     }
     if (!h->sched || !(h->cu_wide || h->cu_wide4)) return EVAC_OK;       // nothing to deal
+    if (h->persist && h->parts_pending)                                   // (the resident kernel keeps the deal it started with: it ends first)
+        if (const int rc = join_parts(h, (hipStream_t)stream); rc != EVAC_OK) return rc;
     DeviceGuard g(h->device);
     deal_now(h, (hipStream_t)stream, true);
     return check_launch(h, "evac_reschedule");
@@ -986,7 +1057,7 @@ int evac_team_error_nosync(evac_handle_t h, int32_t* out) {
 int evac_team_clear_error(evac_handle_t h) {
     if (!h) return EVAC_ERR_INVALID_ARGUMENT;
     if (h->team_flag_host) {
-        if (*h->team_flag_host != 0u) { h->team_k = 0; h->chain = false; }     // the handle stays on one workgroup per env / on plain launches
+        if (*h->team_flag_host != 0u) { h->team_k = 0; h->chain = false; h->persist = false; }     // the handle stays on one workgroup per env / on plain launches
         *h->team_flag_host = 0u;
     }
     return EVAC_OK;
@@ -1083,6 +1154,77 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
             if (rc != EVAC_OK) return fail(h, rc, std::string("evac_rollout (part): ") + c->err);
         }
         return EVAC_OK;
+    }
+    if (h->persist && !(capture || actions_out || noise || actions)) {
+        hipStream_t s_ = (hipStream_t)stream;
+        hipStreamCaptureStatus pcap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s_, &pcap) != hipSuccess) { (void)hipGetLastError(); pcap = hipStreamCaptureStatusNone; }
+        if (pcap == hipStreamCaptureStatusNone) {
+            // ONE PERSISTENT KERNEL PER JOIN: the call becomes a command of the resident kernel's ring.  The kernel is started -- behind
+            // what the caller's stream holds at this moment, as the parts' fork -- by the first call after a join (or after
+            // evac_order_next_rollout); the calls that follow cost the host a 64-byte write through the BAR and the device nothing but the
+            // steps: the state stays in registers.  (Given actions take the plain path below: their buffer is the caller's stream's business.)
+            using FW = evac::Wave<1, 1024>;
+            using FW4 = evac::Wave<4, 1024>;
+            hipStream_t S = h->part_stream[0];
+            if (h->persist_running && !h->forked) {          // the caller touched a buffer (evac_order_next_rollout): a new kernel behind a new fork
+                post_command(h, 0, nullptr, nullptr, nullptr);
+                h->persist_running = false;
+            }
+            if (h->persist_running && h->persist_seq - h->persist_first >= evac::kPersistRing - 2) {
+                // the ring is about to lap the kernel: it is stopped and WAITED FOR on the host (once per ~1000 calls without a join)
+                post_command(h, 0, nullptr, nullptr, nullptr);
+                h->persist_running = false;
+                if (hipStreamSynchronize(S) != hipSuccess) { (void)hipGetLastError(); return fail(h, EVAC_ERR_HIP, "evac_rollout: the persistent kernel did not end"); }
+            }
+            if (!h->persist_running) {
+                if (hipEventRecord(h->fork_ev, s_) != hipSuccess || hipStreamWaitEvent(S, h->fork_ev, 0) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return fail(h, EVAC_ERR_HIP, "evac_rollout: fork of the persistent kernel failed");
+                }
+                h->forked = true;
+                const int E = h->p.n_envs;
+                if (h->sched && h->sched_gen < 0) deal_now(h, S, true);
+                const int g_ = h->sched_gen;
+                const bool dealt = h->sched && g_ >= 0;
+                const int32_t* perm = dealt ? h->sched + (2 + (g_ & 1)) * E : nullptr;
+                int32_t* moving = h->sched ? h->sched + (dealt ? (g_ & 1) : 0) * E : nullptr;
+                const int32_t* deal_loads = dealt ? h->sched + ((g_ + 1) & 1) * E : nullptr;       // (workgroup 0 deals the NEXT kernel's envs as it starts)
+                int32_t* deal_perm = dealt ? h->sched + (2 + ((g_ + 1) & 1)) * E : nullptr;
+                if (dealt) h->sched_gen = g_ + 1;
+                if (hipMemsetAsync(h->chain_abort, 0, 16, S) != hipSuccess) { (void)hipGetLastError(); return fail(h, EVAC_ERR_HIP, "evac_rollout: hipMemsetAsync failed"); }
+                evac::ChainArgs ca{h->chain_xchg, h->persist_seq, nullptr, nullptr, 0, nullptr};      // (the abort line and the error word: found from the ring, evac_common.h)
+#define EVAC_PERSIST_ARGS h->p, (const int*)perm, (int*)moving, (const int*)deal_loads, (int*)deal_perm, ca
+                if (h->cu_wide4) {
+                    const dim3 grid((unsigned)(E / FW4::kEnvsPerBlock));
+                    if (h->default_cfg && h->p.obs_pos == EVAC_POS_GRAV)
+                        hipLaunchKernelGGL((evac::k_rollout_persist_default_config<FW4, true>), grid, dim3(FW4::kBlock), 0, S, EVAC_PERSIST_ARGS);
+                    else if (h->default_cfg)
+                        hipLaunchKernelGGL((evac::k_rollout_persist_default_config<FW4, false>), grid, dim3(FW4::kBlock), 0, S, EVAC_PERSIST_ARGS);
+                    else if (h->p.obs_pos == EVAC_POS_GRAV)
+                        hipLaunchKernelGGL((evac::k_rollout_persist<FW4, true>), grid, dim3(FW4::kBlock), 0, S, EVAC_PERSIST_ARGS);
+                    else
+                        hipLaunchKernelGGL((evac::k_rollout_persist<FW4, false>), grid, dim3(FW4::kBlock), 0, S, EVAC_PERSIST_ARGS);
+                } else {
+                    const dim3 grid((unsigned)(E / FW::kEnvsPerBlock));
+                    if (h->default_cfg && h->p.obs_pos == EVAC_POS_GRAV)
+                        hipLaunchKernelGGL((evac::k_rollout_persist_default_config<FW, true>), grid, dim3(FW::kBlock), 0, S, EVAC_PERSIST_ARGS);
+                    else if (h->default_cfg)
+                        hipLaunchKernelGGL((evac::k_rollout_persist_default_config<FW, false>), grid, dim3(FW::kBlock), 0, S, EVAC_PERSIST_ARGS);
+                    else if (h->p.obs_pos == EVAC_POS_GRAV)
+                        hipLaunchKernelGGL((evac::k_rollout_persist<FW, true>), grid, dim3(FW::kBlock), 0, S, EVAC_PERSIST_ARGS);
+                    else
+                        hipLaunchKernelGGL((evac::k_rollout_persist<FW, false>), grid, dim3(FW::kBlock), 0, S, EVAC_PERSIST_ARGS);
+                }
+#undef EVAC_PERSIST_ARGS
+                if (const int lc = check_launch(h, "evac_rollout (persistent kernel)"); lc != EVAC_OK) return lc;
+                h->persist_running = true;
+                h->persist_first = h->persist_seq;
+            }
+            post_command(h, (int)n_steps, slab_out, final_stats, nullptr);
+            h->parts_pending = true;
+            return EVAC_OK;
+        }
     }
     if (h->chain && h->chain_bound && !(capture || actions_out || noise)) {
         hipStream_t s_ = (hipStream_t)stream;

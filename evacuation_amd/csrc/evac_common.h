@@ -823,6 +823,60 @@ __device__ __forceinline__ void store_record(char* rec, int idx, int lane, bool 
     }
 }
 
+// ---- ONE PERSISTENT KERNEL PER JOIN (evac_options_t.chain = 2): the rollout kernel stays resident between evac_rollout calls and takes
+// every call as a COMMAND from a ring in uncached device memory that the host writes through the PCIe BAR (no stream operation, no
+// kernel: nothing that would need a CU the resident kernel holds).  A command is one 64-byte segment: the payload, then -- behind a
+// store fence -- its sequence number in the same segment; a wave reads the segment with ONE load instruction (four lanes x 16 bytes;
+// a 64-byte segment is never seen torn: tools/microbench/seg_atomicity.hip) and takes the command when the sequence number is the one it
+// waits for.  n_steps = 0 is STOP: the waves store their state and the kernel ends (evac_join).
+struct PersistCmd {
+    unsigned long long slab, stats, actions;     // the call's output / input pointers (stats, actions: 0 = none)
+    int n_steps;                                 // 0: stop
+    int pad_[8];
+    unsigned seq;                                // written LAST (the segment's 16th word)
+};
+static_assert(sizeof(PersistCmd) == 64, "one 64-byte segment");
+constexpr int kPersistRing = 1024;               // commands per ring (the host joins before it would lap the kernel)
+constexpr int kPersistMaxPolls = 1 << 21;        // bounded wait for the next command: ~2 s (a host thread may be descheduled for a while; a caller who
+                                                 // waits for the DEVICE with the kernel resident -- instead of joining -- gets the error after this long)
+// (behind the ring, in the same allocation: a 128-byte line with the abort word [0], its diagnostics [1], [2] and -- words 4, 5 -- the
+// device address of the handle's host-mapped error word; found from the ring's address alone, so that a resident kernel carries ONE pointer
+// through its step loop: every scalar register counts there)
+__device__ __forceinline__ unsigned* persist_abort_line(const char* ring) { return (unsigned*)(ring + (size_t)kPersistRing * 64); }
+__device__ __forceinline__ void persist_give_up(const char* ring, int lane, int idx, int env) {
+    if (lane == 0) {
+        unsigned* line = persist_abort_line(ring);
+        unsigned* err = *(unsigned* const*)(line + 4);
+        store_dev_i32(line + 1, idx);
+        store_dev_i32(line + 2, env);
+        store_dev_i32(line, 1);
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// Wait for command `idx` (sequence number idx + 1) of the ring.  Wave-uniform results.  false: timed out / aborted.
+__device__ __forceinline__ bool persist_wait(const char* ring, int idx, int lane, int& n_steps, unsigned long long& slab,
+                                             unsigned long long& stats) {
+    const char* addr = ring + (size_t)(idx & (kPersistRing - 1)) * 64 + (lane & 3) * 16;
+    int pause = 0;
+    for (int polls = 0; polls < kPersistMaxPolls; ++polls) {
+        f4 v;
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+        const unsigned seq = (unsigned)__builtin_bit_cast(int, readlane_const<3>(v.w));
+        if (seq == (unsigned)idx + 1u) {
+            const unsigned lo0 = (unsigned)__builtin_bit_cast(int, readlane_const<0>(v.x)), hi0 = (unsigned)__builtin_bit_cast(int, readlane_const<0>(v.y));
+            const unsigned lo1 = (unsigned)__builtin_bit_cast(int, readlane_const<0>(v.z)), hi1 = (unsigned)__builtin_bit_cast(int, readlane_const<0>(v.w));
+            slab = ((unsigned long long)hi0 << 32) | lo0;
+            stats = ((unsigned long long)hi1 << 32) | lo1;
+            n_steps = __builtin_bit_cast(int, readlane_const<1>(v.z));
+            return true;
+        }
+        if ((polls & 255) == 255 && __builtin_amdgcn_readfirstlane(load_dev_i32_now(persist_abort_line(ring))) != 0) return false;
+        if (pause < 8) __builtin_amdgcn_s_sleep(1); else if (pause < 64) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(16);
+        pause += 1;
+    }
+    return false;
+}
+
 // the episode record: env.py:115-125 (nine keys) + Time.n_episodes
 __device__ __forceinline__ void write_stats(evac_episode_stats_t* dst, const Env& e, const StepOut& o) {
     dst->episode_reward = e.acc_ret;

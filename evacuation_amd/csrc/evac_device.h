@@ -570,7 +570,9 @@ EVAC_STEP_KERNEL_DEFAULT(k_step_norm_default_config, true)
 // of that code.
 // CHAIN: the launch is one of a chain of overlapping launches on two queues (evac_common.h, ChainArgs): every wave first waits
 // for ITS env's generation word, exchanges the state by device-scope accesses and publishes the next generation at its end.
-template <class F, bool GRAV, bool DIAG, bool CHAIN = false>
+// PERSIST: the kernel stays resident and takes every evac_rollout call as a command from a ring (evac_common.h, PersistCmd): the state
+// stays in registers from call to call -- no launch boundary, no prologue, no hand-off -- until a STOP command (evac_join).
+template <class F, bool GRAV, bool DIAG, bool CHAIN = false, bool PERSIST = false>
 __device__ __forceinline__ void rollout_body(
     typename F::Smem& sm, const Params& p, int n_steps, const float2* __restrict__ actions, float2* __restrict__ actions_out,
     float* __restrict__ slab_out, evac_episode_stats_t* __restrict__ final_stats, int capture_envs,
@@ -669,7 +671,7 @@ __device__ __forceinline__ void rollout_body(
         }
         lane_adir = agent_direction(p, lane_act.x, lane_act.y);
     };
-    draw_actions(0);
+    if constexpr (!PERSIST) draw_actions(0);
 #ifdef EVAC_STEP_TIMES
     asm volatile("" ::"v"(lane_adir.x), "v"(lane_adir.y));
     EVAC_MARK(mark_act_);
@@ -715,6 +717,23 @@ __device__ __forceinline__ void rollout_body(
             pace_seen = (w.lane & 3) < pace_prio ? (1 << 30) : -1;
         }
     }
+    // PERSIST: one pass of the loop below per command; `t_base` = the steps of the commands before (the pace counters run on)
+    int cmd_index = PERSIST ? chain.gen : 0, t_base = 0;
+    bool persist_lost = false;
+    for (;;) {
+    if constexpr (PERSIST) {
+        unsigned long long c_slab, c_stats;
+        int c_steps;
+        if (!persist_wait(chain.xchg, cmd_index, w.lane, c_steps, c_slab, c_stats)) {     // (wave-uniform) no command came: the host is told
+            persist_lost = true;
+            break;
+        }
+        if (c_steps == 0) break;                        // STOP: evac_join
+        n_steps = c_steps;
+        slab_out = (float*)c_slab;
+        final_stats = (evac_episode_stats_t*)c_stats;
+        draw_actions(0);                                 // (RandomAgent actions: calls with GIVEN actions take the plain path, evac_api.hip)
+    }
     // Staging block of the slab rows (GRAV kernels): the step's row goes to byte offset `stage_off`; the block is flushed after
     // step `flush_t` (its seventh row, or the launch's last); `stage_t0` = the step its first row belongs to.
     int stage_off = 0, stage_t0 = 0, flush_t = min(kStageSteps, n_steps) - 1;
@@ -741,7 +760,7 @@ __device__ __forceinline__ void rollout_body(
                 }
             }
         }
-        if constexpr (F::kPace) pace_step(pace_slot, &sm.progress[EVAC_PACE_SIMD * 4], w.lane, t, pace_seen, pace_prio);
+        if constexpr (F::kPace) pace_step(pace_slot, &sm.progress[EVAC_PACE_SIMD * 4], w.lane, t_base + t, pace_seen, pace_prio);
         EVAC_T(w, 12);  // (sub-phase of the diagnostic build: loop top + pace keeping)
 #undef EVAC_PACE_SIMD
 #undef EVAC_PACE_K
@@ -859,6 +878,16 @@ __device__ __forceinline__ void rollout_body(
             if (t + 1 < n_steps) draw_actions(t + 1);
         }
         EVAC_T(w, 7);   // autoreset check, observation epilogue, output stores
+    }
+    if constexpr (!PERSIST) break;
+    cmd_index += 1;
+    t_base += n_steps;
+    }
+    if constexpr (PERSIST) {
+        if (persist_lost) {                              // (the state in registers is behind what the host has asked for: the run is void)
+            persist_give_up(chain.xchg, w.lane, cmd_index, w.env);
+            if constexpr (F::kEnvBarrier) return;        // (several waves per env: they all read the same ring and give up alike)
+        }
     }
 #ifdef EVAC_STAMP
     unsigned long long rt1_;
@@ -984,6 +1013,25 @@ __global__ __launch_bounds__(F::kBlock, 4) void k_rollout_chain_default_config(
     const Params q = default_config_constants<GRAV>(p);
     rollout_body<F, GRAV, false, true>(sm, q, n_steps, actions, nullptr, slab_out, final_stats, 0, nullptr, nullptr, perm, moving_out,
                                        deal_loads, deal_perm, chain);
+}
+// One persistent kernel per join (evac_options_t.chain = 2): rollout_body<..., PERSIST> -- n_steps, the slab, the episode records and the
+// actions come with every command of the ring at chain.xchg, the first of them command chain.gen.
+template <class F, bool GRAV>
+__global__ __launch_bounds__(F::kBlock, 4) void k_rollout_persist(
+    Params p, const int* __restrict__ perm, int* __restrict__ moving_out, const int* __restrict__ deal_loads, int* __restrict__ deal_perm,
+    ChainArgs chain) {
+    __shared__ typename F::Smem sm;
+    rollout_body<F, GRAV, false, false, true>(sm, p, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, perm, moving_out,
+                                              deal_loads, deal_perm, chain);
+}
+template <class F, bool GRAV>
+__global__ __launch_bounds__(F::kBlock, 4) void k_rollout_persist_default_config(
+    Params p, const int* __restrict__ perm, int* __restrict__ moving_out, const int* __restrict__ deal_loads, int* __restrict__ deal_perm,
+    ChainArgs chain) {
+    __shared__ typename F::Smem sm;
+    const Params q = default_config_constants<GRAV>(p);
+    rollout_body<F, GRAV, false, false, true>(sm, q, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, perm, moving_out,
+                                              deal_loads, deal_perm, chain);
 }
 // (re)start of a chain: every env's generation word (device-scope stores, like the launches' own), and one permutation copied to
 // the three other buffers of the four-deep rotation

@@ -198,6 +198,10 @@ def test_kernel_resource_budgets():
         headline = ("k_step" in name or "k_rollout" in name) and "diag" not in name and \
                    ("Wave<1," in name or "_sub<" in name or "Cells<" in name or "Team<" in name)
         generic_chain = "k_rollout_chain<" in name     # chained launches of NON-default configurations (the benchmark's faces are the _default_config ones)
+        generic_persist = "k_rollout_persist<" in name # ... and their persistent kernels: the command loop around the step loop costs them a few scalar spills
+        if generic_persist:
+            assert k["private_segment_fixed_size"] <= 40, (name, k)
+            continue
         if headline and not generic_chain:
             assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (name, k)
         if generic_chain:                              # ... may keep a few spilled registers (the hand-off's addresses live through the step loop)
@@ -210,4 +214,6 @@ def test_kernel_resource_budgets():
         assert sum(fam in n and "k_rollout<" in n for n in names) == 2 and sum(fam in n and "k_rollout_default_config<" in n for n in names) == 2
     # chained launches: one-wave envs in 256-thread and in CU-wide workgroups, four-wave envs in CU-wide workgroups; 2 observation faces each
     assert sum("k_rollout_chain<" in n for n in names) == 6 and sum("k_rollout_chain_default_config<" in n for n in names) == 6
+    # one persistent kernel per join: the CU-wide families of one- and four-wave envs, 2 observation faces, generic + default configuration
+    assert sum("k_rollout_persist<" in n for n in names) == 4 and sum("k_rollout_persist_default_config<" in n for n in names) == 4
     assert sum("k_rollout_default_config" in n for n in names) >= 30 and sum("k_step_default_config" in n for n in names) >= 20

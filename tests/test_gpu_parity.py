@@ -588,17 +588,22 @@ def _where_slabs_differ(outs, refs, replay=None):
     return " | ".join(lines) if lines else "(equal apart from NaN payloads)"
 
 
-@pytest.mark.parametrize("n,E,wrap_kw,T,wide", [
-    (60, 4096, dict(positions="grav", alpha=3), 20, 1),                       # BASELINE config 2 with the driver's launch length
-    (60, 512, dict(positions="grav", alpha=3), 7, 1),                         # CU-wide forced on a small batch, odd launch length
-    (33, 64, dict(positions="rel", statuses="ohe", type="Box"), 10, 1),       # generic observation, four workgroups
-    (64, 160, dict(positions="abs", statuses="cat", type="Dict"), 5, 1),      # the env fills its wave; generic kernels (not the default configuration)
-    (256, 1024, dict(positions="grav", alpha=3), 20, 1),                      # BASELINE config 3: four waves per env, four envs per CU-wide workgroup
-    (200, 52, dict(positions="rel", statuses="ohe", type="Box"), 6, 1),       # four-wave envs that do not fill their lanes, 13 workgroups, Box observation
-    (60, 4096, dict(positions="grav", alpha=3), 20, 0),                       # BASELINE config 2 in 256-thread workgroups (four envs each, no deal)
-    (33, 36, dict(positions="rel", statuses="ohe", type="Box"), 9, 0),        # ... a small batch of them, generic observation
+@pytest.mark.parametrize("n,E,wrap_kw,T,wide,form", [
+    (60, 4096, dict(positions="grav", alpha=3), 20, 1, 1),                    # BASELINE config 2 with the driver's launch length
+    (60, 512, dict(positions="grav", alpha=3), 7, 1, 1),                       # CU-wide forced on a small batch, odd launch length
+    (33, 64, dict(positions="rel", statuses="ohe", type="Box"), 10, 1, 1),      # generic observation, four workgroups
+    (64, 160, dict(positions="abs", statuses="cat", type="Dict"), 5, 1, 1),     # the env fills its wave; generic kernels (not the default configuration)
+    (256, 1024, dict(positions="grav", alpha=3), 20, 1, 1),                     # BASELINE config 3: four waves per env, four envs per CU-wide workgroup
+    (200, 52, dict(positions="rel", statuses="ohe", type="Box"), 6, 1, 1),      # four-wave envs that do not fill their lanes, 13 workgroups, Box observation
+    (60, 4096, dict(positions="grav", alpha=3), 20, 0, 1),                     # BASELINE config 2 in 256-thread workgroups (four envs each, no deal)
+    (33, 36, dict(positions="rel", statuses="ohe", type="Box"), 9, 0, 1),     # ... a small batch of them, generic observation
+    # chain = 2: ONE PERSISTENT KERNEL per join, every launch a command of its ring (the state stays in registers from call to call)
+    (60, 4096, dict(positions="grav", alpha=3), 20, 1, 2),
+    (33, 64, dict(positions="rel", statuses="ohe", type="Box"), 10, 1, 2),
+    (256, 1024, dict(positions="grav", alpha=3), 20, 1, 2),
+    (200, 52, dict(positions="rel", statuses="ohe", type="Box"), 6, 1, 2),
 ])
-def test_chained_launches_equal_plain_launches(ea, n, E, wrap_kw, T, wide):
+def test_chained_launches_equal_plain_launches(ea, n, E, wrap_kw, T, wide, form):
     """evac_options_t.chain = 1: consecutive rollout launches on two queues, ordered per env by generation
     words on the device.  Slabs, episode records and the final state of many back-to-back launches -- autoresets among them --
     equal the plain handle's bit for bit; calls that are not plain rollouts join and restart the chain behind them."""
@@ -606,8 +611,9 @@ def test_chained_launches_equal_plain_launches(ea, n, E, wrap_kw, T, wide):
     cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=45, is_new_exiting_reward=True, is_new_followers_reward=True)
     wrap = ea.EnvWrappersConfig(**wrap_kw)
     one = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=11, options=ea.KernelOptions(cu_wide=wide))
-    ch = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=11, options=ea.KernelOptions(cu_wide=wide, chain=1))
-    assert ch.own_streams == 2 and ch.num_parts == 1 and ch.resolved_options().chain == 1 and "chained" in ch.kernel_variant()
+    ch = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=11, options=ea.KernelOptions(cu_wide=wide, chain=form))
+    assert ch.own_streams == 2 and ch.num_parts == 1 and ch.resolved_options().chain == form
+    assert ("chained" if form == 1 else "persistent") in ch.kernel_variant()
     assert ("CU-wide" in ch.kernel_variant()) == bool(wide)
     assert one.own_streams == 0
     one.reset(); ch.reset()
@@ -678,6 +684,60 @@ def test_a_chained_launch_that_is_lost_is_reported(ea):
     torch.cuda.synchronize()
     assert torch.isfinite(a["slab"]).all() and a["slab"].shape == ref.rollout(6)["slab"].shape
     ch.close(); ref.close()
+
+
+def test_a_persistent_kernel_left_without_commands_gives_up_and_says_so(ea):
+    """evac_options_t.chain = 2: the resident kernel's waits are bounded.  A caller who starts it and then neither launches nor joins for
+    longer than the bound gets the error word and ERR_TEAM_ABORTED from the next call -- never a hang, never silently stale outputs."""
+    import time
+    import torch
+    from evacuation_amd import _lib
+    cfg = ea.EnvConfig(number_of_pedestrians=60, max_timesteps=100)
+    wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
+    ch = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=64, seed=3, options=ea.KernelOptions(cu_wide=1, chain=2))
+    assert "persistent" in ch.kernel_variant()
+    ch.reset()
+    out = {"slab": torch.empty((4, 64, ch.obs_dim + 3), device=ch.device)}
+    go = ch.rollout_launcher(4, out)
+    go(); go()
+    t0 = time.time()
+    while ch.team_error(sync=False) == 0 and time.time() - t0 < 20.0:      # (no join: the kernel polls its ring until its bound runs out)
+        time.sleep(0.05)
+    assert ch.team_error(sync=False) == 1, "the resident kernel is still waiting after 20 s"
+    with pytest.raises(_lib.EvacError) as ei:
+        ch.get_state()
+    assert ei.value.code == _lib.ERR_TEAM_ABORTED and "persistent" in str(ei.value)
+    ch.team_clear_error()
+    assert ch.team_error() == 0 and "persistent" not in ch.kernel_variant()
+    ch.reset()
+    a = ch.rollout(6)
+    torch.cuda.synchronize()
+    assert torch.isfinite(a["slab"]).all()
+    ch.close()
+
+
+def test_a_persistent_kernels_ring_may_be_lapped(ea):
+    """More calls without a join than the command ring holds (1024): the library stops the kernel, waits for it on the host and starts the
+    next one -- the results are those of as many plain launches."""
+    import torch
+    cfg = ea.EnvConfig(number_of_pedestrians=33, max_timesteps=45, is_new_exiting_reward=True, is_new_followers_reward=True)
+    wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
+    one = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=32, seed=5, options=ea.KernelOptions(cu_wide=1))
+    ch = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=32, seed=5, options=ea.KernelOptions(cu_wide=1, chain=2))
+    one.reset(); ch.reset()
+    out = {"slab": torch.empty((1, 32, ch.obs_dim + 3), device=ch.device)}
+    ref = {"slab": torch.empty((1, 32, ch.obs_dim + 3), device=ch.device)}
+    go, go_ref = ch.rollout_launcher(1, out), one.rollout_launcher(1, ref)
+    for _ in range(2300):
+        go(); go_ref()
+    ch.join()
+    torch.cuda.synchronize()
+    assert ch.team_error(sync=False) == 0
+    assert torch.equal(out["slab"], ref["slab"])
+    sa, sb = one.get_state(), ch.get_state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    one.close(); ch.close()
 
 
 def test_full_size_invariants_c2(ea):

@@ -179,18 +179,18 @@ def test_cu_wide_default_config_rollout_vs_oracle(ea):
     assert peds >= 0.92 * all_peds and scalars >= 0.97 * 96 * 50, (peds, all_peds, scalars)     # (observed: 97.6 % / 100 %, printed at the end of the session)
 
 
-@pytest.mark.parametrize("face", ["c2", "c2_chained", "c3", "c5_team8"])
+@pytest.mark.parametrize("face", ["c2", "c2_chained", "c2_persistent", "c3", "c5_team8"])
 def test_production_faces_late_in_an_episode_vs_oracle(ea, face):
     """the same faces checked where an episode spends most of its time -- from t = 1200 (N = 60, 256) / 600
     (N = 1024) on, 40 free-running steps against the oracle started from the batch's own state at that moment: compacted rows and
-    columns, row-less envs (no tile, no loop), the teams' transposed few-rows sweep.  `c2_chained`: BASELINE config 2's kernel as
-    the bench times it since round 6 -- chained launches -- with the 40 steps issued as two launches of 20."""
-    if face in ("c2", "c2_chained"):
+    columns, row-less envs (no tile, no loop), the teams' transposed few-rows sweep.  `c2_chained` / `c2_persistent`: BASELINE config 2's kernel in
+    the forms the bench times since round 6 -- chained launches, one persistent kernel per join."""
+    if face in ("c2", "c2_chained", "c2_persistent"):
         p = O.OracleParams(number_of_pedestrians=60, is_new_exiting_reward=True, is_new_followers_reward=True, max_timesteps=2000)
         wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
-        opts = ea.KernelOptions(cu_wide=1, chain=1 if face == "c2_chained" else 0)
+        opts = ea.KernelOptions(cu_wide=1, chain={"c2": 0, "c2_chained": 1, "c2_persistent": 2}[face])
         peds, all_peds, scalars = check_against_oracle(ea, p, wrap, E=96, T=40, seed=0x5EED0002, offset=1000, late=1200, options=opts,
-                                                       expect_variant=("k_rollout_default_config", "CU-wide") + (("chained",) if face == "c2_chained" else ()))
+                                                       expect_variant=("k_rollout_default_config", "CU-wide") + {"c2": (), "c2_chained": ("chained",), "c2_persistent": ("persistent",)}[face])
         assert peds >= 0.85 * all_peds and scalars >= 0.9 * 96 * 40, (peds, all_peds, scalars)
     elif face == "c3":
         p = O.OracleParams(number_of_pedestrians=256, is_new_exiting_reward=True, max_timesteps=2000)

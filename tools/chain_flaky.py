@@ -33,7 +33,7 @@ def one_run(n, E, wrap_kw, T, foreign=1, reps=6):
     cfg = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=45, is_new_exiting_reward=True, is_new_followers_reward=True)
     wrap = ea.EnvWrappersConfig(**wrap_kw)
     one = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=11, options=ea.KernelOptions(cu_wide=1))
-    ch = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=11, options=ea.KernelOptions(cu_wide=1, chain=1))
+    ch = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=11, options=ea.KernelOptions(cu_wide=1, chain=int(os.environ.get("FLAKY_CHAIN", "1"))))
     one.reset(); ch.reset()
     R = 12
     outs = [{"slab": torch.empty((T, E, one.obs_dim + 3), device=ch.device), "episode_stats": torch.zeros((T, E, ch.stats_words), device=ch.device)} for _ in range(R)]

@@ -8,6 +8,7 @@ say() { echo "$(date +%T) $*" | tee -a $P; }
 B="python bench.py"
 if [ $PART = all ] || [ $PART = lines ]; then
 say "driver line";            $B --steps 20 --warmup 5 > gpurun_out/$TAG/bench_c2_driver.json 2> gpurun_out/$TAG/bench_c2_driver.err
+say "driver line, chained";   $B --steps 20 --warmup 5 --rollout-form chain --no-cpu-baseline --no-step-api > gpurun_out/$TAG/bench_c2_driver_chained_launches.json 2>/dev/null
 say "driver line, plain";     $B --steps 20 --warmup 5 --rollout-form one --no-cpu-baseline --no-step-api > gpurun_out/$TAG/bench_c2_driver_one_kernel_per_launch.json 2>/dev/null
 say "driver line, two parts"; $B --steps 20 --warmup 5 --rollout-form parts --no-cpu-baseline --no-step-api > gpurun_out/$TAG/bench_c2_driver_two_parts.json 2>/dev/null
 say "default line";           $B --no-cpu-baseline > gpurun_out/$TAG/bench_c2_default.json 2>/dev/null

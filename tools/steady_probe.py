@@ -61,9 +61,10 @@ if "e" in which:
     timed("e) one handle, CHAINED launches           ", [env.rollout_launcher(T, out)], [env.join], 4096)
     print("   team/chain error word:", env.team_error(), env.kernel_variant())
     env.close()
-if "f" in which or "g" in which:          # BASELINE config 3 (N = 256 x 1024 envs, four waves per env): plain and chained
+if "f" in which or "g" in which or "q" in which:          # BASELINE config 3 (N = 256 x 1024 envs, four waves per env): plain, chained, persistent
     cfg3 = ea.EnvConfig(number_of_pedestrians=256, is_new_exiting_reward=True, is_new_followers_reward=True, max_timesteps=2000)
-    for tag, opt in (("f) C3 one handle, one kernel per launch  ", dict(chain=0)), ("g) C3 one handle, CHAINED launches       ", dict(chain=1))):
+    for tag, opt in (("f) C3 one handle, one kernel per launch  ", dict(chain=0)), ("g) C3 one handle, CHAINED launches       ", dict(chain=1)),
+                     ("q) C3 ONE PERSISTENT KERNEL per sweep    ", dict(chain=2))):
         if tag[0] not in which:
             continue
         env = ea.BatchedEvacuationEnv(cfg3, wrap, num_envs=1024, seed=0x5EED0003, options=ea.KernelOptions(**opt))
@@ -122,3 +123,8 @@ if "l" in which or "m" in which:
         timed("m) C3: 8192 envs, one handle              ", [env.rollout_launcher(T, out)], [env.join], 8192, sweeps=4, warm=min(WARM, 40))
         print("  ", env.kernel_variant())
         env.close()
+if "p" in which:
+    env, out = make(4096, 0x5EED0001, chain=2)
+    timed("p) ONE PERSISTENT KERNEL per sweep         ", [env.rollout_launcher(T, out)], [env.join], 4096)
+    print("   error word:", env.team_error(), env.kernel_variant())
+    env.close()
