@@ -151,8 +151,11 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
  *   team_coop   1: team grids are launched with hipLaunchCooperativeKernel (3-4 % slower; automatic: plain launches)
  *   team_fault  1: fault injection for tests (the team grid is launched one workgroup short; chained launches: the last env's
  *               generation word is never published)
- *   chain       1: CHAINED rollout launches (CU-wide one-wave handles with a bound workspace; see below); 0: never; -1: where it
- *               pays (those handles).  Wins over `parts`.  evac_create() always takes 0, like parts = 1. */
+ *   chain       1: CHAINED rollout launches (CU-wide handles with a bound workspace; see below); 0: never; -1: where it
+ *               pays (those handles).  Wins over `parts`.  evac_create() always takes 0, like parts = 1.
+ *               2: ONE PERSISTENT KERNEL PER JOIN (see below; on request only -- the kernel holds the device until evac_join);
+ *               where it cannot be had (no CU-wide family, a batch of more workgroups than the device has CUs, no large BAR) the
+ *               handle falls back to 1, then 0: evac_get_options says what it became. */
 typedef struct evac_options {
     int32_t subwave, cells, cu_wide, team, specialize, parts, team_coop, team_fault, chain;
 } evac_options_t;
@@ -197,7 +200,24 @@ int evac_destroy(evac_handle_t h);
  * that times out (it cannot, unless a launch is lost: every launch a wave waits for was dispatched in full before its own) voids
  * the run like a lost team member: the handle's error word is raised, evac_* calls return EVAC_ERR_TEAM_ABORTED until
  * evac_team_clear_error(), and the handle issues plain launches from then on.
- * evac_own_streams: 0, or 2 for handles with parts = 2 or chain = 1 (the kernels in flight per rollout round). */
+ *
+ * ONE PERSISTENT KERNEL PER JOIN (chain = 2; no reference analogue).  What a launch adds to the heaviest env's sequence of steps --
+ * the queue's boundary, the dispatch of a 1024-thread workgroup (3.4 us on a CU that has just become free), the prologue, the
+ * state's way through memory -- is a fifth of a 20-step call even when launches are chained.  With chain = 2 the first evac_rollout
+ * after a join starts the rollout kernel on the handle's stream and every call (that one included) becomes a 64-byte COMMAND
+ * {steps, slab, episode records} that the host writes, through the PCIe BAR, into a ring in uncached device memory; the resident
+ * kernel runs the call's steps into the call's slab and takes the next command with the state still in registers.  evac_join
+ * posts STOP: the waves store their state and the kernel ends.  Every call still computes exactly its n_steps into its own
+ * buffers; same bits as every other form.  Stream contract: that of parts = 2, and in addition
+ *   - between the first evac_rollout and the evac_join the kernel HOLDS the CUs it runs on (all of them for a batch that fills the
+ *     device): other kernels of the process wait for the join, and a host that waits for the DEVICE (hipDeviceSynchronize,
+ *     hipStreamSynchronize of a stream with work queued behind the kernel) without having joined waits for the kernel's own bound;
+ *   - the kernel's waits for a command are bounded (~2 s): a caller who neither calls nor joins for that long gets the error word
+ *     and EVAC_ERR_TEAM_ABORTED (outputs void), as for a lost chained launch -- never a hang;
+ *   - calls with `actions` (and the diagnostic faces) join and run as one kernel on `stream`; more than ~1000 calls without a
+ *     join make the library stop the kernel, wait for it on the host and start the next one;
+ *   - one such handle at a time per device may have its kernel resident (a second one's kernel starts when the first has joined).
+ * evac_own_streams: 0, or 2 for handles with parts = 2, chain = 1 or chain = 2. */
 int evac_join(evac_handle_t h, void* stream);
 /* The NEXT evac_rollout call puts the handle's own streams behind what its `stream` holds at that moment, as the first call after a
  * join does: for a caller who, between two rollout calls and without a join, gave `stream` work the coming launches must follow -- a

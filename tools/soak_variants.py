@@ -47,11 +47,16 @@ for name, n, E, wrap_kw, T in (("C5 teams of 8 CUs", 1024, 32, dict(positions="r
 # rounds a per-step call in between (the chain joins, exports, and restarts from an import).
 for name, n, E, wrap_kw, T, opts in (("C2 chained, 20-step launches", 60, 4096, dict(positions="grav", alpha=3), 20, dict()),
                                      ("C2 chained, 7-step launches", 60, 4096, dict(positions="grav", alpha=3), 7, dict()),
-                                     ("N = 40 x 512 chained (Box obs)", 40, 512, dict(positions="rel", statuses="ohe", type="Box"), 10, dict(cu_wide=1))):
+                                     ("N = 40 x 512 chained (Box obs)", 40, 512, dict(positions="rel", statuses="ohe", type="Box"), 10, dict(cu_wide=1)),
+                                     # one persistent kernel per join (chain = 2): the same pattern, every launch a command of the resident kernel's ring
+                                     ("C2 persistent, 20-step calls", 60, 4096, dict(positions="grav", alpha=3), 20, dict(chain=2)),
+                                     ("C2 persistent, 7-step calls", 60, 4096, dict(positions="grav", alpha=3), 7, dict(chain=2)),
+                                     ("C3 persistent, 20-step calls", 256, 1024, dict(positions="grav", alpha=3), 20, dict(chain=2)),
+                                     ("N = 40 x 512 persistent (Box obs)", 40, 512, dict(positions="rel", statuses="ohe", type="Box"), 10, dict(cu_wide=1, chain=2))):
     cfg = ea.EnvConfig(number_of_pedestrians=n, is_new_exiting_reward=True, is_new_followers_reward=True, max_timesteps=700)
     wrap = ea.EnvWrappersConfig(**wrap_kw)
     a = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=123, options=ea.KernelOptions(cu_wide=0, workspace=False))
-    b = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=123, options=ea.KernelOptions(chain=1, **opts))
+    b = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=123, options=ea.KernelOptions(**{"chain": 1, **opts}))
     a.reset(); b.reset()
     R = 16
     outs = [{"slab": torch.empty((T, E, a.obs_dim + 3), device=b.device), "episode_stats": torch.zeros((T, E, b.stats_words), device=b.device)} for _ in range(R)]
