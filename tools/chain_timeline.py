@@ -2,7 +2,8 @@
 """A rocprofv3 --kernel-trace CSV of a bench.py run as the timeline of its rollout launches: launches per hardware queue, the
 start-to-start distance of consecutive launches (= the launch PERIOD the roofline is priced on), each kernel's own duration (a
 chained launch is enqueued behind its queue's previous launch and ends two periods later), how many consecutive launches overlap, and
-a sample of begin / end pairs.  usage: chain_timeline.py <dir with *_kernel_trace.csv> [kernel substring]"""
+a sample of begin / end pairs.  A PERSISTENT rollout kernel (evac_options_t.chain = 2) carries all calls of a sweep: its duration over the
+calls per sweep (third argument) is the call period.  usage: chain_timeline.py <dir with *_kernel_trace.csv> [kernel substring] [calls per kernel]"""
 import csv, glob, statistics as st, sys
 d = sys.argv[1]
 sub = sys.argv[2] if len(sys.argv) > 2 else "k_rollout"
@@ -18,6 +19,16 @@ q = {}
 for x in r:
     q[x["Queue_Id"]] = q.get(x["Queue_Id"], 0) + 1
 print(f"kernel: {name[:150]}")
+if "persist" in name:
+    calls = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    du_ = sorted((E[i] - S[i]) for i in range(len(r)))
+    full = [x for x in du_ if x > 0.5 * du_[len(du_) // 2]]            # (whole sweeps: warm-up and single-call kernels of the diagnostics left out)
+    tail = full[-max(1, len(full) // 4):] if False else full
+    print(f"persistent kernels: {len(r)} in the trace, {len(full)} of them whole sweeps; duration of a whole sweep [us]: mean {st.mean(full):.1f}, median {st.median(full):.1f}")
+    if calls:
+        late = [E[i] - S[i] for i in range(len(r) * 3 // 4, len(r)) if E[i] - S[i] > 0.5 * du_[len(du_) // 2]]
+        print(f"  = {st.mean(full) / calls:.2f} us per call over the run ({calls} calls per kernel), {st.median(late) / calls:.2f} us per call in its last quarter "
+              f"(kernel start, the calls' steps and STOP; the sweep's join and timing events lie outside the kernel)")
 print(f"launches: {len(r)}; per hardware queue: {q}")
 # consecutive launches closer than 2.5 median distances belong to one back-to-back run (a sweep); the gaps between sweeps are left out
 all_ss = [S[i + 1] - S[i] for i in range(len(r) - 1)]

@@ -15,6 +15,12 @@ if [ -d $d ]; then
   { cat $d/command.txt; echo; cat $d/timeline.txt; } > profiles/${T}_c2_driver_timeline.txt
   tail -1 $d/bench_line.json > profiles/${T}_c2_driver_traced_line.json
 fi
+d=gpurun_out/${T}_c2_chained
+if [ -d $d ]; then
+  cp "$(ls -t $d/stats/*/*_kernel_stats.csv | head -1)" profiles/${T}_c2_chained_kernel_stats.csv
+  { cat $d/command.txt; echo; cat $d/timeline.txt; } > profiles/${T}_c2_chained_timeline.txt
+  tail -1 $d/bench_line.json > profiles/${T}_c2_chained_traced_line.json
+fi
 # every entry of `workloads` traced on its own (the trace covers the launches that entry times and no others)
 for s in c2_one_kernel c3 c5_shard big_step; do
   d=gpurun_out/${T}_side_$s

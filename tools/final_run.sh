@@ -33,8 +33,15 @@ say "kernel trace of the driver's command"
 D=gpurun_out/${TAG}_c2_driver; mkdir -p $D
 echo "bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-step-api" > $D/command.txt
 (cd /tmp && TMPDIR=/tmp timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$D/stats -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-step-api > $ROOT/$D/stats.log 2>&1)
-python tools/chain_timeline.py $D/stats > $D/timeline.txt 2>&1
+python tools/chain_timeline.py $D/stats k_rollout 100 > $D/timeline.txt 2>&1      # (100 calls of 20 steps per sweep = per persistent kernel)
 grep '^{"' $D/stats.log | tail -1 > $D/bench_line.json   # (rocprofv3 prints its own lines after the program's)
+# 1b. the same command with CHAINED launches (evac_options_t.chain = 1): the timeline of two launches in flight
+say "kernel trace of the driver's command, chained launches"
+D=gpurun_out/${TAG}_c2_chained; mkdir -p $D
+echo "bench.py --steps 20 --warmup 5 --rollout-form chain --no-cpu-baseline --no-step-api" > $D/command.txt
+(cd /tmp && TMPDIR=/tmp timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$D/stats -- python3 $ROOT/bench.py --steps 20 --warmup 5 --rollout-form chain --no-cpu-baseline --no-step-api > $ROOT/$D/stats.log 2>&1)
+python tools/chain_timeline.py $D/stats > $D/timeline.txt 2>&1
+grep '^{"' $D/stats.log | tail -1 > $D/bench_line.json
 # 2. every entry of `workloads` on its own: the trace covers the launches that entry times and no others
 for s in c2_one_kernel c3 c5_shard big_step; do
   say "kernel trace of --side-only $s"
@@ -43,7 +50,7 @@ for s in c2_one_kernel c3 c5_shard big_step; do
   (cd /tmp && TMPDIR=/tmp timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$D/stats -- python3 $ROOT/bench.py --side-only $s --steps 20 > $ROOT/$D/stats.log 2>&1)
   grep '^{"' $D/stats.log | tail -1 > $D/bench_line.json   # (rocprofv3 prints its own lines after the program's)
   python tools/summarize_pmc.py $D > $D/summary.txt 2>&1
-  python tools/chain_timeline.py $D/stats > $D/timeline.txt 2>&1      # (start-to-start = the launch period, also where the entry chains its launches)
+  python tools/chain_timeline.py $D/stats k_ 20 > $D/timeline.txt 2>&1      # (start-to-start = the launch period; c3: one persistent kernel per sweep of 20 calls)
 done
 # 3. counters (separate --pmc passes; short runs: every dispatch is serialised under the counters)
 # (rollouts are counted in their PLAIN launches -- --rollout-form one: rocprofv3 --pmc runs every dispatch alone and a chained launch would wait
