@@ -23,12 +23,12 @@ if "persist" in name:
     calls = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     du_ = sorted((E[i] - S[i]) for i in range(len(r)))
     full = [x for x in du_ if x > 0.5 * du_[len(du_) // 2]]            # (whole sweeps: warm-up and single-call kernels of the diagnostics left out)
-    tail = full[-max(1, len(full) // 4):] if False else full
-    print(f"persistent kernels: {len(r)} in the trace, {len(full)} of them whole sweeps; duration of a whole sweep [us]: mean {st.mean(full):.1f}, median {st.median(full):.1f}")
+    print(f"persistent kernels: {len(r)} in the trace, {len(full)} of them whole sweeps (the others: single calls of the warm-up and of the diagnostics); "
+          f"duration of a whole sweep [us]: mean {st.mean(full):.1f}, median {st.median(full):.1f}")
     if calls:
-        late = [E[i] - S[i] for i in range(len(r) * 3 // 4, len(r)) if E[i] - S[i] > 0.5 * du_[len(du_) // 2]]
-        print(f"  = {st.mean(full) / calls:.2f} us per call over the run ({calls} calls per kernel), {st.median(late) / calls:.2f} us per call in its last quarter "
-              f"(kernel start, the calls' steps and STOP; the sweep's join and timing events lie outside the kernel)")
+        print(f"  = {st.mean(full) / calls:.2f} (mean) / {st.median(full) / calls:.2f} (median) us per call, {calls} calls per kernel: kernel start, the calls' steps and STOP; "
+              f"the sweep's join and its timing events lie outside the kernel")
+    sys.exit(0)
 print(f"launches: {len(r)}; per hardware queue: {q}")
 # consecutive launches closer than 2.5 median distances belong to one back-to-back run (a sweep); the gaps between sweeps are left out
 all_ss = [S[i + 1] - S[i] for i in range(len(r) - 1)]
