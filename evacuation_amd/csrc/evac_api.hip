@@ -628,7 +628,7 @@ void post_command(evac_handle* h, int n_steps, const void* slab, const void* sta
 void destroy_parts(evac_handle* h) {
     DeviceGuard g(h->device);
     if (h->persist && h->persist_running) {            // (a handle destroyed without a join: the resident kernel is told to end)
-        post_command(h, 0, nullptr, nullptr, nullptr);
+        post_command(h, 0, nullptr, nullptr, nullptr);     //  -- and would leave by itself for lack of commands anyway
         h->persist_running = false;
     }
     for (int k = 0; k < 2; ++k)
@@ -658,13 +658,65 @@ void destroy_parts(evac_handle* h) {
     h->parts_pending = false;
 }
 // `stream` waits for everything the part streams have been given so far (evac_join; implied by every call that is not a plain rollout)
+void deal_now(evac_handle_t h, hipStream_t s, bool both);
+// The persistent rollout kernel on the handle's stream.  fresh: the first kernel after a join -- every env starts at command
+// h->persist_seq, workgroup 0 deals the next kernel's envs as it starts; resume: every env at the command it had reached when the kernel
+// before left; stop_at: the index of a STOP command that is already in the ring (the finisher of a join), else INT_MAX.
+int launch_persistent(evac_handle* h, int resume, int stop_at, bool fresh) {
+    using FW = evac::Wave<1, 1024>;
+    using FW4 = evac::Wave<4, 1024>;
+    hipStream_t S = h->part_stream[0];
+    const int E = h->p.n_envs;
+    if (h->sched && h->sched_gen < 0) deal_now(h, S, true);
+    const int g_ = h->sched_gen;
+    const bool dealt = h->sched && g_ >= 0;
+    const bool deals = dealt && fresh;
+    const int32_t* perm = dealt ? h->sched + (2 + (g_ & 1)) * E : nullptr;
+    int32_t* moving = h->sched ? h->sched + (dealt ? (g_ & 1) : 0) * E : nullptr;
+    const int32_t* deal_loads = deals ? h->sched + ((g_ + 1) & 1) * E : nullptr;       // (workgroup 0 deals the NEXT fresh kernel's envs as it starts)
+    int32_t* deal_perm = deals ? h->sched + (2 + ((g_ + 1) & 1)) * E : nullptr;
+    if (deals) h->sched_gen = g_ + 1;
+    evac::ChainArgs ca{h->chain_xchg, h->persist_seq, nullptr, nullptr, 0, nullptr, resume, stop_at};
+#define EVAC_PERSIST_ARGS h->p, (const int*)perm, (int*)moving, (const int*)deal_loads, (int*)deal_perm, ca
+    if (h->cu_wide4) {
+        const dim3 grid((unsigned)(E / FW4::kEnvsPerBlock));
+        if (h->default_cfg && h->p.obs_pos == EVAC_POS_GRAV)
+            hipLaunchKernelGGL((evac::k_rollout_persist_default_config<FW4, true>), grid, dim3(FW4::kBlock), 0, S, EVAC_PERSIST_ARGS);
+        else if (h->default_cfg)
+            hipLaunchKernelGGL((evac::k_rollout_persist_default_config<FW4, false>), grid, dim3(FW4::kBlock), 0, S, EVAC_PERSIST_ARGS);
+        else if (h->p.obs_pos == EVAC_POS_GRAV)
+            hipLaunchKernelGGL((evac::k_rollout_persist<FW4, true>), grid, dim3(FW4::kBlock), 0, S, EVAC_PERSIST_ARGS);
+        else
+            hipLaunchKernelGGL((evac::k_rollout_persist<FW4, false>), grid, dim3(FW4::kBlock), 0, S, EVAC_PERSIST_ARGS);
+    } else {
+        const dim3 grid((unsigned)(E / FW::kEnvsPerBlock));
+        if (h->default_cfg && h->p.obs_pos == EVAC_POS_GRAV)
+            hipLaunchKernelGGL((evac::k_rollout_persist_default_config<FW, true>), grid, dim3(FW::kBlock), 0, S, EVAC_PERSIST_ARGS);
+        else if (h->default_cfg)
+            hipLaunchKernelGGL((evac::k_rollout_persist_default_config<FW, false>), grid, dim3(FW::kBlock), 0, S, EVAC_PERSIST_ARGS);
+        else if (h->p.obs_pos == EVAC_POS_GRAV)
+            hipLaunchKernelGGL((evac::k_rollout_persist<FW, true>), grid, dim3(FW::kBlock), 0, S, EVAC_PERSIST_ARGS);
+        else
+            hipLaunchKernelGGL((evac::k_rollout_persist<FW, false>), grid, dim3(FW::kBlock), 0, S, EVAC_PERSIST_ARGS);
+    }
+#undef EVAC_PERSIST_ARGS
+    if (const int lc = check_launch(h, "evac_rollout (persistent kernel)"); lc != EVAC_OK) return lc;
+    if (hipEventRecord(h->chain_ev, S) != hipSuccess) { (void)hipGetLastError(); return fail(h, EVAC_ERR_HIP, "evac_rollout: event record behind the persistent kernel failed"); }
+    return EVAC_OK;
+}
+// STOP, and behind the resident kernel a FINISHER: a kernel that takes up every env that has not yet run everything up to the STOP (the
+// resident kernel may have left, or be leaving, for lack of commands) and ends at once where there is nothing to do.
+int stop_persistent(evac_handle* h) {
+    const int stop_index = h->persist_seq;
+    post_command(h, 0, nullptr, nullptr, nullptr);
+    h->persist_running = false;
+    return launch_persistent(h, /*resume=*/1, stop_index, /*fresh=*/false);
+}
 int join_parts(evac_handle* h, hipStream_t stream) {
     if (!h->part_stream[0] || !h->parts_pending) return EVAC_OK;
     DeviceGuard g(h->device);
-    if (h->persist && h->persist_running) {            // STOP: the waves store their state and the kernel ends
-        post_command(h, 0, nullptr, nullptr, nullptr);
-        h->persist_running = false;
-    }
+    if (h->persist && h->persist_running)              // STOP: the waves store their state and the kernel ends (+ the finisher)
+        if (const int rc = stop_persistent(h); rc != EVAC_OK) return rc;
     for (int k = 0; k < 2; ++k)
         if (hipEventRecord(h->part_done[k], h->part_stream[k]) != hipSuccess || hipStreamWaitEvent(stream, h->part_done[k], 0) != hipSuccess) {
             (void)hipGetLastError();
@@ -728,17 +780,13 @@ int evac_create_ex(const evac_config_t* cfg, int32_t num_envs, int32_t device, u
             void* dev = (void*)h->team_flag_dev;
             if (!host && !take_error_word(device, &host, &dev)) ok = false;
             if (ok) { h->team_flag_host = (volatile unsigned*)host; h->team_flag_dev = (unsigned*)dev; }
+            ok = ok && hipEventCreateWithFlags(&h->chain_ev, hipEventDisableTiming) == hipSuccess;      // (behind every persistent kernel: has it left?)
             void* ring = nullptr;
-            const size_t rbytes = (size_t)evac::kPersistRing * 64 + 128;          // the ring, then a line with the abort word
+            const size_t rbytes = (size_t)evac::kPersistRing * 64 + 128 + 4 * (size_t)num_envs;      // the ring, a line of diagnostics, next_cmd[E]
             if (ok) { ring = take_uncached(device, rbytes, &h->chain_xchg_bytes); ok = ring != nullptr; }
             if (ok && (hipMemset(ring, 0, rbytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) { (void)hipGetLastError(); ok = false; }
             h->chain_xchg = (char*)ring;
-            if (ok) {
-                h->chain_abort = (unsigned*)((char*)ring + (size_t)evac::kPersistRing * 64);
-                void* err_dev = (void*)h->team_flag_dev;                                     // words 4, 5 of the line: where the kernel raises the error word
-                ok = hipMemcpy((char*)h->chain_abort + 16, &err_dev, sizeof(err_dev), hipMemcpyHostToDevice) == hipSuccess;
-                if (!ok) (void)hipGetLastError();
-            }
+            if (ok) h->chain_abort = (unsigned*)((char*)ring + (size_t)evac::kPersistRing * 64);
         }
         if (ok) {
             h->persist = true;
@@ -1163,18 +1211,15 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
             // ONE PERSISTENT KERNEL PER JOIN: the call becomes a command of the resident kernel's ring.  The kernel is started -- behind
             // what the caller's stream holds at this moment, as the parts' fork -- by the first call after a join (or after
             // evac_order_next_rollout); the calls that follow cost the host a 64-byte write through the BAR and the device nothing but the
-            // steps: the state stays in registers.  (Given actions take the plain path below: their buffer is the caller's stream's business.)
-            using FW = evac::Wave<1, 1024>;
-            using FW4 = evac::Wave<4, 1024>;
+            // steps: the state stays in registers.  A kernel that found no command for ~150 us has LEFT by itself (every env's state and place
+            // in the ring stored): the call then starts one that takes every env up where it stopped.  (Given actions take the plain path
+            // below: their buffer is the caller's stream's business.)
             hipStream_t S = h->part_stream[0];
-            if (h->persist_running && !h->forked) {          // the caller touched a buffer (evac_order_next_rollout): a new kernel behind a new fork
-                post_command(h, 0, nullptr, nullptr, nullptr);
-                h->persist_running = false;
-            }
+            if (h->persist_running && !h->forked)            // the caller touched a buffer (evac_order_next_rollout): a new kernel behind a new fork
+                if (const int rc = stop_persistent(h); rc != EVAC_OK) return rc;
             if (h->persist_running && h->persist_seq - h->persist_first >= evac::kPersistRing - 2) {
-                // the ring is about to lap the kernel: it is stopped and WAITED FOR on the host (once per ~1000 calls without a join)
-                post_command(h, 0, nullptr, nullptr, nullptr);
-                h->persist_running = false;
+                // the ring is about to lap the slowest env: the kernel is stopped and WAITED FOR on the host (once per ~1000 calls without a join)
+                if (const int rc = stop_persistent(h); rc != EVAC_OK) return rc;
                 if (hipStreamSynchronize(S) != hipSuccess) { (void)hipGetLastError(); return fail(h, EVAC_ERR_HIP, "evac_rollout: the persistent kernel did not end"); }
             }
             if (!h->persist_running) {
@@ -1183,43 +1228,15 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
                     return fail(h, EVAC_ERR_HIP, "evac_rollout: fork of the persistent kernel failed");
                 }
                 h->forked = true;
-                const int E = h->p.n_envs;
-                if (h->sched && h->sched_gen < 0) deal_now(h, S, true);
-                const int g_ = h->sched_gen;
-                const bool dealt = h->sched && g_ >= 0;
-                const int32_t* perm = dealt ? h->sched + (2 + (g_ & 1)) * E : nullptr;
-                int32_t* moving = h->sched ? h->sched + (dealt ? (g_ & 1) : 0) * E : nullptr;
-                const int32_t* deal_loads = dealt ? h->sched + ((g_ + 1) & 1) * E : nullptr;       // (workgroup 0 deals the NEXT kernel's envs as it starts)
-                int32_t* deal_perm = dealt ? h->sched + (2 + ((g_ + 1) & 1)) * E : nullptr;
-                if (dealt) h->sched_gen = g_ + 1;
-                if (hipMemsetAsync(h->chain_abort, 0, 16, S) != hipSuccess) { (void)hipGetLastError(); return fail(h, EVAC_ERR_HIP, "evac_rollout: hipMemsetAsync failed"); }
-                evac::ChainArgs ca{h->chain_xchg, h->persist_seq, nullptr, nullptr, 0, nullptr};      // (the abort line and the error word: found from the ring, evac_common.h)
-#define EVAC_PERSIST_ARGS h->p, (const int*)perm, (int*)moving, (const int*)deal_loads, (int*)deal_perm, ca
-                if (h->cu_wide4) {
-                    const dim3 grid((unsigned)(E / FW4::kEnvsPerBlock));
-                    if (h->default_cfg && h->p.obs_pos == EVAC_POS_GRAV)
-                        hipLaunchKernelGGL((evac::k_rollout_persist_default_config<FW4, true>), grid, dim3(FW4::kBlock), 0, S, EVAC_PERSIST_ARGS);
-                    else if (h->default_cfg)
-                        hipLaunchKernelGGL((evac::k_rollout_persist_default_config<FW4, false>), grid, dim3(FW4::kBlock), 0, S, EVAC_PERSIST_ARGS);
-                    else if (h->p.obs_pos == EVAC_POS_GRAV)
-                        hipLaunchKernelGGL((evac::k_rollout_persist<FW4, true>), grid, dim3(FW4::kBlock), 0, S, EVAC_PERSIST_ARGS);
-                    else
-                        hipLaunchKernelGGL((evac::k_rollout_persist<FW4, false>), grid, dim3(FW4::kBlock), 0, S, EVAC_PERSIST_ARGS);
-                } else {
-                    const dim3 grid((unsigned)(E / FW::kEnvsPerBlock));
-                    if (h->default_cfg && h->p.obs_pos == EVAC_POS_GRAV)
-                        hipLaunchKernelGGL((evac::k_rollout_persist_default_config<FW, true>), grid, dim3(FW::kBlock), 0, S, EVAC_PERSIST_ARGS);
-                    else if (h->default_cfg)
-                        hipLaunchKernelGGL((evac::k_rollout_persist_default_config<FW, false>), grid, dim3(FW::kBlock), 0, S, EVAC_PERSIST_ARGS);
-                    else if (h->p.obs_pos == EVAC_POS_GRAV)
-                        hipLaunchKernelGGL((evac::k_rollout_persist<FW, true>), grid, dim3(FW::kBlock), 0, S, EVAC_PERSIST_ARGS);
-                    else
-                        hipLaunchKernelGGL((evac::k_rollout_persist<FW, false>), grid, dim3(FW::kBlock), 0, S, EVAC_PERSIST_ARGS);
-                }
-#undef EVAC_PERSIST_ARGS
-                if (const int lc = check_launch(h, "evac_rollout (persistent kernel)"); lc != EVAC_OK) return lc;
+                if (const int rc = launch_persistent(h, /*resume=*/0, /*stop_at=*/0x7fffffff, /*fresh=*/true); rc != EVAC_OK) return rc;
                 h->persist_running = true;
                 h->persist_first = h->persist_seq;
+            } else if (hipEventQuery(h->chain_ev) == hipSuccess) {
+                // the kernel has left (idle): one that resumes.  (A kernel that is leaving RIGHT NOW is seen at the next call or at the join,
+                // whose finisher runs whatever an env has not run yet: no command is lost, it only waits for that kernel.)
+                if (const int rc = launch_persistent(h, /*resume=*/1, /*stop_at=*/0x7fffffff, /*fresh=*/false); rc != EVAC_OK) return rc;
+            } else {
+                (void)hipGetLastError();                         // (hipErrorNotReady: resident)
             }
             post_command(h, (int)n_steps, slab_out, final_stats, nullptr);
             h->parts_pending = true;

@@ -762,6 +762,8 @@ struct ChainArgs {
     int deal_mode;       // diagnostic (EVAC_CHAIN_DEAL): how workgroup 0 deals the launch after next (schedule_slot); 0 in the product
     unsigned long long* started;   // workgroups of the chain's launches that have started (since the chain's last restart): what the
                                    // NEXT launch's queue waits for before it dispatches (evac_api.hip, "the invariant of the chain")
+    int resume;                    // persistent kernels: 1 = every env takes up at ITS OWN next command (the word the kernel before left for it)
+    int stop_at;                   // persistent kernels: the index of a STOP command that is known to be in the ring (the finisher of a join), else INT_MAX
 };
 constexpr int kChainMaxPolls = 1 << 19;     // bounded wait: ~0.3 s of polls with the back-off below; a launch that gives up voids the run
 // Wait until the env's record holds generation `gen`.  Wave-uniform (all lanes poll the same word).  false: timed out.
@@ -837,28 +839,19 @@ struct PersistCmd {
 };
 static_assert(sizeof(PersistCmd) == 64, "one 64-byte segment");
 constexpr int kPersistRing = 1024;               // commands per ring (the host joins before it would lap the kernel)
-constexpr int kPersistMaxPolls = 1 << 21;        // bounded wait for the next command: ~2 s (a host thread may be descheduled for a while; a caller who
-                                                 // waits for the DEVICE with the kernel resident -- instead of joining -- gets the error after this long)
-// (behind the ring, in the same allocation: a 128-byte line with the abort word [0], its diagnostics [1], [2] and -- words 4, 5 -- the
-// device address of the handle's host-mapped error word; found from the ring's address alone, so that a resident kernel carries ONE pointer
-// through its step loop: every scalar register counts there)
-__device__ __forceinline__ unsigned* persist_abort_line(const char* ring) { return (unsigned*)(ring + (size_t)kPersistRing * 64); }
-__device__ __forceinline__ void persist_give_up(const char* ring, int lane, int idx, int env) {
-    if (lane == 0) {
-        unsigned* line = persist_abort_line(ring);
-        unsigned* err = *(unsigned* const*)(line + 4);
-        store_dev_i32(line + 1, idx);
-        store_dev_i32(line + 2, env);
-        store_dev_i32(line, 1);
-        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-// Wait for command `idx` (sequence number idx + 1) of the ring.  Wave-uniform results.  false: timed out / aborted.
+constexpr int kPersistIdlePolls = 256;           // a wave that finds no command for this many polls (~150 us) LEAVES: it stores its env's state and the
+                                                 // index of the command it was waiting for, and the kernel ends when all its waves have left -- a
+                                                 // resident kernel never outlives the caller's attention (a host that waits for the device, another
+                                                 // kernel that needs the CUs), and the next evac_rollout / evac_join starts a kernel that takes up
+                                                 // every env where it stopped (ChainArgs.resume)
+// (behind the ring, in the same allocation: a 128-byte line of diagnostics, then next_cmd[E] -- per env, the index of the first command it
+// has NOT run; written by a leaving wave, read by the waves of a kernel started with resume = 1)
+__device__ __forceinline__ int* persist_next_cmd(const char* ring) { return (int*)(ring + (size_t)kPersistRing * 64 + 128); }
+// Wait for command `idx` (sequence number idx + 1) of the ring.  Wave-uniform results.  false: none came within the idle bound.
 __device__ __forceinline__ bool persist_wait(const char* ring, int idx, int lane, int& n_steps, unsigned long long& slab,
                                              unsigned long long& stats) {
     const char* addr = ring + (size_t)(idx & (kPersistRing - 1)) * 64 + (lane & 3) * 16;
-    int pause = 0;
-    for (int polls = 0; polls < kPersistMaxPolls; ++polls) {
+    for (int polls = 0; polls < kPersistIdlePolls; ++polls) {
         f4 v;
         asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
         const unsigned seq = (unsigned)__builtin_bit_cast(int, readlane_const<3>(v.w));
@@ -870,9 +863,7 @@ __device__ __forceinline__ bool persist_wait(const char* ring, int idx, int lane
             n_steps = __builtin_bit_cast(int, readlane_const<1>(v.z));
             return true;
         }
-        if ((polls & 255) == 255 && __builtin_amdgcn_readfirstlane(load_dev_i32_now(persist_abort_line(ring))) != 0) return false;
-        if (pause < 8) __builtin_amdgcn_s_sleep(1); else if (pause < 64) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(16);
-        pause += 1;
+        if (polls < 8) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4);
     }
     return false;
 }

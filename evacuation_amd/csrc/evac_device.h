@@ -719,16 +719,42 @@ __device__ __forceinline__ void rollout_body(
     }
     // PERSIST: one pass of the loop below per command; `t_base` = the steps of the commands before (the pace counters run on)
     int cmd_index = PERSIST ? chain.gen : 0, t_base = 0;
-    bool persist_lost = false;
+    if constexpr (PERSIST) {      // (a kernel that takes up where another one left: every env at the command IT had reached)
+        if (chain.resume) cmd_index = __builtin_amdgcn_readfirstlane(load_dev_i32_now(persist_next_cmd(chain.xchg) + w.env));
+    }
     for (;;) {
     if constexpr (PERSIST) {
-        unsigned long long c_slab, c_stats;
-        int c_steps;
-        if (!persist_wait(chain.xchg, cmd_index, w.lane, c_steps, c_slab, c_stats)) {     // (wave-uniform) no command came: the host is told
-            persist_lost = true;
+        unsigned long long c_slab = 0, c_stats = 0;
+        int c_steps = 0;
+        bool got = false;
+        if (cmd_index > chain.stop_at) break;           // (the finisher of a join: this env has run everything up to its STOP)
+        if constexpr (F::WPE == 1) {
+            got = persist_wait(chain.xchg, cmd_index, w.lane, c_steps, c_slab, c_stats);
+        } else {
+            // several waves per env: its first wave reads the ring, the others take ITS verdict and command at the env's barrier -- the
+            // waves of an env must not disagree on whether a command came in time
+            if (w.wave_in_env == 0) {
+                got = persist_wait(chain.xchg, cmd_index, w.lane, c_steps, c_slab, c_stats);
+                if (w.lane == 0) {
+                    int* pc = sm.persist_cmd[w.slot];
+                    pc[0] = got ? 1 : 0; pc[1] = c_steps;
+                    pc[2] = (int)(unsigned)c_slab; pc[3] = (int)(unsigned)(c_slab >> 32);
+                    pc[4] = (int)(unsigned)c_stats; pc[5] = (int)(unsigned)(c_stats >> 32);
+                }
+            }
+            F::sync(w);
+            const int* pc = sm.persist_cmd[w.slot];
+            got = __builtin_amdgcn_readfirstlane(pc[0]) != 0;
+            c_steps = __builtin_amdgcn_readfirstlane(pc[1]);
+            c_slab = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(pc[3]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(pc[2]);
+            c_stats = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(pc[5]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(pc[4]);
+            // (the next write to persist_cmd lies behind this command's steps and their barriers: no second barrier here)
+        }
+        if (!got) break;                                // IDLE: nothing came for ~150 us -- the env's state and its place in the ring are stored, the wave leaves
+        if (c_steps == 0) {                             // STOP (evac_join): consumed
+            cmd_index += 1;
             break;
         }
-        if (c_steps == 0) break;                        // STOP: evac_join
         n_steps = c_steps;
         slab_out = (float*)c_slab;
         final_stats = (evac_episode_stats_t*)c_stats;
@@ -883,12 +909,6 @@ __device__ __forceinline__ void rollout_body(
     cmd_index += 1;
     t_base += n_steps;
     }
-    if constexpr (PERSIST) {
-        if (persist_lost) {                              // (the state in registers is behind what the host has asked for: the run is void)
-            persist_give_up(chain.xchg, w.lane, cmd_index, w.env);
-            if constexpr (F::kEnvBarrier) return;        // (several waves per env: they all read the same ring and give up alike)
-        }
-    }
 #ifdef EVAC_STAMP
     unsigned long long rt1_;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1_)::"memory");
@@ -942,6 +962,9 @@ __device__ __forceinline__ void rollout_body(
         }
     } else {
         store_env(p, w.env, w.i, active, w.owner, q, e);
+        if constexpr (PERSIST) {      // where a kernel started with resume = 1 takes this env up
+            if (w.owner) store_dev_i32(persist_next_cmd(chain.xchg) + w.env, cmd_index);
+        }
     }
 #ifdef EVAC_STEP_TIMES
     if (w.lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && threadIdx.x < 1024 && n_steps > 0) {

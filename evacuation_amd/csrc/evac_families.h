@@ -66,6 +66,7 @@ struct Wave {
         float exitg[kEnvsPerBlock][2];            // gravity exit term from the lane that computed it (WPE > 1)
         int poison[2][kEnvsPerBlock];             // WPE > 1: a moving pedestrian has a NaN heading (by step parity)
         int bar[kEnvsPerBlock];                   // kEnvBarrier: arrivals at the env's own barrier (WPE per generation)
+        int persist_cmd[kEnvsPerBlock][6];        // persistent kernels, WPE > 1: the command the env's first wave read (rollout_body)
         // rollout outputs of up to kStageSteps steps, flushed with ONE 64-lane store (GRAV kernels)
         alignas(16) float stage[kEnvsPerBlock][kStageSteps][12];   // rows written as two 16-byte vectors + 1 word
         alignas(16) int progress[kPace ? 16 : 4];                  // kPace: step counter of every wave, [SIMD][wave of the SIMD]
