@@ -486,7 +486,7 @@ def side_workload(name: str, mode: str, inner: int, sweeps: int, device, traffic
     ea0.record(stream)                                        # (every launch of this entry, warm-up included: what a kernel trace of the process averages)
     for _ in range(warm):
         go()
-    env.join(stream)                                          # (a persistent kernel ends at a join only: never wait for the device with one resident)
+    env.join(stream)                                          # (the handle's own streams: the warm-up ends here)
     torch.cuda.synchronize()
     wall, dev = [], []
     for _ in range(sweeps):
@@ -819,7 +819,7 @@ def main(argv=None):
         """Opens a timed region (and, being the next one's opening, closes the previous one outside its timed region)."""
         if use_dist:
             dist.barrier()
-        if loc.own_streams:                                   # (a persistent kernel ends at a join only: a device-wide wait with it resident would wait for its time-out)
+        if loc.own_streams:                                   # (everything the handle's own streams hold belongs to the region that ends here)
             loc.join()
         torch.cuda.synchronize()
 
@@ -1493,9 +1493,9 @@ def dry_run(args, rank, world, total_envs, envs_per_gpu, K, W, inner, per_sweep,
 
 
 def _main_with_fallback():
-    """`--rollout-form auto` takes the persistent kernel on one GPU.  Its waits are bounded, and a host that is held up for longer than
-    the bound between two calls of a sweep (never seen; the bound is ~2 s) would end the run with ERR_TEAM_ABORTED: the line is then
-    measured again with chained launches, in a CHILD process (this one has an aborted handle; no exec once the GPU is in use)."""
+    """`--rollout-form auto` takes the persistent kernel on one GPU.  Should a run in that form ever end with the library's ABORTED code (the
+    chained launches' bounded waits are the only source left; the persistent kernel has none), the line is measured again with chained
+    launches, in a CHILD process (this one has an aborted handle; no exec once the GPU is in use)."""
     try:
         return main()
     except Exception as exc:  # noqa: BLE001
@@ -1503,7 +1503,7 @@ def _main_with_fallback():
         auto = "--rollout-form" not in " ".join(sys.argv[1:])
         if not (isinstance(exc, _lib.EvacError) and exc.code == _lib.ERR_TEAM_ABORTED and auto and int(os.environ.get("WORLD_SIZE", "1")) == 1):
             raise
-        print(f"bench.py: the persistent rollout kernel gave up ({exc}); measuring with chained launches instead", file=sys.stderr, flush=True)
+        print(f"bench.py: the run was aborted ({exc}); measuring with chained launches instead", file=sys.stderr, flush=True)
         import subprocess
         return subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--rollout-form", "chain"]).returncode
 

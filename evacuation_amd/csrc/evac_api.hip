@@ -130,13 +130,6 @@ int fail(evac_handle_t h, int code, const std::string& msg) {
 // A team rollout of this handle lost a member (evac_team.h): the outputs of that launch are void.  Sticky until
 // evac_team_clear_error; the handle runs the one-workgroup-per-env kernels from then on.
 int team_aborted(evac_handle_t h, const char* what) {
-    if (h->team_flag_host && *h->team_flag_host != 0u && h->persist) {
-        h->persist = false;
-        return fail(h, EVAC_ERR_TEAM_ABORTED,
-                    std::string(what) + ": the persistent rollout kernel waited in vain for its next command (more than ~2 s between two "
-                    "evac_rollout calls without an evac_join -- or the host waited for the device instead of joining) and gave up; the outputs since are void -- call evac_team_clear_error(), then reset or "
-                    "restore the batch; the handle issues plain launches from now on");
-    }
     if (h->team_flag_host && *h->team_flag_host != 0u && h->chain) {
         h->chain = false;
         return fail(h, EVAC_ERR_TEAM_ABORTED,

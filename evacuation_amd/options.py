@@ -32,7 +32,7 @@ class KernelOptions:
     team_coop: int = AUTO    # 1: cooperative launches of the team grids
     team_fault: int = AUTO   # 1: fault injection (tests)
     chain: int = 0           # 2: ONE PERSISTENT rollout kernel per ``join`` -- every launch a command of its ring, the state stays in registers
-                             #    (include/evac.h: the kernel holds the device until ``join``; never wait for the device without joining first);
+                             #    (include/evac.h: the kernel holds its CUs while it has commands and leaves by itself after ~150 us without one);
                              # 1: chained rollout launches on the handle's own two streams (include/evac.h; ``join`` as for parts = 2);
                              # -1: where it pays.  (0, not -1: the stream contract of existing callers)
     workspace: bool = True   # bind the rollout workspace (load schedule, team exchange areas); False: A/B runs without it

@@ -208,15 +208,18 @@ int evac_destroy(evac_handle_t h);
  * {steps, slab, episode records} that the host writes, through the PCIe BAR, into a ring in uncached device memory; the resident
  * kernel runs the call's steps into the call's slab and takes the next command with the state still in registers.  evac_join
  * posts STOP: the waves store their state and the kernel ends.  Every call still computes exactly its n_steps into its own
- * buffers; same bits as every other form.  Stream contract: that of parts = 2, and in addition
- *   - between the first evac_rollout and the evac_join the kernel HOLDS the CUs it runs on (all of them for a batch that fills the
- *     device): other kernels of the process wait for the join, and a host that waits for the DEVICE (hipDeviceSynchronize,
- *     hipStreamSynchronize of a stream with work queued behind the kernel) without having joined waits for the kernel's own bound;
- *   - the kernel's waits for a command are bounded (~2 s): a caller who neither calls nor joins for that long gets the error word
- *     and EVAC_ERR_TEAM_ABORTED (outputs void), as for a lost chained launch -- never a hang;
+ * buffers; same bits as every other form.  Stream contract: that of parts = 2.  What is particular to this form:
+ *   - while it has commands the kernel HOLDS the CUs it runs on (all of them for a batch that fills the device): other kernels of
+ *     the process run when it has left;
+ *   - a kernel that finds no command for ~150 us LEAVES by itself: every wave stores its env's state and the index of the command
+ *     it was waiting for, and the next evac_rollout -- or the join -- starts a kernel that takes every env up where it stopped.
+ *     So a caller may pause, wait for the device without having joined, or turn to another handle (also another one with
+ *     chain = 2): nothing hangs and nothing starves, there is no bound to exceed and no error to raise; what a gap of more than
+ *     ~150 us between two calls costs is a kernel start;
+ *   - evac_join posts STOP and enqueues, behind the resident kernel, a FINISHER kernel that runs whatever an env has not run up to
+ *     the STOP (nothing, normally: it ends at once) -- the join itself only enqueues, like every call;
  *   - calls with `actions` (and the diagnostic faces) join and run as one kernel on `stream`; more than ~1000 calls without a
- *     join make the library stop the kernel, wait for it on the host and start the next one;
- *   - one such handle at a time per device may have its kernel resident (a second one's kernel starts when the first has joined).
+ *     join make the library stop the kernel, wait for it on the host and start the next one.
  * evac_own_streams: 0, or 2 for handles with parts = 2, chain = 1 or chain = 2. */
 int evac_join(evac_handle_t h, void* stream);
 /* The NEXT evac_rollout call puts the handle's own streams behind what its `stream` holds at that moment, as the first call after a
