@@ -1323,9 +1323,12 @@ def main(argv=None):
                              "expected_kernel_trace_avg_duration_ms": (launches_per_sweep if persistent else max(1, loc.own_streams)) * (sum(sweep_dev) + sum(sustain_dev)) * 1e3
                                                                       / max(1, (len(sweep_dev) + len(sustain_dev)) * launches_per_sweep),
                              "note": ("for a reader with the kernel trace of this command: ONE PERSISTENT rollout kernel per sweep carries all its "
-                                      f"{launches_per_sweep} calls, so the trace's average DURATION of the rollout kernel is the sweep (expected_kernel_trace_avg_duration_ms) and "
-                                      "the call period is that over the calls of a sweep; mean_period_ms_all_sweeps is over every timed sweep (headline + "
-                                      "sustained), round_ms the settled median `value` uses") if persistent else
+                                      f"{launches_per_sweep} calls, so the DURATION of a resident kernel is the sweep (expected_kernel_trace_avg_duration_ms) and "
+                                      "the call period is that over the calls of a sweep.  The trace lists further kernels of the same name: the FINISHER that "
+                                      "every evac_join enqueues behind the resident kernel (a few us: it finds nothing left to run) and the single-call kernels "
+                                      "of the warm-up and of the diagnostics -- so the per-name AVERAGE of a kernel_stats table is not the sweep; "
+                                      "tools/chain_timeline.py separates them (profiles/*_timeline.txt: the whole-sweep kernels' mean and median duration).  "
+                                      "mean_period_ms_all_sweeps is over every timed sweep (headline + sustained), round_ms the settled median `value` uses") if persistent else
                                      "for a reader with the kernel trace of this command: a CHAINED launch is enqueued behind its queue's previous launch and "
                                      "ends two launch periods later (its queue carries every second launch), so the trace's average DURATION of the "
                                      "rollout kernel is kernels_in_flight x the launch period, and the period itself is the trace's start-to-start "

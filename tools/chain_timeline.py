@@ -22,8 +22,10 @@ print(f"kernel: {name[:150]}")
 if "persist" in name:
     calls = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     du_ = sorted((E[i] - S[i]) for i in range(len(r)))
-    full = [x for x in du_ if x > 0.5 * du_[len(du_) // 2]]            # (whole sweeps: warm-up and single-call kernels of the diagnostics left out)
-    print(f"persistent kernels: {len(r)} in the trace, {len(full)} of them whole sweeps (the others: single calls of the warm-up and of the diagnostics); "
+    full = [x for x in du_ if x > 0.5 * du_[len(du_) * 9 // 10]]       # (whole sweeps: the joins' finishers -- a few us each --, the warm-up and the single-call kernels of the diagnostics left out)
+    short = [x for x in du_ if x < 30.0]
+    print(f"persistent kernels: {len(r)} in the trace, {len(full)} of them whole sweeps (the others: {len(short)} of under 30 us -- the finishers behind the joins, median "
+          f"{st.median(short) if short else 0.0:.1f} us -- and single calls of the warm-up and of the diagnostics); "
           f"duration of a whole sweep [us]: mean {st.mean(full):.1f}, median {st.median(full):.1f}")
     if calls:
         print(f"  = {st.mean(full) / calls:.2f} (mean) / {st.median(full) / calls:.2f} (median) us per call, {calls} calls per kernel: kernel start, the calls' steps and STOP; "
