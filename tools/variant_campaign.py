@@ -28,3 +28,20 @@ for c in range(cases):
     if c % 10 == 9:
         print(f"{c + 1} cases ok ({time.time() - t0:.0f} s)", flush=True)
 print(f"CAMPAIGN OK: {cases} cases, {fam.get((True, True), 0)} with teams, {fam.get((False, True), 0)} multi-wave, {fam.get((False, False), 0)} one-wave / sub-wave")
+# ... and the forms with launches in flight (evac_options_t.chain = 1 / 2): bursts of launches of random lengths without a join against one
+# plain launch after the other (tests/test_gpu_variants_sweep.py::test_launches_in_flight_equal_one_launch_after_the_other), fresh random shapes
+flying = int(sys.argv[3]) if len(sys.argv) > 3 else cases // 3
+t1, forms = time.time(), {1: 0, 2: 0}
+for c in range(flying):
+    if rng.integers(0, 3) == 0:
+        n, E = int(rng.choice([130, 200, 256])), 4 * int(rng.integers(2, 64))
+    else:
+        n, E = int(rng.choice([33, 48, 60, 64])), 16 * int(rng.integers(2, 64))
+    mode = str(rng.choice(["grav", "grav", "relbox", "absdict"]))
+    ens = float(rng.choice([1.0, 1.0, 0.5]))
+    form = int(rng.integers(1, 3))
+    S.test_launches_in_flight_equal_one_launch_after_the_other(ea, n, E, mode, ens, form, int(rng.integers(0, 1 << 30)))
+    forms[form] += 1
+    if c % 25 == 24:
+        print(f"{c + 1} bursts-in-flight cases ok ({time.time() - t1:.0f} s)", flush=True)
+print(f"CAMPAIGN OK: {flying} cases with launches in flight: {forms[1]} chained, {forms[2]} persistent")
