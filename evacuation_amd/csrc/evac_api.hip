@@ -216,6 +216,14 @@ const void* team_kernel(const evac_handle* h) {
     return h->team_k == 16 ? EVAC_TEAM_FN(16) : (h->team_k == 8 ? EVAC_TEAM_FN(8) : (h->team_k == 4 ? EVAC_TEAM_FN(4) : EVAC_TEAM_FN(2)));
 #undef EVAC_TEAM_FN
 }
+const void* team_persist_kernel(const evac_handle* h) {
+    const bool grav = h->p.obs_pos == EVAC_POS_GRAV, dflt = h->default_cfg;
+#define EVAC_TEAM_FN(K_)                                                                                                          \
+    (dflt ? (grav ? (const void*)evac::k_rollout_persist_default_config<evac::Team<K_>, true> : (const void*)evac::k_rollout_persist_default_config<evac::Team<K_>, false>) \
+          : (grav ? (const void*)evac::k_rollout_persist<evac::Team<K_>, true> : (const void*)evac::k_rollout_persist<evac::Team<K_>, false>))
+    return h->team_k == 16 ? EVAC_TEAM_FN(16) : (h->team_k == 8 ? EVAC_TEAM_FN(8) : (h->team_k == 4 ? EVAC_TEAM_FN(4) : EVAC_TEAM_FN(2)));
+#undef EVAC_TEAM_FN
+}
 unsigned team_grid(const evac_handle* h) {
     // (EVAC_TEAM_FAULT=1, fault injection for tests/test_gpu_team.py: the last workgroup is never launched, so the team it
     // belongs to loses a member and must time out, flag the error and leave its env's state alone)
@@ -671,7 +679,31 @@ int launch_persistent(evac_handle* h, int resume, int stop_at, bool fresh) {
     if (deals) h->sched_gen = g_ + 1;
     evac::ChainArgs ca{h->chain_xchg, h->persist_seq, nullptr, nullptr, 0, nullptr, resume, stop_at};
 #define EVAC_PERSIST_ARGS h->p, (const int*)perm, (int*)moving, (const int*)deal_loads, (int*)deal_perm, ca
-    if (h->cu_wide4) {
+    if (h->team_k) {
+        // a team grid (evac_team.h): the exchange area starts with the tag of no round, the teams' verdicts at zero; team grids of one
+        // device take turns (g_team_chain), whatever handle or stream they come from
+        int32_t* decision = (int32_t*)(h->chain_xchg + (size_t)evac::kPersistRing * 64 + 128) + E;
+        if (hipMemsetAsync(h->p.team_rec, 0xff, h->team_xchg_bytes, S) != hipSuccess || hipMemsetAsync(decision, 0, 4 * (size_t)E, S) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(h, EVAC_ERR_HIP, "evac_rollout (persistent team kernel): hipMemsetAsync failed");
+        }
+        const dim3 grid(team_grid(h)), block(1024);
+        const int* np_ = nullptr;
+        int* nq_ = nullptr;
+        void* argv[] = {(void*)&h->p, (void*)&np_, (void*)&nq_, (void*)&np_, (void*)&nq_, (void*)&ca};
+        const bool chained = h->device >= 0 && h->device < kMaxDevices;
+        std::unique_lock<std::mutex> chain(g_team_chain_lock, std::defer_lock);
+        if (chained) {
+            chain.lock();
+            hipEvent_t& ev = g_team_chain[h->device];
+            if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev = nullptr; }
+            if (ev && hipStreamWaitEvent(S, ev, 0) != hipSuccess) (void)hipGetLastError();
+        }
+        const hipError_t le = hipLaunchKernel(team_persist_kernel(h), grid, block, argv, 0, S);
+        if (chained && g_team_chain[h->device] && le == hipSuccess && hipEventRecord(g_team_chain[h->device], S) != hipSuccess) (void)hipGetLastError();
+        if (chained) chain.unlock();
+        if (le != hipSuccess) return fail(h, EVAC_ERR_HIP, std::string("evac_rollout (persistent team kernel): ") + hipGetErrorString(le));
+    } else if (h->cu_wide4) {
         const dim3 grid((unsigned)(E / FW4::kEnvsPerBlock));
         if (h->default_cfg && h->p.obs_pos == EVAC_POS_GRAV)
             hipLaunchKernelGGL((evac::k_rollout_persist_default_config<FW4, true>), grid, dim3(FW4::kBlock), 0, S, EVAC_PERSIST_ARGS);
@@ -765,7 +797,8 @@ int evac_create_ex(const evac_config_t* cfg, int32_t num_envs, int32_t device, u
         int large_bar = 0;
         if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess) { (void)hipGetLastError(); large_bar = 0; }
         const int per_wg = h->cu_wide4 ? 4 : 16;
-        const bool fits = (h->cu_wide || h->cu_wide4) && num_envs % per_wg == 0 && num_envs / per_wg <= h->cus;
+        // (teams -- one env on K CUs: the grid's fit is checked where it is for plain team launches, at the call, once the exchange areas are bound)
+        const bool fits = ((h->cu_wide || h->cu_wide4) && num_envs % per_wg == 0 && num_envs / per_wg <= h->cus) || (h->team_k != 0 && !h->team_fault);
         bool ok = large_bar != 0 && fits && make_part_streams(h);
         if (ok) {
             DeviceGuard g(device);
@@ -775,7 +808,7 @@ int evac_create_ex(const evac_config_t* cfg, int32_t num_envs, int32_t device, u
             if (ok) { h->team_flag_host = (volatile unsigned*)host; h->team_flag_dev = (unsigned*)dev; }
             ok = ok && hipEventCreateWithFlags(&h->chain_ev, hipEventDisableTiming) == hipSuccess;      // (behind every persistent kernel: has it left?)
             void* ring = nullptr;
-            const size_t rbytes = (size_t)evac::kPersistRing * 64 + 128 + 4 * (size_t)num_envs;      // the ring, a line of diagnostics, next_cmd[E]
+            const size_t rbytes = (size_t)evac::kPersistRing * 64 + 128 + 8 * (size_t)num_envs;      // the ring, a line of diagnostics, next_cmd[E], decision[E] (teams)
             if (ok) { ring = take_uncached(device, rbytes, &h->chain_xchg_bytes); ok = ring != nullptr; }
             if (ok && (hipMemset(ring, 0, rbytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) { (void)hipGetLastError(); ok = false; }
             h->chain_xchg = (char*)ring;
@@ -881,7 +914,13 @@ void* evac_part_stream(evac_handle_t h, int32_t part) { return (h && evac_own_st
 const char* evac_kernel_variant(evac_handle_t h, int32_t rollout) {
     if (!h) return "";
     if (!rollout) return h->variant[0].c_str();
-    if (h->n_parts > 1 || (h->chain && h->chain_bound) || h->persist) return h->variant[3].c_str();
+    if (h->persist) {          // (teams: the persistent form of the team kernel, once its exchange areas are bound and its grid fits)
+        const bool team = h->team_k && h->team_bound && h->team_fit != 0;
+        if (h->team_k && !team) return h->variant[1].c_str();
+        h->variant[3] = h->variant[team ? 2 : 1] + ", one persistent kernel per join";
+        return h->variant[3].c_str();
+    }
+    if (h->n_parts > 1 || (h->chain && h->chain_bound)) return h->variant[3].c_str();
     // the path evac_rollout takes right now: teams only with their exchange areas bound and a grid that fits the device
     return h->variant[(h->team_k && h->team_bound && h->team_fit != 0) ? 2 : 1].c_str();
 }
@@ -1196,7 +1235,7 @@ int evac_rollout(evac_handle_t h, int32_t n_steps, const float* actions, float* 
         }
         return EVAC_OK;
     }
-    if (h->persist && !(capture || actions_out || noise || actions)) {
+    if (h->persist && !(capture || actions_out || noise || actions) && (!h->team_k || (h->team_bound && team_grid_fits(h)))) {
         hipStream_t s_ = (hipStream_t)stream;
         hipStreamCaptureStatus pcap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s_, &pcap) != hipSuccess) { (void)hipGetLastError(); pcap = hipStreamCaptureStatusNone; }

@@ -847,6 +847,19 @@ constexpr int kPersistIdlePolls = 256;           // a wave that finds no command
 // (behind the ring, in the same allocation: a 128-byte line of diagnostics, then next_cmd[E] -- per env, the index of the first command it
 // has NOT run; written by a leaving wave, read by the waves of a kernel started with resume = 1)
 __device__ __forceinline__ int* persist_next_cmd(const char* ring) { return (int*)(ring + (size_t)kPersistRing * 64 + 128); }
+// TEAMS (one env on K workgroups): the members read the ring each for itself, and must not disagree on whether command idx came in time
+// -- one that runs it would wait in the team's exchange for one that has left.  decision[env] (behind next_cmd[E], zeroed before every
+// kernel) holds the team's verdict for the r-th command of this kernel (r = 1, 2, ...): 2 r + 1 = run it, 2 r = leave before it; the first
+// member to have an outcome of its own makes it the team's (compare-and-swap from the verdict of command r - 1, which was "run"), the
+// others take it: a member that found nothing keeps reading until the command it was told to run shows, one that found the command after
+// the team has left discards it (it stays in the ring for the kernel that resumes).
+__device__ __forceinline__ int* persist_decision(const char* ring, int n_envs) { return persist_next_cmd(ring) + n_envs; }
+__device__ __forceinline__ int persist_team_decide(int* word, int r, bool mine_run) {
+    int expected = r == 1 ? 0 : 2 * (r - 1) + 1;
+    const int want = 2 * r + (mine_run ? 1 : 0);
+    if (__hip_atomic_compare_exchange_strong(word, &expected, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return want;
+    return expected;          // (what another member decided: 2 r or 2 r + 1)
+}
 // Wait for command `idx` (sequence number idx + 1) of the ring.  Wave-uniform results.  false: none came within the idle bound.
 __device__ __forceinline__ bool persist_wait(const char* ring, int idx, int lane, int& n_steps, unsigned long long& slab,
                                              unsigned long long& stats) {

@@ -722,13 +722,40 @@ __device__ __forceinline__ void rollout_body(
     if constexpr (PERSIST) {      // (a kernel that takes up where another one left: every env at the command IT had reached)
         if (chain.resume) cmd_index = __builtin_amdgcn_readfirstlane(load_dev_i32_now(persist_next_cmd(chain.xchg) + w.env));
     }
+    [[maybe_unused]] const int cmd_first = cmd_index;   // (teams: their verdicts are numbered from the kernel's first command)
     for (;;) {
     if constexpr (PERSIST) {
         unsigned long long c_slab = 0, c_stats = 0;
         int c_steps = 0;
         bool got = false;
         if (cmd_index > chain.stop_at) break;           // (the finisher of a join: this env has run everything up to its STOP)
-        if constexpr (F::WPE == 1) {
+        if constexpr (F::kHelpers) {
+            if (F::aborted(w)) break;                   // (a team that lost a member in the command before: void, nothing more is run)
+            // a team: every member workgroup reads the ring through its first wave, and the TEAM decides once (evac_common.h)
+            if (w.wave == 0) {
+                got = persist_wait(chain.xchg, cmd_index, w.lane, c_steps, c_slab, c_stats);
+                int verdict = 0;
+                if (w.lane == 0) verdict = persist_team_decide(persist_decision(chain.xchg, p.n_envs) + w.env, cmd_index - cmd_first + 1, got);
+                verdict = __builtin_amdgcn_readfirstlane(verdict);
+                const bool run = (verdict & 1) != 0;
+                if (run && !got)                        // the team runs it: it is in the ring, or about to show
+                    for (int tries = 0; tries < 8192 && !got; ++tries) got = persist_wait(chain.xchg, cmd_index, w.lane, c_steps, c_slab, c_stats);
+                if (!run) got = false;                  // the team has left before this command
+                if (w.lane == 0) {
+                    int* pc = sm.persist_cmd[0];
+                    pc[0] = got ? 1 : 0; pc[1] = c_steps;
+                    pc[2] = (int)(unsigned)c_slab; pc[3] = (int)(unsigned)(c_slab >> 32);
+                    pc[4] = (int)(unsigned)c_stats; pc[5] = (int)(unsigned)(c_stats >> 32);
+                }
+            }
+            __syncthreads();
+            const int* pc = sm.persist_cmd[0];
+            got = __builtin_amdgcn_readfirstlane(pc[0]) != 0;
+            c_steps = __builtin_amdgcn_readfirstlane(pc[1]);
+            c_slab = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(pc[3]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(pc[2]);
+            c_stats = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(pc[5]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(pc[4]);
+            // (the next write to persist_cmd lies behind this command's steps and their workgroup barriers)
+        } else if constexpr (F::WPE == 1) {
             got = persist_wait(chain.xchg, cmd_index, w.lane, c_steps, c_slab, c_stats);
         } else {
             // several waves per env: its first wave reads the ring, the others take ITS verdict and command at the env's barrier -- the

@@ -104,6 +104,7 @@ struct Team {
         int segcnt[WPE];                      // entries | NaN headings << 16 of segment w, counted by the wave that fetched it
         i2 totals;                            // entries of the tile, NaN headings among them
         alignas(16) float stage[1][kStageSteps][12];
+        int persist_cmd[1][6];                // persistent kernels: the command this member's first wave read and the team agreed on (rollout_body)
     };
 
     struct Ctx {

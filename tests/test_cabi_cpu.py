@@ -217,6 +217,8 @@ def test_kernel_resource_budgets():
         assert sum(fam in n and "k_rollout<" in n for n in names) == 2 and sum(fam in n and "k_rollout_default_config<" in n for n in names) == 2
     # chained launches: one-wave envs in 256-thread and in CU-wide workgroups, four-wave envs in CU-wide workgroups; 2 observation faces each
     assert sum("k_rollout_chain<" in n for n in names) == 6 and sum("k_rollout_chain_default_config<" in n for n in names) == 6
-    # one persistent kernel per join: the CU-wide families of one- and four-wave envs, 2 observation faces, generic + default configuration
-    assert sum("k_rollout_persist<" in n for n in names) == 4 and sum("k_rollout_persist_default_config<" in n for n in names) == 4
+    # one persistent kernel per join: the CU-wide families of one- and four-wave envs and the four team sizes, 2 observation faces,
+    # generic + default configuration
+    assert sum("k_rollout_persist<" in n for n in names) == 12 and sum("k_rollout_persist_default_config<" in n for n in names) == 12
+    assert sum("Team<" in n and "k_rollout_persist" in n for n in names) == 16
     assert sum("k_rollout_default_config" in n for n in names) >= 30 and sum("k_step_default_config" in n for n in names) >= 20

@@ -602,6 +602,9 @@ def _where_slabs_differ(outs, refs, replay=None):
     (33, 64, dict(positions="rel", statuses="ohe", type="Box"), 10, 1, 2),
     (256, 1024, dict(positions="grav", alpha=3), 20, 1, 2),
     (200, 52, dict(positions="rel", statuses="ohe", type="Box"), 6, 1, 2),
+    # ... of TEAMS (one env on 8 / 16 CUs): the members of a team agree on every command (BASELINE config 5's shard; a gravity face)
+    (1024, 32, dict(positions="rel", statuses="ohe", type="Box"), 6, -1, 2),
+    (700, 11, dict(positions="grav", alpha=3), 9, -1, 2),
 ])
 def test_chained_launches_equal_plain_launches(ea, n, E, wrap_kw, T, wide, form):
     """evac_options_t.chain = 1: consecutive rollout launches on two queues, ordered per env by generation
@@ -614,7 +617,10 @@ def test_chained_launches_equal_plain_launches(ea, n, E, wrap_kw, T, wide, form)
     ch = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=11, options=ea.KernelOptions(cu_wide=wide, chain=form))
     assert ch.own_streams == 2 and ch.num_parts == 1 and ch.resolved_options().chain == form
     assert ("chained" if form == 1 else "persistent") in ch.kernel_variant()
-    assert ("CU-wide" in ch.kernel_variant()) == bool(wide)
+    if wide >= 0:
+        assert ("CU-wide" in ch.kernel_variant()) == bool(wide)
+    else:
+        assert "CUs/env" in ch.kernel_variant(), ch.kernel_variant()
     assert one.own_streams == 0
     one.reset(); ch.reset()
     D = one.obs_dim
@@ -693,11 +699,12 @@ def test_a_persistent_kernel_left_without_commands_leaves_and_is_taken_up_again(
     import time
     import torch
     wrap = ea.EnvWrappersConfig(positions="grav", alpha=3)
-    for E, n in ((64, 60), (4096, 60), (24, 200)):               # a corner of the device; every CU; four-wave envs
+    for E, n in ((64, 60), (4096, 60), (24, 200), (12, 1024)):   # a corner of the device; every CU; four-wave envs; teams of 16 CUs
         cfg_ = ea.EnvConfig(number_of_pedestrians=n, max_timesteps=100, is_new_exiting_reward=True, is_new_followers_reward=True)
-        one = ea.BatchedEvacuationEnv(cfg_, wrap, num_envs=E, seed=3, options=ea.KernelOptions(cu_wide=1))
-        ch = ea.BatchedEvacuationEnv(cfg_, wrap, num_envs=E, seed=3, options=ea.KernelOptions(cu_wide=1, chain=2))
-        other = ea.BatchedEvacuationEnv(cfg_, wrap, num_envs=E, seed=4, options=ea.KernelOptions(cu_wide=1, chain=2))      # a second persistent handle
+        cw = 1 if n <= 256 else -1
+        one = ea.BatchedEvacuationEnv(cfg_, wrap, num_envs=E, seed=3, options=ea.KernelOptions(cu_wide=cw))
+        ch = ea.BatchedEvacuationEnv(cfg_, wrap, num_envs=E, seed=3, options=ea.KernelOptions(cu_wide=cw, chain=2))
+        other = ea.BatchedEvacuationEnv(cfg_, wrap, num_envs=E, seed=4, options=ea.KernelOptions(cu_wide=cw, chain=2))      # a second persistent handle
         assert "persistent" in ch.kernel_variant() and "persistent" in other.kernel_variant()
         one.reset(); ch.reset(); other.reset()
         T, R = 4, 9

@@ -52,7 +52,9 @@ for name, n, E, wrap_kw, T, opts in (("C2 chained, 20-step launches", 60, 4096, 
                                      ("C2 persistent, 20-step calls", 60, 4096, dict(positions="grav", alpha=3), 20, dict(chain=2)),
                                      ("C2 persistent, 7-step calls", 60, 4096, dict(positions="grav", alpha=3), 7, dict(chain=2)),
                                      ("C3 persistent, 20-step calls", 256, 1024, dict(positions="grav", alpha=3), 20, dict(chain=2)),
-                                     ("N = 40 x 512 persistent (Box obs)", 40, 512, dict(positions="rel", statuses="ohe", type="Box"), 10, dict(cu_wide=1, chain=2))):
+                                     ("N = 40 x 512 persistent (Box obs)", 40, 512, dict(positions="rel", statuses="ohe", type="Box"), 10, dict(cu_wide=1, chain=2)),
+                                     ("C5 teams of 8, persistent", 1024, 32, dict(positions="rel", statuses="ohe", type="Box"), 20, dict(chain=2)),
+                                     ("teams of 16, persistent (grav)", 1024, 9, dict(positions="grav", alpha=3), 7, dict(chain=2))):
     cfg = ea.EnvConfig(number_of_pedestrians=n, is_new_exiting_reward=True, is_new_followers_reward=True, max_timesteps=700)
     wrap = ea.EnvWrappersConfig(**wrap_kw)
     a = ea.BatchedEvacuationEnv(cfg, wrap, num_envs=E, seed=123, options=ea.KernelOptions(cu_wide=0, workspace=False))
