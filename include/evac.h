@@ -154,7 +154,8 @@ int evac_create(const evac_config_t* cfg, int32_t num_envs, int32_t device, uint
  *   chain       1: CHAINED rollout launches (CU-wide handles with a bound workspace; see below); 0: never; -1: where it
  *               pays (those handles).  Wins over `parts`.  evac_create() always takes 0, like parts = 1.
  *               2: ONE PERSISTENT KERNEL PER JOIN (see below; on request only -- the kernel holds the device until evac_join);
- *               where it cannot be had (no CU-wide family, a batch of more workgroups than the device has CUs, no large BAR) the
+ *               (the CU-wide kernels of one- and four-wave envs, and the team kernels of rooms of more than 512 pedestrians);
+ *               where it cannot be had (no such family, a batch of more workgroups than the device has CUs, no large BAR) the
  *               handle falls back to 1, then 0: evac_get_options says what it became. */
 typedef struct evac_options {
     int32_t subwave, cells, cu_wide, team, specialize, parts, team_coop, team_fault, chain;
