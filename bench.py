@@ -1382,7 +1382,10 @@ def main(argv=None):
                       "handle owns; a sweep is closed by evac_join on the timing stream; roofline.achieved = the whole batch's "
                       "algorithmic bytes per round of launches / the round's period (round_ms = kernel_ms_per_launch), "
                       "part_stream_ms_per_launch = the launch period of each of the two streams") if loc.num_parts > 1 else
-                     "one kernel per rollout call on the launching stream")}
+                     "one kernel per rollout call on the launching stream" +
+                     (" (an N > 1 line runs plain launches beside its gathers -- the gather of chunk j - 1 under chunk j needs CUs that a resident or "
+                      "a waiting chained kernel would hold --; the like-for-like N = 1 line for a scaling ratio is `--rollout-form one`, not the "
+                      "N = 1 default's persistent kernel)" if world > 1 else ""))}
         out["cpu_baseline"] = cpu_base
         if side is not None:
             out["workloads"] = side
